@@ -1,0 +1,103 @@
+"""ctypes binding of libbm_gar.so (declared in include/bm_gar.h).
+
+`import torch` must precede the CDLL so that the loader resolves our DT_NEEDED
+libamdhip64.so.7 to the copy torch has already mapped (one HIP runtime per process,
+streams and device pointers are then shared with torch).
+
+There is NO fallback: if the library is missing or does not load, every product entry
+point raises.  The CPU oracle under oracle/ is test infrastructure and is never used here.
+"""
+
+import ctypes
+import pathlib
+
+import torch  # noqa: F401  (must be imported before the CDLL, see above)
+
+_PKG_DIR = pathlib.Path(__file__).resolve().parent
+LIB_PATH = _PKG_DIR / "libbm_gar.so"
+
+ABI_VERSION = 1
+MAX_ROWS = 64
+EINVAL = -100000
+
+OP_MEDIAN, OP_TRMEAN, OP_PHOCAS, OP_MEAMED = 0, 1, 2, 3
+WS_PAIRWISE, WS_AKSEL, WS_STATS, WS_DOT = 0, 1, 2, 3
+RANK_KRUM, RANK_BULYAN = 0, 1
+
+_c_float_pp = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> (restype, argtypes); mirrors include/bm_gar.h one to one
+SIGNATURES = {
+  "bm_abi_version": (ctypes.c_int, []),
+  "bm_error_string": (ctypes.c_char_p, [ctypes.c_int]),
+  "bm_colwise": (ctypes.c_int, [ctypes.c_int, _c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                ctypes.c_void_p, ctypes.c_void_p]),
+  "bm_workspace_bytes": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
+  "bm_pairwise_sqdist": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p,
+                                        ctypes.c_void_p, ctypes.c_void_p]),
+  "bm_krum_rank": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+  "bm_selected_mean": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+  "bm_bulyan_pass2": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+  "bm_aksel_pass1": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p,
+                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+  "bm_stack_stats": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p,
+                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+  "bm_multi_dot": (ctypes.c_int, [_c_float_pp, ctypes.c_int, _c_float_pp, ctypes.c_int, ctypes.c_int64,
+                                  ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+  "bm_stable_argsort": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+  "bm_multi_axpby": (ctypes.c_int, [_c_float_pp, _c_float_pp, ctypes.c_int, ctypes.c_int64,
+                                    ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),
+  "bm_brute_select": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+}
+
+
+class NativeLibraryError(RuntimeError):
+  """libbm_gar.so is missing, stale or failed to load: the HIP path cannot run."""
+
+
+_lib = None
+
+
+def load():
+  """Load (once) and return the ctypes handle; raise NativeLibraryError on any problem."""
+  global _lib
+  if _lib is not None:
+    return _lib
+  if not LIB_PATH.exists():
+    raise NativeLibraryError(
+      f"{LIB_PATH} not found: build it with `python -m byzantinemomentum_amd.build` "
+      "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+  try:
+    lib = ctypes.CDLL(str(LIB_PATH))
+  except OSError as err:
+    raise NativeLibraryError(f"cannot load {LIB_PATH}: {err}") from err
+  for name, (restype, argtypes) in SIGNATURES.items():
+    try:
+      fn = getattr(lib, name)
+    except AttributeError as err:
+      raise NativeLibraryError(f"{LIB_PATH} does not export {name!r} (stale build?)") from err
+    fn.restype = restype
+    fn.argtypes = argtypes
+  if lib.bm_abi_version() != ABI_VERSION:
+    raise NativeLibraryError(
+      f"{LIB_PATH} has ABI {lib.bm_abi_version()}, host code expects {ABI_VERSION}: rebuild")
+  _lib = lib
+  return lib
+
+
+def check(code, what):
+  """Turn a negative status of an entry point into a RuntimeError."""
+  if code != 0:
+    msg = load().bm_error_string(code).decode("utf-8", "replace")
+    raise RuntimeError(f"libbm_gar {what} failed: {msg} (code {code})")
+
+
+def pointer_table(tensors):
+  """Host array of device pointers for a list of tensors (aliased entries allowed)."""
+  arr = (ctypes.c_void_p * len(tensors))()
+  for i, t in enumerate(tensors):
+    arr[i] = t.data_ptr()
+  return arr

@@ -1,0 +1,189 @@
+// bm_common.h — shared device/host helpers for libbm_gar.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <utility>
+#include "../../include/bm_gar.h"
+
+namespace bm {
+
+// Row pointer table passed BY VALUE in the kernarg segment (512 B): no H2D copy,
+// no host sync, indexable with compile-time indices (s_load from kernarg) or with a
+// wave-uniform runtime index.  Replaces torch.stack (aggregators/median.py:39,
+// trmean.py:79) — the n x d copy is never made.
+struct RowTable {
+  const float* p[BM_MAX_ROWS];
+};
+struct MutRowTable {
+  float* p[BM_MAX_ROWS];
+};
+
+static inline int hip_code(hipError_t e) { return e == hipSuccess ? 0 : -(int)e; }
+
+#define BM_LAUNCH_CHECK()                      \
+  do {                                         \
+    hipError_t e__ = hipGetLastError();        \
+    if (e__ != hipSuccess) return hip_code(e__); \
+  } while (0)
+
+// ---------------------------------------------------------------------------
+// Compile-time sorting network: Knuth's merge-exchange (TAOCP 5.2.2, Alg. M),
+// valid for every N (not only powers of two).  The comparator list is a
+// constexpr table so that every register index is a compile-time constant and
+// the n values of a column stay in VGPRs.  Unused outputs are removed by the
+// compiler's DCE, which turns the sorter into a selection network for the
+// median for free.
+// ---------------------------------------------------------------------------
+template <int N>
+struct MergeExchange {
+  static constexpr int kMax = (N < 2) ? 1 : (N * 10);  // generous upper bound on #comparators
+  struct Table {
+    short a[kMax];
+    short b[kMax];
+    int count;
+  };
+  static constexpr Table make() {
+    Table t{};
+    t.count = 0;
+    if (N < 2) return t;
+    int tt = 0;
+    while ((1 << tt) < N) ++tt;
+    for (int p = 1 << (tt - 1); p > 0; p /= 2) {
+      int q = 1 << (tt - 1), r = 0, d = p;
+      while (true) {
+        for (int i = 0; i < N - d; ++i)
+          if ((i & p) == r) {
+            t.a[t.count] = (short)i;
+            t.b[t.count] = (short)(i + d);
+            ++t.count;
+          }
+        if (q == p) break;
+        d = q - p;
+        q /= 2;
+        r = p;
+      }
+    }
+    return t;
+  }
+  static constexpr Table table = make();
+};
+
+__device__ __forceinline__ void cmp_exchange(float& a, float& b) {
+  const float lo = fminf(a, b);
+  const float hi = fmaxf(a, b);
+  a = lo;
+  b = hi;
+}
+
+template <int N, size_t... I>
+__device__ __forceinline__ void sort_network_impl(float (&x)[N], std::index_sequence<I...>) {
+  (cmp_exchange(x[MergeExchange<N>::table.a[I]], x[MergeExchange<N>::table.b[I]]), ...);
+}
+
+// Ascending in-register sort of x[0..N).  Inputs must be NaN-free (v_min/v_max drop NaNs).
+template <int N>
+__device__ __forceinline__ void sort_network(float (&x)[N]) {
+  if constexpr (N >= 2)
+    sort_network_impl<N>(x, std::make_index_sequence<MergeExchange<N>::table.count>{});
+}
+
+// Correctly rounded x / m for a small positive integer m given rm = 1.0f/m (Markstein
+// correction): three VALU ops instead of the ~10-op IEEE division sequence, same bits as
+// torch's `.div_(m)` (aggregators/krum.py:80, bulyan.py:70) except for subnormal quotients.
+__device__ __forceinline__ float div_small_int(float x, float m, float rm) {
+  const float q = x * rm;
+  const float r = __builtin_fmaf(-q, m, x);
+  const float q1 = __builtin_fmaf(r, rm, q);
+  // inf/nan inputs: r is nan, keep the plain product
+  return (q1 == q1) ? q1 : q;
+}
+
+// 16/8/4-byte streaming loads of data that is read exactly once (non-temporal: do not
+// displace useful lines from L2 / Infinity Cache).
+template <int VEC>
+struct VecLoad;
+template <>
+struct VecLoad<4> {
+  using T = float __attribute__((ext_vector_type(4)));
+};
+template <>
+struct VecLoad<2> {
+  using T = float __attribute__((ext_vector_type(2)));
+};
+template <>
+struct VecLoad<1> {
+  using T = float;
+};
+
+template <int VEC>
+__device__ __forceinline__ void load_stream(const float* p, float (&dst)[VEC]) {
+  using T = typename VecLoad<VEC>::T;
+  const T v = __builtin_nontemporal_load(reinterpret_cast<const T*>(p));
+  if constexpr (VEC == 1) {
+    dst[0] = v;
+  } else {
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) dst[c] = v[c];
+  }
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_stream(float* p, const float (&src)[VEC]) {
+  using T = typename VecLoad<VEC>::T;
+  T v;
+  if constexpr (VEC == 1) {
+    v = src[0];
+  } else {
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) v[c] = src[c];
+  }
+  __builtin_nontemporal_store(v, reinterpret_cast<T*>(p));
+}
+
+// Largest vector width (4, 2 or 1 floats) every pointer of the table and `extra` allow.
+static inline int common_vec_width(const void* const* ptrs, int n, const void* extra) {
+  uintptr_t bits = reinterpret_cast<uintptr_t>(extra);
+  for (int i = 0; i < n; ++i) bits |= reinterpret_cast<uintptr_t>(ptrs[i]);
+  if ((bits & 15u) == 0) return 4;
+  if ((bits & 7u) == 0) return 2;
+  return 1;
+}
+
+// Grid size for a streaming kernel: enough workgroups to fill 256 CUs several times over,
+// capped so that the grid-stride loop amortises launch/tail effects.
+static inline int stream_grid(int64_t work_items, int block, int max_blocks) {
+  int64_t g = (work_items + block - 1) / block;
+  if (g < 1) g = 1;
+  if (g > max_blocks) g = max_blocks;
+  return (int)g;
+}
+
+// Deterministic block reduction (sum) of one double per thread; result valid on thread 0.
+template <int BLOCK>
+__device__ __forceinline__ double block_reduce_sum(double v, double* lds /* BLOCK/64 doubles */) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) lds[wave] = v;
+  __syncthreads();
+  double r = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < BLOCK / 64; ++w) r += lds[w];
+  }
+  __syncthreads();
+  return r;
+}
+
+}  // namespace bm
+
+namespace bm {
+// Launch-shape knobs, read once from the environment (experiments only; defaults are the
+// measured best on MI355X).
+struct Tuning {
+  int force_vec;       // BM_FORCE_VEC: 0 auto, 1 or 2 force a narrower column vector
+  int col_max_blocks;  // BM_COL_MAX_BLOCKS: grid cap of the column kernels
+  int pair_blocks;     // BM_PAIR_BLOCKS: persistent grid of the pairwise-distance kernel
+};
+const Tuning& tuning();
+}  // namespace bm

@@ -1,0 +1,343 @@
+// bulyan.hip — Bulyan pass 2 and Aksel pass 1: column kernels that consume a device-resident
+// ranking, so the whole rule runs without a host synchronisation.
+//
+// Bulyan pass 2 replaces aggregators/bulyan.py:64-84.  The reference's score update is dead
+// code (its guard `gid == gid_prune` can never hold for scores[1:], bulyan.py:74-76), so the
+// scores are static: with order = stable argsort of the initial scores,
+//     selected[i] = (0 + G[order[i]] + G[order[i+1]] + ...)/c_i ,  c_i = min(m, m_max - i)
+// and the output is the coordinate-wise mean of the beta = theta-2f values of `selected`
+// closest to their lower median.  One pass: read the m_max ranked rows once (4*d*m_max bytes),
+// write d floats; the theta x d `selected` tensor never exists.
+//
+// Aksel pass 1 replaces aggregators/aksel.py:35-41: coordinate-wise lower median fused with the
+// n per-row squared distances to it (one read of the n rows instead of n+2).
+#include "colwise_kernels.h"
+
+namespace bm {
+
+constexpr int kBulBlock = 256;
+
+// ---------------------------------------------------------------------------
+// Register-resident Bulyan pass 2 for a compile-time (n, f) and the default m = m_max.
+// ---------------------------------------------------------------------------
+template <int N, int F, int VEC>
+__global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(RowTable rows,
+                                                                 const int32_t* __restrict__ order,
+                                                                 int64_t nvec,
+                                                                 float* __restrict__ out) {
+  constexpr int MMAX = N - F - 2;
+  constexpr int THETA = N - 2 * F - 2;
+  constexpr int BETA = THETA - 2 * F;
+  static_assert(BETA >= 1, "bulyan needs n >= 4f+3");
+  __shared__ const float* ranked[MMAX];
+  if (threadIdx.x < MMAX) ranked[threadIdx.x] = rows.p[order[threadIdx.x]];
+  __syncthreads();
+  const float kNaN = __builtin_nanf("");
+  const int64_t stride = (int64_t)gridDim.x * kBulBlock;
+  for (int64_t v = (int64_t)blockIdx.x * kBulBlock + threadIdx.x; v < nvec; v += stride) {
+    float x[VEC][MMAX];
+#pragma unroll
+    for (int t = 0; t < MMAX; ++t) {
+      float tmp[VEC];
+      load_stream<VEC>(ranked[t] + v * VEC, tmp);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) x[c][t] = tmp[c];
+    }
+    float r[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      // selected[i]: forward sequential sum from rank i to m_max-1, exact division by the count
+      float sel[THETA];
+      bool has_nan = false;
+#pragma unroll
+      for (int i = 0; i < THETA; ++i) {
+        float s = 0.0f;
+#pragma unroll
+        for (int t = i; t < MMAX; ++t) s += x[c][t];
+        const float cnt = (float)(MMAX - i);
+        sel[i] = div_small_int(s, cnt, 1.0f / cnt);
+        has_nan |= (sel[i] != sel[i]);
+      }
+      sort_network<THETA>(sel);
+      const float med = sel[(THETA - 1) / 2];
+      // beta closest to the median: window [s, s+BETA) of the sorted values
+      int s0 = 0;
+#pragma unroll
+      for (int t = 0; t < THETA - BETA; ++t) {
+        const float dl = __builtin_fabsf(sel[t] - med);
+        const float dh = __builtin_fabsf(sel[t + BETA] - med);
+        s0 = (dl > dh) ? (t + 1) : s0;
+      }
+      float w = 0.0f;
+#pragma unroll
+      for (int i = 0; i < THETA; ++i) w += (i >= s0 && i < s0 + BETA) ? sel[i] : 0.0f;
+      const float res = div_small_int(w, (float)BETA, 1.0f / (float)BETA);
+      r[c] = has_nan ? kNaN : res;
+    }
+    store_stream<VEC>(out + v * VEC, r);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Generic Bulyan pass 2 (any n, f, m): per-lane arrays live in LDS, column-major so that lane l
+// always hits bank l.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(kBulBlock) void bulyan_pass2_generic_kernel(
+    RowTable rows, const int32_t* __restrict__ order, int n, int f, int m, int64_t d,
+    float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int m_max = n - f - 2;
+  const int theta = n - 2 * f - 2;
+  const int beta = theta - 2 * f;
+  __shared__ const float* ranked[BM_MAX_ROWS];
+  if ((int)threadIdx.x < m_max) ranked[threadIdx.x] = rows.p[order[threadIdx.x]];
+  __syncthreads();
+  float* xs = smem + threadIdx.x;                       // [m_max][kBulBlock]
+  float* sel = smem + m_max * kBulBlock + threadIdx.x;  // [theta][kBulBlock]
+  const float kNaN = __builtin_nanf("");
+  const int64_t stride = (int64_t)gridDim.x * kBulBlock;
+  for (int64_t j = (int64_t)blockIdx.x * kBulBlock + threadIdx.x; j < d; j += stride) {
+    for (int t = 0; t < m_max; ++t) xs[t * kBulBlock] = __builtin_nontemporal_load(ranked[t] + j);
+    bool has_nan = false;
+    for (int i = 0; i < theta; ++i) {
+      int cnt = m_max - i;
+      if (cnt > m) cnt = m;
+      float s = 0.0f;
+      for (int t = 0; t < cnt; ++t) s += xs[(i + t) * kBulBlock];
+      float val = s / (float)cnt;
+      has_nan |= (val != val);
+      if (val != val) val = __builtin_inff();
+      // insertion sort (ascending)
+      int p = i;
+      while (p > 0 && sel[(p - 1) * kBulBlock] > val) {
+        sel[p * kBulBlock] = sel[(p - 1) * kBulBlock];
+        --p;
+      }
+      sel[p * kBulBlock] = val;
+    }
+    const float med = sel[((theta - 1) / 2) * kBulBlock];
+    int lo = 0, hi = theta - 1;
+    for (int drop = 0; drop < theta - beta; ++drop) {
+      const float dl = __builtin_fabsf(sel[lo * kBulBlock] - med);
+      const float dh = __builtin_fabsf(sel[hi * kBulBlock] - med);
+      if (dl > dh) ++lo; else --hi;
+    }
+    float w = 0.0f;
+    for (int i = lo; i <= hi; ++i) w += sel[i * kBulBlock];
+    out[j] = has_nan ? kNaN : (w / (float)beta);
+  }
+}
+
+template <int N, int F>
+static int launch_bulyan_fast(const float* const* rows_host, const int32_t* order, int64_t d,
+                              float* out, hipStream_t s) {
+  RowTable tab{};
+  for (int i = 0; i < N; ++i) tab.p[i] = rows_host[i];
+  int vec = common_vec_width(reinterpret_cast<const void* const*>(rows_host), N, out);
+  constexpr int MMAX = N - F - 2;
+  constexpr int kMaxVec = (MMAX <= 20) ? 4 : (MMAX <= 44 ? 2 : 1);
+  if (vec > kMaxVec) vec = kMaxVec;
+  const int forced = tuning().force_vec;
+  if (forced == 1 || (forced == 2 && vec >= 2)) vec = forced;
+  int64_t body = 0;
+  if (vec == 4 && kMaxVec >= 4 && d / 4 > 0) {
+    const int64_t nvec = d / 4;
+    hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 4 ? 4 : 1)>),
+                       dim3(stream_grid(nvec, kBulBlock, tuning().col_max_blocks)), dim3(kBulBlock), 0,
+                       s, tab, order, nvec, out);
+    BM_LAUNCH_CHECK();
+    body = nvec * 4;
+  } else if (vec == 2 && kMaxVec >= 2 && d / 2 > 0) {
+    const int64_t nvec = d / 2;
+    hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 2 ? 2 : 1)>),
+                       dim3(stream_grid(nvec, kBulBlock, tuning().col_max_blocks)), dim3(kBulBlock), 0,
+                       s, tab, order, nvec, out);
+    BM_LAUNCH_CHECK();
+    body = nvec * 2;
+  }
+  if (body < d) {
+    RowTable tail{};
+    for (int i = 0; i < N; ++i) tail.p[i] = rows_host[i] + body;
+    const int64_t rest = d - body;
+    hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, 1>),
+                       dim3(stream_grid(rest, kBulBlock, tuning().col_max_blocks)), dim3(kBulBlock), 0,
+                       s, tail, order, rest, out + body);
+    BM_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// Aksel pass 1: median + per-row squared distance to the median.
+// ---------------------------------------------------------------------------
+template <int N, int VEC>
+__global__ __launch_bounds__(kColBlock) void aksel_pass1_kernel(RowTable rows, int64_t nvec,
+                                                                float* __restrict__ median_out,
+                                                                double* __restrict__ partial) {
+  __shared__ double red[kColBlock / 64];
+  float acc[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) acc[i] = 0.0f;
+  const int64_t stride = (int64_t)gridDim.x * kColBlock;
+  for (int64_t v = (int64_t)blockIdx.x * kColBlock + threadIdx.x; v < nvec; v += stride) {
+    float x[VEC][N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      float t[VEC];
+      load_stream<VEC>(rows.p[i] + v * VEC, t);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) x[c][i] = t[c];
+    }
+    float med[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      float srt[N];
+#pragma unroll
+      for (int i = 0; i < N; ++i) srt[i] = x[c][i];
+      med[c] = column_rule<N, BM_OP_MEDIAN>(srt, 0, 1.0f, nullptr);
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const float df = x[c][i] - med[c];
+        acc[i] += df * df;  // (x - m).pow_(2).sum()
+      }
+    }
+    if (median_out != nullptr) store_stream<VEC>(median_out + v * VEC, med);
+  }
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    const double r = block_reduce_sum<kColBlock>((double)acc[i], red);
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * BM_MAX_ROWS + i] = r;
+  }
+}
+
+__global__ __launch_bounds__(64) void aksel_finish_kernel(const double* __restrict__ partial,
+                                                          int nparts, int n,
+                                                          double* __restrict__ sq_out) {
+  const int i = threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int b = 0; b < nparts; ++b) s += partial[(int64_t)b * BM_MAX_ROWS + i];
+  sq_out[i] = s;
+}
+
+constexpr int kAkselMaxBlocks = 1024;
+
+template <int N>
+static int launch_aksel_n(const float* const* rows_host, int64_t d, float* median_out,
+                          double* sq_out, double* partial, hipStream_t s) {
+  RowTable tab{};
+  for (int i = 0; i < N; ++i) tab.p[i] = rows_host[i];
+  int vec = common_vec_width(reinterpret_cast<const void* const*>(rows_host), N, median_out);
+  constexpr int kMaxVec = (N <= 28) ? 2 : 1;
+  if (vec > kMaxVec) vec = kMaxVec;
+  int nparts = 0;
+  int64_t body = 0;
+  if (vec == 2 && kMaxVec >= 2 && d / 2 > 0) {
+    const int64_t nvec = d / 2;
+    const int grid = stream_grid(nvec, kColBlock, kAkselMaxBlocks - 1);
+    hipLaunchKernelGGL((aksel_pass1_kernel<N, (kMaxVec >= 2 ? 2 : 1)>), dim3(grid), dim3(kColBlock), 0, s,
+                       tab, nvec, median_out, partial);
+    BM_LAUNCH_CHECK();
+    nparts = grid;
+    body = nvec * 2;
+  }
+  if (body < d) {
+    RowTable tail{};
+    for (int i = 0; i < N; ++i) tail.p[i] = rows_host[i] + body;
+    const int64_t rest = d - body;
+    const int grid = (body == 0) ? stream_grid(rest, kColBlock, kAkselMaxBlocks) : 1;
+    hipLaunchKernelGGL((aksel_pass1_kernel<N, 1>), dim3(grid), dim3(kColBlock), 0, s, tail, rest,
+                       median_out ? median_out + body : nullptr,
+                       partial + (int64_t)nparts * BM_MAX_ROWS);
+    BM_LAUNCH_CHECK();
+    nparts += grid;
+  }
+  hipLaunchKernelGGL(aksel_finish_kernel, dim3(1), dim3(64), 0, s, partial, nparts, N, sq_out);
+  BM_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int... Ns>
+static int dispatch_aksel(std::integer_sequence<int, Ns...>, const float* const* rows, int n,
+                          int64_t d, float* median_out, double* sq_out, double* partial,
+                          hipStream_t s) {
+  int rc = BM_EINVAL;
+  ((n == Ns + 1 ? (rc = launch_aksel_n<Ns + 1>(rows, d, median_out, sq_out, partial, s), 0) : 0), ...);
+  return rc;
+}
+
+int64_t pairwise_workspace_bytes(int n, int64_t d);  // pairwise.hip
+
+}  // namespace bm
+
+extern "C" int bm_bulyan_pass2(const float* const* rows, int n, const int32_t* order, int f, int m,
+                               int64_t d, float* out, void* stream) {
+  using namespace bm;
+  if (rows == nullptr || order == nullptr || out == nullptr || n < 1 || n > BM_MAX_ROWS || f < 1 ||
+      n < 4 * f + 3 || m < 1 || m > n - f - 2 || d < 0)
+    return BM_EINVAL;
+  if (d == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int m_max = n - f - 2;
+  if (m == m_max && tuning().force_vec != -1) {
+    // register-resident instances for the (n, f) grid the reference exercises
+    // (reproduce.py:139,182; reproduce-appendix.py:121-158) and their neighbours
+#define BM_BULYAN_CASE(NN, FF) \
+  if (n == NN && f == FF) return launch_bulyan_fast<NN, FF>(rows, order, d, out, s);
+    BM_BULYAN_CASE(11, 2)
+    BM_BULYAN_CASE(15, 3)
+    BM_BULYAN_CASE(19, 4)
+    BM_BULYAN_CASE(25, 5)
+    BM_BULYAN_CASE(23, 5)
+    BM_BULYAN_CASE(27, 6)
+    BM_BULYAN_CASE(31, 7)
+    BM_BULYAN_CASE(35, 8)
+    BM_BULYAN_CASE(39, 9)
+    BM_BULYAN_CASE(43, 10)
+    BM_BULYAN_CASE(47, 11)
+    BM_BULYAN_CASE(51, 12)
+    BM_BULYAN_CASE(51, 10)
+    BM_BULYAN_CASE(7, 1)
+#undef BM_BULYAN_CASE
+  }
+  RowTable tab{};
+  for (int i = 0; i < n; ++i) tab.p[i] = rows[i];
+  const int theta = n - 2 * f - 2;
+  const size_t lds = (size_t)(m_max + theta) * kBulBlock * sizeof(float);
+  const int grid = stream_grid(d, kBulBlock, tuning().col_max_blocks);
+  if (lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bulyan_pass2_generic_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return hip_code(e);
+  }
+  hipLaunchKernelGGL(bulyan_pass2_generic_kernel, dim3(grid), dim3(kBulBlock), lds, s, tab, order, n,
+                     f, m, d, out);
+  BM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int bm_aksel_pass1(const float* const* rows, int n, int64_t d, float* median_out,
+                              double* sq_out, void* ws, void* stream) {
+  using namespace bm;
+  if (rows == nullptr || sq_out == nullptr || ws == nullptr || n < 1 || n > BM_MAX_ROWS || d < 1)
+    return BM_EINVAL;
+  return dispatch_aksel(std::make_integer_sequence<int, BM_MAX_ROWS>{}, rows, n, d, median_out,
+                        sq_out, static_cast<double*>(ws), static_cast<hipStream_t>(stream));
+}
+
+extern "C" int64_t bm_workspace_bytes(int kind, int n, int64_t d) {
+  using namespace bm;
+  if (n < 1 || n > BM_MAX_ROWS) return BM_EINVAL;
+  switch (kind) {
+    case BM_WS_PAIRWISE:
+      return pairwise_workspace_bytes(n, d);
+    case BM_WS_AKSEL:
+      return (int64_t)kAkselMaxBlocks * BM_MAX_ROWS * (int64_t)sizeof(double);
+    case BM_WS_STATS:
+      return (int64_t)2048 * 3 * (int64_t)sizeof(double);
+    case BM_WS_DOT:
+      return (int64_t)1025 * 42 * (int64_t)sizeof(double);
+    default:
+      return BM_EINVAL;
+  }
+}

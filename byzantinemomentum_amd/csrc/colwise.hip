@@ -1,0 +1,103 @@
+// colwise.hip — coordinate-wise rules over the worker axis, one HBM pass.
+//
+// Replaces (reference, PyTorch):
+//   median   aggregators/median.py:39    torch.stack(g).median(dim=0)[0]
+//   trmean   aggregators/trmean.py:33    g.sort(dim=0).values[f:-f].mean(dim=0)
+//   phocas   aggregators/trmean.py:81-94  closest(g, f, trmean(g, f))
+//   meamed   aggregators/trmean.py:96-109 closest(g, f, median(g))
+//
+// Layout: no stacked copy exists.  The n rows are read through a by-value pointer
+// table; a lane owns VEC consecutive coordinates, so a wave issues n independent
+// 64*VEC*4-byte fully coalesced non-temporal loads per step, keeps the n values of
+// each of its columns in VGPRs, sorts them with a compile-time merge-exchange
+// network (v_min_f32/v_max_f32, no LDS, no divergence) and applies the rule's
+// reduction before one coalesced store.  Algorithmic traffic: 4*d*(n+1) bytes.
+//
+// NaN semantics follow the torch in this image (2.10): `median` propagates NaN,
+// `sort` orders NaN last (so trmean is NaN iff more than f values of the column are NaN).
+
+#include "colwise_kernels.h"
+
+namespace bm {
+
+template <int N, int OP, int VEC>
+static int launch_colwise_vec(const RowTable& rows, int64_t nvec, int f, float* out,
+                              hipStream_t stream) {
+  if (nvec <= 0) return 0;
+  const int keep = (OP == BM_OP_TRMEAN) ? (N - 2 * f) : (N - f);
+  const float inv_keep = 1.0f / (float)(keep > 0 ? keep : 1);
+  const int grid = stream_grid(nvec, kColBlock, tuning().col_max_blocks);
+  hipLaunchKernelGGL((colwise_kernel<N, OP, VEC>), dim3(grid), dim3(kColBlock), 0, stream, rows,
+                     nvec, f, inv_keep, out);
+  BM_LAUNCH_CHECK();
+  return 0;
+}
+
+// Body with the widest vector the pointers allow, remaining (d % VEC) columns one by one.
+template <int N, int OP>
+static int launch_colwise_n(const float* const* rows_host, int64_t d, int f, float* out,
+                            hipStream_t stream) {
+  RowTable tab{};
+  for (int i = 0; i < N; ++i) tab.p[i] = rows_host[i];
+  // Register budget: N*VEC live values.  Keep it at or below ~112 so that >= 4 waves/SIMD fit.
+  int vec = common_vec_width(reinterpret_cast<const void* const*>(rows_host), N, out);
+  constexpr int kMaxVec = (N <= 28) ? 4 : (N <= 56 ? 2 : 1);
+  if (vec > kMaxVec) vec = kMaxVec;
+  const int forced = tuning().force_vec;  // experiment knob (BM_FORCE_VEC), 0 = automatic
+  if (forced == 1 || (forced == 2 && vec >= 2)) vec = forced;
+  int64_t body = 0;
+  int rc = 0;
+  if (vec == 4 && kMaxVec >= 4) {
+    body = (d / 4) * 4;
+    rc = launch_colwise_vec < N, OP, (kMaxVec >= 4 ? 4 : 1) > (tab, d / 4, f, out, stream);
+  } else if (vec == 2 && kMaxVec >= 2) {
+    body = (d / 2) * 2;
+    rc = launch_colwise_vec < N, OP, (kMaxVec >= 2 ? 2 : 1) > (tab, d / 2, f, out, stream);
+  }
+  if (rc != 0) return rc;
+  if (body < d) {
+    RowTable tail{};
+    for (int i = 0; i < N; ++i) tail.p[i] = rows_host[i] + body;
+    rc = launch_colwise_vec<N, OP, 1>(tail, d - body, f, out + body, stream);
+  }
+  return rc;
+}
+
+template <int OP, int... Ns>
+static int dispatch_n(std::integer_sequence<int, Ns...>, const float* const* rows, int n,
+                      int64_t d, int f, float* out, hipStream_t stream) {
+  int rc = BM_EINVAL;
+  // Ns = 0..63 -> N = Ns+1
+  ((n == Ns + 1 ? (rc = launch_colwise_n<Ns + 1, OP>(rows, d, f, out, stream), 0) : 0), ...);
+  return rc;
+}
+
+#ifndef BM_COLWISE_OPS
+#define BM_COLWISE_OPS 0xF
+#endif
+
+}  // namespace bm
+
+extern "C" int bm_colwise(int op, const float* const* rows, int n, int64_t d, int f, float* out,
+                          void* stream) {
+  using namespace bm;
+  if (rows == nullptr || out == nullptr || n < 1 || n > BM_MAX_ROWS || d < 0) return BM_EINVAL;
+  if (d == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  auto seq = std::make_integer_sequence<int, BM_MAX_ROWS>{};
+  switch (op) {
+    case BM_OP_MEDIAN:
+      return dispatch_n<BM_OP_MEDIAN>(seq, rows, n, d, 0, out, s);
+    case BM_OP_TRMEAN:
+      if (f < 0 || n < 2 * f + 1) return BM_EINVAL;
+      return dispatch_n<BM_OP_TRMEAN>(seq, rows, n, d, f, out, s);
+    case BM_OP_PHOCAS:
+      if (f < 0 || n < 2 * f + 1) return BM_EINVAL;
+      return dispatch_n<BM_OP_PHOCAS>(seq, rows, n, d, f, out, s);
+    case BM_OP_MEAMED:
+      if (f < 0 || n < 2 * f + 1) return BM_EINVAL;
+      return dispatch_n<BM_OP_MEAMED>(seq, rows, n, d, f, out, s);
+    default:
+      return BM_EINVAL;
+  }
+}

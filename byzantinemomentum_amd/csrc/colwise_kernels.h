@@ -1,0 +1,101 @@
+// colwise_kernels.h — device code of the coordinate-wise rules (see colwise.hip for the contract).
+#pragma once
+#include "bm_common.h"
+
+namespace bm {
+
+constexpr int kColBlock = 256;
+
+// Per-column rule on N register-resident values.  `lds` points at this lane's slot of a
+// [N][kColBlock] scratch array (only used by the closest-to-centre rules).
+template <int N, int OP>
+__device__ __forceinline__ float column_rule(float (&x)[N], int f, float inv_keep, float* lds) {
+  const float kNaN = __builtin_nanf("");
+  const float kInf = __builtin_inff();
+  // --- NaN scan (1 v_cmp per value, masks OR-ed on the scalar unit) ---
+  bool has_nan = false;
+#pragma unroll
+  for (int i = 0; i < N; ++i) has_nan |= (x[i] != x[i]);
+
+  if constexpr (OP == BM_OP_MEDIAN) {
+    // torch.median: any NaN in the column -> NaN.  Other lanes are unaffected by a
+    // NaN-polluted network in this lane, so no replacement pass is needed.
+    sort_network<N>(x);
+    const float med = x[(N - 1) / 2];
+    return has_nan ? kNaN : med;
+  } else {
+    int nan_count = 0;
+    if (__builtin_amdgcn_ballot_w64(has_nan) != 0ull) {  // wave-uniform, rarely taken
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const bool isn = (x[i] != x[i]);
+        nan_count += isn ? 1 : 0;
+        x[i] = isn ? kInf : x[i];  // NaN sorts last (torch.sort)
+      }
+    }
+    sort_network<N>(x);
+    // trimmed mean: ranks f .. N-f-1, summed in ascending order
+    float tsum = 0.0f;
+    if constexpr (OP == BM_OP_TRMEAN || OP == BM_OP_PHOCAS) {
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        if (i >= f && i < N - f) tsum += x[i];  // f is wave-uniform
+    }
+    if constexpr (OP == BM_OP_TRMEAN) {
+      const float r = div_small_int(tsum, (float)(N - 2 * f), inv_keep);
+      return (nan_count > f) ? kNaN : r;
+    } else {
+      // closest(): mean of the m = N-f values nearest the centre.  In sorted order these
+      // form a window [s, s+m) with 0 <= s <= f; "drop low end t" is monotone in t.
+      float c;
+      if constexpr (OP == BM_OP_PHOCAS) {
+        c = div_small_int(tsum, (float)(N - 2 * f), 1.0f / (float)(N - 2 * f));
+        if (nan_count > f) c = kNaN;
+      } else {
+        c = has_nan ? kNaN : x[(N - 1) / 2];
+      }
+      const int m = N - f;
+#pragma unroll
+      for (int i = 0; i < N; ++i) lds[i * kColBlock] = x[i];
+      // "t is farther than t+m" forces the window to start after t; the last such t decides
+      // (with duplicated values the predicate is not monotone, so take the max, not the count).
+      int s = 0;
+      for (int t = 0; t < f; ++t) {
+        const float dl = __builtin_fabsf(lds[t * kColBlock] - c);
+        const float dh = __builtin_fabsf(lds[(t + m) * kColBlock] - c);
+        s = (dl > dh) ? (t + 1) : s;
+      }
+      float wsum = 0.0f;
+      for (int i = 0; i < m; ++i) wsum += lds[(s + i) * kColBlock];
+      const float r = div_small_int(wsum, (float)m, inv_keep);
+      return (c != c || nan_count > f) ? kNaN : r;
+    }
+  }
+}
+
+template <int N, int OP, int VEC>
+__global__ __launch_bounds__(kColBlock) void colwise_kernel(RowTable rows, int64_t nvec, int f,
+                                                            float inv_keep,
+                                                            float* __restrict__ out) {
+  constexpr bool kNeedsLds = (OP == BM_OP_PHOCAS || OP == BM_OP_MEAMED);
+  __shared__ float scratch[kNeedsLds ? N * kColBlock : 1];
+  float* lds = scratch + (kNeedsLds ? threadIdx.x : 0);
+
+  const int64_t stride = (int64_t)gridDim.x * kColBlock;
+  for (int64_t v = (int64_t)blockIdx.x * kColBlock + threadIdx.x; v < nvec; v += stride) {
+    float x[VEC][N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      float t[VEC];
+      load_stream<VEC>(rows.p[i] + v * VEC, t);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) x[c][i] = t[c];
+    }
+    float r[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) r[c] = column_rule<N, OP>(x[c], f, inv_keep, lds);
+    store_stream<VEC>(out + v * VEC, r);
+  }
+}
+
+}  // namespace bm

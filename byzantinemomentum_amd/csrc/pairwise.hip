@@ -1,0 +1,353 @@
+// pairwise.hip — all n(n-1)/2 squared L2 distances in ONE pass over the n x d gradients,
+// plus the on-device score/rank step of Krum and Bulyan.
+//
+// Replaces the reference's per-pair loop
+//     dist = gradients[x].sub(gradients[y]).norm().item()
+// (aggregators/krum.py:44-48, bulyan.py:49-54, brute.py:43-45): n(n-1)/2 x {alloc d, write d,
+// read d, host sync} ~ 100x the algorithmic traffic.  Here every coordinate is read from HBM
+// once (4*d*n bytes) and the direct-difference form (a-b)^2 is kept, so identical rows give an
+// exact 0 and bitwise-equal rows give bitwise-equal distances to any third row (exact score
+// ties, broken by index like the reference's stable sort, krum.py:62).
+//
+// Kernel shape (gfx950):
+//   * a workgroup stages a [rows][64*S coords] tile in LDS (coalesced float4 global reads);
+//   * the n rows are cut in groups of 4; a lane owns ONE 4x4 pair tile (I <= J) and one
+//     64-coordinate strip, keeps its 16 (x2, packed even/odd) fp32 accumulators in VGPRs for the
+//     whole kernel, and per step reads 8 x ds_read_b128 and issues 32 v_pk_add + 32 v_pk_fma;
+//   * LDS rows are stored group-major (row 4I+a at index a*NG+I) with a one-slot (16 B) pad, and
+//     lanes are mapped so that each hardware ds_read_b128 service group of 16 lanes sees one
+//     strip and 16 distinct pair tiles: every read is bank-conflict free, and every pair
+//     accumulates its coordinates in the same canonical order (needed for the exact ties);
+//   * per-workgroup partial sums go to a workspace as fp64 and are reduced in a fixed order by
+//     a second tiny kernel — deterministic, no float atomics.
+#include "bm_common.h"
+
+namespace bm {
+
+constexpr int kPairMaxThreads = 512;
+constexpr int kTileR = 4;  // rows per group; pair tile = kTileR x kTileR
+
+struct PairGeom {
+  int n;        // rows
+  int ng;       // row groups = ceil(n/4)
+  int tiles;    // ng*(ng+1)/2 pair tiles (I <= J)
+  int ut;       // 16-lane units per strip = ceil(tiles/16)
+  int strips;   // S
+  int threads;  // 16*ut*S rounded up to 64
+  int width;    // coordinates per LDS tile = 64*S
+  int stride;   // floats per LDS row = width + 4
+};
+
+static PairGeom pair_geometry(int n) {
+  PairGeom g;
+  g.n = n;
+  g.ng = (n + kTileR - 1) / kTileR;
+  g.tiles = g.ng * (g.ng + 1) / 2;
+  g.ut = (g.tiles + 15) / 16;
+  // as many strips as fit in <= 256 lanes (more lanes per workgroup = fewer LDS tile bytes per
+  // lane), at least one
+  int s = 256 / (16 * g.ut);
+  if (s < 1) s = 1;
+  if (s > 4) s = 4;
+  g.strips = s;
+  g.threads = ((16 * g.ut * s + 63) / 64) * 64;
+  g.width = 64 * s;
+  g.stride = g.width + 4;
+  return g;
+}
+
+// lane -> (unit within wave 0..3, position within unit 0..15), following the ds_read_b128
+// service groups of gfx950: {0-3,12-15,20-27} {4-11,16-19,28-31} {32-35,44-47,52-59}
+// {36-43,48-51,60-63}.
+__device__ __forceinline__ void lane_unit(int lane, int& unit, int& pos) {
+  const int half = lane >> 5;
+  const int l = lane & 31;
+  int u, p;
+  if (l < 4) {
+    u = 0; p = l;
+  } else if (l < 12) {
+    u = 1; p = l - 4;
+  } else if (l < 16) {
+    u = 0; p = l - 8;      // 12..15 -> 4..7
+  } else if (l < 20) {
+    u = 1; p = l - 8;      // 16..19 -> 8..11
+  } else if (l < 28) {
+    u = 0; p = l - 12;     // 20..27 -> 8..15
+  } else {
+    u = 1; p = l - 16;     // 28..31 -> 12..15
+  }
+  unit = half * 2 + u;
+  pos = p;
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <bool ALIGNED>
+__global__ __launch_bounds__(kPairMaxThreads) void pairwise_partial_kernel(
+    RowTable rows, PairGeom g, int64_t d, double* __restrict__ partial) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  int unit_in_wave, pos;
+  lane_unit(lane, unit_in_wave, pos);
+  const int unit = wave * 4 + unit_in_wave;  // global 16-lane unit
+  const int strip = unit / g.ut;
+  const int tile = (unit % g.ut) * 16 + pos;
+  const bool active = (strip < g.strips) && (tile < g.tiles);
+  // tile -> (I, J), I <= J, enumerated row-major over the upper triangle
+  int ti = 0, tj = 0;
+  {
+    int t = active ? tile : 0, row_len = g.ng;
+    while (t >= row_len) {
+      t -= row_len;
+      --row_len;
+      ++ti;
+    }
+    tj = ti + t;
+  }
+  const int nrows_lds = g.ng * kTileR;
+  const float* li[kTileR];
+  const float* lj[kTileR];
+#pragma unroll
+  for (int a = 0; a < kTileR; ++a) {
+    li[a] = lds + (a * g.ng + ti) * g.stride + strip * 64;
+    lj[a] = lds + (a * g.ng + tj) * g.stride + strip * 64;
+  }
+
+  f32x2 acc[kTileR][kTileR];
+#pragma unroll
+  for (int a = 0; a < kTileR; ++a)
+#pragma unroll
+    for (int b = 0; b < kTileR; ++b) acc[a][b] = f32x2{0.0f, 0.0f};
+
+  const int width = g.width;
+  const int vec_per_row = width / 4;                    // 16*S float4 per LDS row
+  const int rows_per_pass = blockDim.x / vec_per_row;   // >= 1 for every geometry
+  const int sub_row = tid / vec_per_row;
+  const int col = (tid - sub_row * vec_per_row) * 4;
+  const bool loader = sub_row < rows_per_pass;
+
+  // chunk c of this workgroup = blockIdx.x + c*gridDim.x (neighbouring workgroups stream
+  // neighbouring addresses); the per-pair accumulation order is the same for every pair.
+  for (int64_t chunk = blockIdx.x;; chunk += gridDim.x) {
+    const int64_t base = chunk * width;
+    if (base >= d) break;
+    __syncthreads();  // previous tile fully consumed
+    // ---- stage rows[*][base .. base+width) into LDS (zero fill past d and past n) ----
+    if (loader) {
+      for (int r = sub_row; r < nrows_lds; r += rows_per_pass) {
+        const int lrow = (r & (kTileR - 1)) * g.ng + (r >> 2);  // group-major LDS row
+        f32x4 val = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (r < g.n) {
+          const float* src = rows.p[r] + base + col;
+          const int64_t left = d - (base + col);
+          if (ALIGNED && left >= 4) {
+            val = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
+          } else {
+            if (left > 0) val.x = src[0];
+            if (left > 1) val.y = src[1];
+            if (left > 2) val.z = src[2];
+            if (left > 3) val.w = src[3];
+          }
+        }
+        *reinterpret_cast<f32x4*>(lds + lrow * g.stride + col) = val;
+      }
+    }
+    __syncthreads();
+    // ---- 16 slots of 4 coordinates, canonical order for every pair ----
+    if (active) {
+#pragma unroll 4
+      for (int k = 0; k < 16; ++k) {
+        f32x4 xi[kTileR], xj[kTileR];
+#pragma unroll
+        for (int a = 0; a < kTileR; ++a) {
+          xi[a] = *reinterpret_cast<const f32x4*>(li[a] + k * 4);
+          xj[a] = *reinterpret_cast<const f32x4*>(lj[a] + k * 4);
+        }
+#pragma unroll
+        for (int a = 0; a < kTileR; ++a)
+#pragma unroll
+          for (int b = 0; b < kTileR; ++b) {
+            const f32x4 df = xi[a] - xj[b];
+            const f32x2 lo = {df.x, df.y};
+            const f32x2 hi = {df.z, df.w};
+            acc[a][b] = __builtin_elementwise_fma(lo, lo, acc[a][b]);
+            acc[a][b] = __builtin_elementwise_fma(hi, hi, acc[a][b]);
+          }
+      }
+    }
+  }
+  // ---- combine strips in a fixed order, emit this workgroup's partial (fp64) ----
+  __syncthreads();
+  float* red = lds;  // reuse: [strip][tile][16]
+  if (active) {
+#pragma unroll
+    for (int a = 0; a < kTileR; ++a)
+#pragma unroll
+      for (int b = 0; b < kTileR; ++b)
+        red[(strip * g.tiles + tile) * 16 + a * kTileR + b] = acc[a][b].x + acc[a][b].y;
+  }
+  __syncthreads();
+  const int per_block = g.tiles * 16;
+  for (int e = tid; e < per_block; e += blockDim.x) {
+    double s = 0.0;
+    for (int st = 0; st < g.strips; ++st) s += (double)red[st * per_block + e];
+    partial[(int64_t)blockIdx.x * per_block + e] = s;
+  }
+}
+
+// Cross-workgroup reduction in a fixed order.  A workgroup of 8 waves owns 64 consecutive
+// partial entries e = tile*16 + a*4 + b (coalesced 512-byte reads); wave w adds the partials of
+// workgroups w, w+8, ... in increasing order, then wave 0 adds the 8 wave sums in order and
+// scatters the value to sq[i][j] and sq[j][i].
+constexpr int kRedWaves = 8;
+__global__ __launch_bounds__(64 * kRedWaves) void pairwise_reduce_kernel(
+    const double* __restrict__ partial, int nblocks, PairGeom g, double* __restrict__ sq) {
+  __shared__ double wsum[kRedWaves][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int per_block = g.tiles * 16;
+  const int e = blockIdx.x * 64 + lane;
+  double s = 0.0;
+  if (e < per_block) {
+#pragma unroll 8
+    for (int blk = wave; blk < nblocks; blk += kRedWaves) s += partial[(int64_t)blk * per_block + e];
+  }
+  wsum[wave][lane] = s;
+  __syncthreads();
+  if (wave != 0 || e >= per_block) return;
+  double tot = wsum[0][lane];
+#pragma unroll
+  for (int w = 1; w < kRedWaves; ++w) tot += wsum[w][lane];
+  // e -> (tile, a, b) -> (I, J) -> (i, j)
+  const int tile = e >> 4, a = (e >> 2) & 3, b = e & 3;
+  int I = 0, t = tile, row_len = g.ng;
+  while (t >= row_len) {
+    t -= row_len;
+    --row_len;
+    ++I;
+  }
+  const int J = I + t;
+  const int i = I * kTileR + a, j = J * kTileR + b;
+  const int n = g.n;
+  if (i >= n || j >= n) return;
+  if (i == j) {
+    sq[i * n + j] = 0.0;
+  } else if (I != J || a < b) {
+    // off-diagonal tiles hold each unordered pair once; diagonal tiles hold (a,b) and (b,a)
+    // with bitwise-equal sums, keep the a<b copy
+    sq[i * n + j] = tot;
+    sq[j * n + i] = tot;
+  }
+}
+
+static int pair_grid_blocks(const PairGeom& g, int64_t d) {
+  const int64_t chunks = (d + g.width - 1) / g.width;
+  int blocks = tuning().pair_blocks > 0 ? tuning().pair_blocks : 256 * 4;
+  if (blocks > chunks) blocks = (int)(chunks > 0 ? chunks : 1);
+  return blocks;
+}
+
+// ---------------------------------------------------------------------------
+// Score + stable rank, one workgroup of 64 lanes (lane i = row i).
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void krum_rank_kernel(const double* __restrict__ sq, int n, int f,
+                                                       int m, int mode,
+                                                       int32_t* __restrict__ order,
+                                                       double* __restrict__ scores_out) {
+  __shared__ double dist[BM_MAX_ROWS][BM_MAX_ROWS + 1];
+  __shared__ double score[BM_MAX_ROWS];
+  const int i = threadIdx.x;
+  const double kInf = __builtin_inf();
+  if (i < n) {
+    // distances of row i to every other row: sqrt in fp64, non-finite -> +inf (krum.py:46-47)
+    int cnt = 0;
+    for (int j = 0; j < n; ++j) {
+      if (j == i) continue;
+      double v = sqrt(sq[i * n + j]);
+      if (!(v == v) || v == kInf || v == -kInf) v = kInf;
+      // insertion sort, ascending (equal values keep arrival order; irrelevant for the sum)
+      int p = cnt++;
+      while (p > 0 && dist[i][p - 1] > v) {
+        dist[i][p] = dist[i][p - 1];
+        --p;
+      }
+      dist[i][p] = v;
+    }
+    // krum: n-f-1 smallest (krum.py:59-60); bulyan: m smallest (bulyan.py:58-61)
+    int take = (mode == BM_RANK_KRUM) ? (n - f - 1) : m;
+    if (take > cnt) take = cnt;
+    if (take < 0) take = 0;
+    double s = 0.0;
+    for (int t = 0; t < take; ++t) s += dist[i][t];
+    score[i] = s;
+    if (scores_out != nullptr) scores_out[i] = s;
+  }
+  __syncthreads();
+  if (i < n) {
+    // stable argsort: rank = #rows with a smaller score, ties to the lower index
+    const double si = score[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) {
+      const double sj = score[j];
+      rank += (sj < si || (sj == si && j < i)) ? 1 : 0;
+    }
+    order[rank] = i;
+  }
+}
+
+}  // namespace bm
+
+extern "C" int bm_pairwise_sqdist(const float* const* rows, int n, int64_t d, double* sq_nxn,
+                                  void* ws, void* stream) {
+  using namespace bm;
+  if (rows == nullptr || sq_nxn == nullptr || ws == nullptr || n < 1 || n > BM_MAX_ROWS || d < 0)
+    return BM_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const PairGeom g = pair_geometry(n);
+  RowTable tab{};
+  for (int i = 0; i < n; ++i) tab.p[i] = rows[i];
+  const int blocks = pair_grid_blocks(g, d);
+  const int nrows_lds = g.ng * kTileR;
+  size_t lds_bytes = (size_t)nrows_lds * g.stride * sizeof(float);
+  const size_t red_bytes = (size_t)g.strips * g.tiles * 16 * sizeof(float);
+  if (red_bytes > lds_bytes) lds_bytes = red_bytes;
+  const bool aligned =
+      common_vec_width(reinterpret_cast<const void* const*>(rows), n, nullptr) == 4;
+  double* partial = static_cast<double*>(ws);
+  if (aligned)
+    hipLaunchKernelGGL(pairwise_partial_kernel<true>, dim3(blocks), dim3(g.threads), lds_bytes, s,
+                       tab, g, d, partial);
+  else
+    hipLaunchKernelGGL(pairwise_partial_kernel<false>, dim3(blocks), dim3(g.threads), lds_bytes, s,
+                       tab, g, d, partial);
+  BM_LAUNCH_CHECK();
+  const int per_block = g.tiles * 16;
+  hipLaunchKernelGGL(pairwise_reduce_kernel, dim3((per_block + 63) / 64), dim3(64 * kRedWaves), 0, s,
+                     partial, blocks, g, sq_nxn);
+  BM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int bm_krum_rank(const double* sq_nxn, int n, int f, int m, int mode,
+                            int32_t* order_out, double* scores_out, void* stream) {
+  using namespace bm;
+  if (sq_nxn == nullptr || order_out == nullptr || n < 1 || n > BM_MAX_ROWS || f < 0 ||
+      (mode != BM_RANK_KRUM && mode != BM_RANK_BULYAN))
+    return BM_EINVAL;
+  hipLaunchKernelGGL(krum_rank_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                     sq_nxn, n, f, m, mode, order_out, scores_out);
+  BM_LAUNCH_CHECK();
+  return 0;
+}
+
+namespace bm {
+int64_t pairwise_workspace_bytes(int n, int64_t d) {
+  const PairGeom g = pair_geometry(n);
+  // upper bound on the grid (BM_PAIR_BLOCKS may raise it, keep a floor of 8192 workgroups)
+  int blocks = tuning().pair_blocks > 0 ? tuning().pair_blocks : 256 * 4;
+  if (blocks < 4096) blocks = 4096;
+  (void)d;
+  return (int64_t)blocks * g.tiles * 16 * (int64_t)sizeof(double);
+}
+}  // namespace bm

@@ -1,0 +1,474 @@
+// reduce.hip — row averaging by a device index table, fused stack statistics, fused dot
+// products and the multi-vector momentum update.
+//
+// Replaces (reference, PyTorch):
+//   sum(grad for _, grad in scores[:m]).div_(m)          krum.py:80, brute.py:80, aksel.py:64
+//   tools.compute_avg_dev_max                             tools/pytorch.py:97-125
+//   torch.dot(...)/norm() chains of the study block       attack.py:851-868
+//   gmtm.mul_(mu).add_(grad, alpha=1-damp) per worker     attack.py:800-804
+// Each is ONE pass over its inputs with every reduction deterministic (fixed trees, fp64
+// across lanes/workgroups, no float atomics) and no host synchronisation.
+#include "bm_common.h"
+
+namespace bm {
+
+constexpr int kRedBlock = 256;
+constexpr int kMaxPartialBlocks = 2048;
+
+// ---------------------------------------------------------------------------
+// selected_mean: out = (((0 + R[idx0]) + R[idx1]) + ... ) / m, sequential fp32.
+// ---------------------------------------------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(kRedBlock) void selected_mean_kernel(RowTable rows,
+                                                                  const int32_t* __restrict__ idx,
+                                                                  int m, int64_t nvec, float fm,
+                                                                  float* __restrict__ out) {
+  __shared__ const float* sel[BM_MAX_ROWS];
+  if (threadIdx.x < m) sel[threadIdx.x] = rows.p[idx[threadIdx.x]];
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * kRedBlock;
+  for (int64_t v = (int64_t)blockIdx.x * kRedBlock + threadIdx.x; v < nvec; v += stride) {
+    float acc[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) acc[c] = 0.0f;
+#pragma unroll 8
+    for (int k = 0; k < m; ++k) {
+      float t[VEC];
+      load_stream<VEC>(sel[k] + v * VEC, t);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) acc[c] += t[c];
+    }
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) acc[c] = acc[c] / fm;
+    store_stream<VEC>(out + v * VEC, acc);
+  }
+}
+
+template <int VEC>
+static int launch_selected_mean(const RowTable& tab, const int32_t* idx, int m, int64_t nvec,
+                                float* out, hipStream_t s) {
+  if (nvec <= 0) return 0;
+  const int grid = stream_grid(nvec, kRedBlock, 256 * 32);
+  hipLaunchKernelGGL(selected_mean_kernel<VEC>, dim3(grid), dim3(kRedBlock), 0, s, tab, idx, m, nvec,
+                     (float)m, out);
+  BM_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------
+// stack_stats: avg (sequential mean of k rows), ||avg||^2, sum_i ||x_i-avg||^2, max|avg|.
+// Per-lane fp32 partials cover only a few dozen columns, everything wider is fp64.
+// ---------------------------------------------------------------------------
+template <int KMAX, int VEC>
+__global__ __launch_bounds__(kRedBlock) void stack_stats_kernel(RowTable rows, int k, int64_t nvec,
+                                                                float* __restrict__ avg_out,
+                                                                double* __restrict__ partial) {
+  __shared__ double red[kRedBlock / 64];
+  const float fk = (float)k;
+  float norm2 = 0.0f, dev2 = 0.0f, amax = 0.0f;
+  bool seen_nan = false;
+  const int64_t stride = (int64_t)gridDim.x * kRedBlock;
+  for (int64_t v = (int64_t)blockIdx.x * kRedBlock + threadIdx.x; v < nvec; v += stride) {
+    float x[KMAX][VEC];
+#pragma unroll
+    for (int i = 0; i < KMAX; ++i)
+      if (i < k) load_stream<VEC>(rows.p[i] + v * VEC, x[i]);
+    float avg[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      float s = x[0][c];  // grad_avg = samples[0].clone(); add_(...)  (tools/pytorch.py:108-110)
+#pragma unroll
+      for (int i = 1; i < KMAX; ++i)
+        if (i < k) s += x[i][c];
+      s = s / fk;
+      avg[c] = s;
+      norm2 = __builtin_fmaf(s, s, norm2);
+      const float as = __builtin_fabsf(s);
+      amax = fmaxf(amax, as);
+      seen_nan |= (s != s);
+      float q = 0.0f;
+#pragma unroll
+      for (int i = 0; i < KMAX; ++i)
+        if (i < k) {
+          const float df = x[i][c] - s;
+          q = __builtin_fmaf(df, df, q);
+        }
+      dev2 += q;
+    }
+    if (avg_out != nullptr) store_stream<VEC>(avg_out + v * VEC, avg);
+  }
+  // torch's abs().max() propagates NaN; fmaxf does not
+  if (seen_nan) amax = __builtin_nanf("");
+  const double n2 = block_reduce_sum<kRedBlock>((double)norm2, red);
+  const double d2 = block_reduce_sum<kRedBlock>((double)dev2, red);
+  // max: NaN-propagating tree
+  float m = amax;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_down(m, off, 64);
+    m = (m != m || o != o) ? __builtin_nanf("") : fmaxf(m, o);
+  }
+  __shared__ float mred[kRedBlock / 64];
+  if ((threadIdx.x & 63) == 0) mred[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float mm = mred[0];
+    for (int w = 1; w < kRedBlock / 64; ++w) {
+      const float o = mred[w];
+      mm = (mm != mm || o != o) ? __builtin_nanf("") : fmaxf(mm, o);
+    }
+    partial[blockIdx.x * 3 + 0] = n2;
+    partial[blockIdx.x * 3 + 1] = d2;
+    partial[blockIdx.x * 3 + 2] = (double)mm;
+  }
+}
+
+// Scalar tail (d % VEC columns) folded into the same partial array as one more "workgroup".
+__global__ void stats_finish_kernel(const double* __restrict__ partial, int nparts,
+                                    double* __restrict__ out3) {
+  // one wave; fixed-order reduction of the per-workgroup partials
+  const int lane = threadIdx.x;
+  double n2 = 0.0, d2 = 0.0, mx = 0.0;
+  bool nan = false;
+  for (int b = lane; b < nparts; b += 64) {
+    n2 += partial[b * 3 + 0];
+    d2 += partial[b * 3 + 1];
+    const double m = partial[b * 3 + 2];
+    nan |= (m != m);
+    mx = m > mx ? m : mx;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    n2 += __shfl_down(n2, off, 64);
+    d2 += __shfl_down(d2, off, 64);
+    const double o = __shfl_down(mx, off, 64);
+    mx = o > mx ? o : mx;
+    nan |= (bool)__shfl_down((int)nan, off, 64);
+  }
+  if (lane == 0) {
+    out3[0] = n2;
+    out3[1] = d2;
+    out3[2] = nan ? __builtin_nan("") : mx;
+  }
+}
+
+template <int KMAX, int VEC>
+static int launch_stack_stats(const RowTable& tab, int k, int64_t nvec, float* avg, double* partial,
+                              int grid, hipStream_t s) {
+  hipLaunchKernelGGL((stack_stats_kernel<KMAX, VEC>), dim3(grid), dim3(kRedBlock), 0, s, tab, k, nvec,
+                     avg, partial);
+  BM_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int VEC>
+static int dispatch_stack_stats(const RowTable& tab, int k, int64_t nvec, float* avg, double* partial,
+                                int grid, hipStream_t s) {
+  if (k <= 8) return launch_stack_stats<8, VEC>(tab, k, nvec, avg, partial, grid, s);
+  if (k <= 16) return launch_stack_stats<16, VEC>(tab, k, nvec, avg, partial, grid, s);
+  if (k <= 24) return launch_stack_stats<24, VEC>(tab, k, nvec, avg, partial, grid, s);
+  if (k <= 32) return launch_stack_stats<32, (VEC > 2 ? 2 : VEC)>(tab, k, nvec * (VEC > 2 ? VEC / 2 : 1),
+                                                                   avg, partial, grid, s);
+  return launch_stack_stats<64, 1>(tab, k, nvec * VEC, avg, partial, grid, s);
+}
+
+// ---------------------------------------------------------------------------
+// multi_dot: Gram matrix of <= 4 "core" vectors + dot(core[0], extra[e]) for <= 32 extras.
+// ---------------------------------------------------------------------------
+constexpr int kMaxCore = 4;
+constexpr int kMaxExtra = 32;
+constexpr int kDotSlots = kMaxCore * (kMaxCore + 1) / 2 + kMaxExtra;  // 42
+
+struct DotTable {
+  const float* core[kMaxCore];
+  const float* extra[kMaxExtra];
+};
+
+template <int VEC>
+__global__ __launch_bounds__(kRedBlock) void multi_dot_kernel(DotTable tab, int nc, int ne,
+                                                              int64_t nvec,
+                                                              double* __restrict__ partial) {
+  __shared__ double red[kRedBlock / 64];
+  float acc[kDotSlots];
+#pragma unroll
+  for (int i = 0; i < kDotSlots; ++i) acc[i] = 0.0f;
+  const int64_t stride = (int64_t)gridDim.x * kRedBlock;
+  for (int64_t v = (int64_t)blockIdx.x * kRedBlock + threadIdx.x; v < nvec; v += stride) {
+    float c[kMaxCore][VEC];
+#pragma unroll
+    for (int a = 0; a < kMaxCore; ++a)
+      if (a < nc) load_stream<VEC>(tab.core[a] + v * VEC, c[a]);
+    int slot = 0;
+#pragma unroll
+    for (int a = 0; a < kMaxCore; ++a)
+#pragma unroll
+      for (int b = a; b < kMaxCore; ++b) {
+        if (b < nc) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) acc[slot] = __builtin_fmaf(c[a][e], c[b][e], acc[slot]);
+        }
+        ++slot;
+      }
+#pragma unroll
+    for (int x = 0; x < kMaxExtra; ++x)
+      if (x < ne) {
+        float t[VEC];
+        load_stream<VEC>(tab.extra[x] + v * VEC, t);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[slot + x] = __builtin_fmaf(c[0][e], t[e], acc[slot + x]);
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < kDotSlots; ++i) {
+    const double r = block_reduce_sum<kRedBlock>((double)acc[i], red);
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * kDotSlots + i] = r;
+  }
+}
+
+__global__ void dot_finish_kernel(const double* __restrict__ partial, int nparts, int nc, int ne,
+                                  double* __restrict__ out) {
+  // thread s < kDotSlots reduces slot s over workgroups in order, then scatters
+  const int s = threadIdx.x;
+  if (s >= kDotSlots) return;
+  double tot = 0.0;
+  for (int b = 0; b < nparts; ++b) tot += partial[(int64_t)b * kDotSlots + s];
+  // slot -> (a, b) of the upper triangle of a kMaxCore x kMaxCore matrix, or extra index
+  int slot = 0;
+  for (int a = 0; a < kMaxCore; ++a)
+    for (int b = a; b < kMaxCore; ++b) {
+      if (slot == s && b < nc) {
+        out[a * nc + b] = tot;
+        out[b * nc + a] = tot;
+      }
+      ++slot;
+    }
+  const int x = s - kMaxCore * (kMaxCore + 1) / 2;
+  if (x >= 0 && x < ne) out[nc * nc + x] = tot;
+}
+
+// ---------------------------------------------------------------------------
+// multi_axpby: y_i = fma(b, x_i, a*y_i) for k vectors; blockIdx.y selects the vector.
+// (torch's vectorised `add_(x, alpha=b)` after `mul_(a)` is a*y rounded, then one fused
+//  multiply-add.)
+// ---------------------------------------------------------------------------
+struct AxpbyTable {
+  float* y[BM_MAX_ROWS];
+  const float* x[BM_MAX_ROWS];
+};
+
+template <int VEC>
+__global__ __launch_bounds__(kRedBlock) void multi_axpby_kernel(AxpbyTable tab, int64_t nvec, float a,
+                                                                float b) {
+  float* __restrict__ y = tab.y[blockIdx.y];
+  const float* __restrict__ x = tab.x[blockIdx.y];
+  const int64_t stride = (int64_t)gridDim.x * kRedBlock;
+  for (int64_t v = (int64_t)blockIdx.x * kRedBlock + threadIdx.x; v < nvec; v += stride) {
+    float yy[VEC], xx[VEC];
+    using T = typename VecLoad<VEC>::T;
+    const T yv = *reinterpret_cast<const T*>(y + v * VEC);
+    if constexpr (VEC == 1) {
+      yy[0] = yv;
+    } else {
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) yy[c] = yv[c];
+    }
+    load_stream<VEC>(x + v * VEC, xx);
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) yy[c] = __builtin_fmaf(b, xx[c], a * yy[c]);
+    T ov;
+    if constexpr (VEC == 1) {
+      ov = yy[0];
+    } else {
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) ov[c] = yy[c];
+    }
+    *reinterpret_cast<T*>(y + v * VEC) = ov;
+  }
+}
+
+// Stable argsort of n (<= 64) fp64 keys on the device; NaN keys rank last (as +inf).
+__global__ __launch_bounds__(64) void stable_argsort_kernel(const double* __restrict__ keys, int n,
+                                                            int32_t* __restrict__ order) {
+  __shared__ double k[BM_MAX_ROWS];
+  const int i = threadIdx.x;
+  if (i < n) {
+    double v = keys[i];
+    if (v != v) v = __builtin_inf();
+    k[i] = v;
+  }
+  __syncthreads();
+  if (i < n) {
+    const double ki = k[i];
+    int rank = 0;
+    for (int j = 0; j < n; ++j) rank += (k[j] < ki || (k[j] == ki && j < i)) ? 1 : 0;
+    order[rank] = i;
+  }
+}
+
+}  // namespace bm
+
+extern "C" int bm_selected_mean(const float* const* rows, int n, const int32_t* idx, int m,
+                                int64_t d, float* out, void* stream) {
+  using namespace bm;
+  if (rows == nullptr || idx == nullptr || out == nullptr || n < 1 || n > BM_MAX_ROWS || m < 1 ||
+      m > BM_MAX_ROWS || d < 0)
+    return BM_EINVAL;
+  if (d == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  RowTable tab{};
+  for (int i = 0; i < n; ++i) tab.p[i] = rows[i];
+  const int vec = common_vec_width(reinterpret_cast<const void* const*>(rows), n, out);
+  int64_t body = 0;
+  int rc = 0;
+  if (vec == 4) {
+    body = (d / 4) * 4;
+    rc = launch_selected_mean<4>(tab, idx, m, d / 4, out, s);
+  } else if (vec == 2) {
+    body = (d / 2) * 2;
+    rc = launch_selected_mean<2>(tab, idx, m, d / 2, out, s);
+  }
+  if (rc != 0) return rc;
+  if (body < d) {
+    RowTable tail{};
+    for (int i = 0; i < n; ++i) tail.p[i] = rows[i] + body;
+    rc = launch_selected_mean<1>(tail, idx, m, d - body, out + body, s);
+  }
+  return rc;
+}
+
+extern "C" int bm_stack_stats(const float* const* rows, int k, int64_t d, float* avg_out,
+                              double* out3, void* ws, void* stream) {
+  using namespace bm;
+  if (rows == nullptr || out3 == nullptr || ws == nullptr || k < 1 || k > BM_MAX_ROWS || d < 1)
+    return BM_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  RowTable tab{};
+  for (int i = 0; i < k; ++i) tab.p[i] = rows[i];
+  double* partial = static_cast<double*>(ws);
+  const int vec = common_vec_width(reinterpret_cast<const void* const*>(rows), k, avg_out);
+  int64_t body = 0;
+  int nparts = 0;
+  int rc = 0;
+  if (vec >= 2) {
+    const int64_t nvec = d / vec;
+    if (nvec > 0) {
+      const int grid = stream_grid(nvec, kRedBlock, kMaxPartialBlocks - 1);
+      rc = (vec == 4) ? dispatch_stack_stats<4>(tab, k, nvec, avg_out, partial, grid, s)
+                      : dispatch_stack_stats<2>(tab, k, nvec, avg_out, partial, grid, s);
+      if (rc != 0) return rc;
+      nparts = grid;
+      body = nvec * vec;
+    }
+  }
+  if (body < d) {
+    RowTable tail{};
+    for (int i = 0; i < k; ++i) tail.p[i] = rows[i] + body;
+    const int64_t rest = d - body;
+    const int grid = (body == 0) ? stream_grid(rest, kRedBlock, kMaxPartialBlocks) : 1;
+    rc = dispatch_stack_stats<1>(tail, k, rest, avg_out ? avg_out + body : nullptr,
+                                 partial + (int64_t)nparts * 3, grid, s);
+    if (rc != 0) return rc;
+    nparts += grid;
+  }
+  hipLaunchKernelGGL(stats_finish_kernel, dim3(1), dim3(64), 0, s, partial, nparts, out3);
+  BM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int bm_multi_dot(const float* const* core, int nc, const float* const* extra, int ne,
+                            int64_t d, double* out, void* ws, void* stream) {
+  using namespace bm;
+  if (core == nullptr || out == nullptr || ws == nullptr || nc < 1 || nc > kMaxCore || ne < 0 ||
+      ne > kMaxExtra || (ne > 0 && extra == nullptr) || d < 1)
+    return BM_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DotTable tab{};
+  uintptr_t bits = 0;
+  for (int i = 0; i < nc; ++i) {
+    tab.core[i] = core[i];
+    bits |= reinterpret_cast<uintptr_t>(core[i]);
+  }
+  for (int i = 0; i < ne; ++i) {
+    tab.extra[i] = extra[i];
+    bits |= reinterpret_cast<uintptr_t>(extra[i]);
+  }
+  double* partial = static_cast<double*>(ws);
+  const int vec = (bits & 15u) == 0 ? 4 : ((bits & 7u) == 0 ? 2 : 1);
+  int nparts = 0;
+  int64_t body = 0;
+  if (vec >= 2 && d / vec > 0) {
+    const int64_t nvec = d / vec;
+    const int grid = stream_grid(nvec, kRedBlock, 1024);
+    if (vec == 4)
+      hipLaunchKernelGGL(multi_dot_kernel<4>, dim3(grid), dim3(kRedBlock), 0, s, tab, nc, ne, nvec,
+                         partial);
+    else
+      hipLaunchKernelGGL(multi_dot_kernel<2>, dim3(grid), dim3(kRedBlock), 0, s, tab, nc, ne, nvec,
+                         partial);
+    BM_LAUNCH_CHECK();
+    nparts = grid;
+    body = nvec * vec;
+  }
+  if (body < d) {
+    DotTable tail = tab;
+    for (int i = 0; i < nc; ++i) tail.core[i] += body;
+    for (int i = 0; i < ne; ++i) tail.extra[i] += body;
+    const int64_t rest = d - body;
+    const int grid = (body == 0) ? stream_grid(rest, kRedBlock, 1024) : 1;
+    hipLaunchKernelGGL(multi_dot_kernel<1>, dim3(grid), dim3(kRedBlock), 0, s, tail, nc, ne, rest,
+                       partial + (int64_t)nparts * kDotSlots);
+    BM_LAUNCH_CHECK();
+    nparts += grid;
+  }
+  hipLaunchKernelGGL(dot_finish_kernel, dim3(1), dim3(64), 0, s, partial, nparts, nc, ne, out);
+  BM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int bm_multi_axpby(float* const* y, const float* const* x, int k, int64_t d, float a,
+                              float b, void* stream) {
+  using namespace bm;
+  if (y == nullptr || x == nullptr || k < 1 || k > BM_MAX_ROWS || d < 0) return BM_EINVAL;
+  if (d == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  AxpbyTable tab{};
+  uintptr_t bits = 0;
+  for (int i = 0; i < k; ++i) {
+    tab.y[i] = y[i];
+    tab.x[i] = x[i];
+    bits |= reinterpret_cast<uintptr_t>(y[i]) | reinterpret_cast<uintptr_t>(x[i]);
+  }
+  const int vec = (bits & 15u) == 0 ? 4 : ((bits & 7u) == 0 ? 2 : 1);
+  int64_t body = 0;
+  if (vec >= 2 && d / vec > 0) {
+    const int64_t nvec = d / vec;
+    const int grid = stream_grid(nvec, kRedBlock, 2048);
+    if (vec == 4)
+      hipLaunchKernelGGL(multi_axpby_kernel<4>, dim3(grid, k), dim3(kRedBlock), 0, s, tab, nvec, a, b);
+    else
+      hipLaunchKernelGGL(multi_axpby_kernel<2>, dim3(grid, k), dim3(kRedBlock), 0, s, tab, nvec, a, b);
+    BM_LAUNCH_CHECK();
+    body = nvec * vec;
+  }
+  if (body < d) {
+    AxpbyTable tail = tab;
+    for (int i = 0; i < k; ++i) {
+      tail.y[i] += body;
+      tail.x[i] += body;
+    }
+    const int64_t rest = d - body;
+    const int grid = stream_grid(rest, kRedBlock, 2048);
+    hipLaunchKernelGGL(multi_axpby_kernel<1>, dim3(grid, k), dim3(kRedBlock), 0, s, tail, rest, a, b);
+    BM_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int bm_stable_argsort(const double* keys, int n, int32_t* order_out, void* stream) {
+  using namespace bm;
+  if (keys == nullptr || order_out == nullptr || n < 1 || n > BM_MAX_ROWS) return BM_EINVAL;
+  hipLaunchKernelGGL(stable_argsort_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+                     keys, n, order_out);
+  BM_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,134 @@
+/*
+ * bm_gar.h — C ABI of libbm_gar.so, the MI355X (gfx950) implementation of the
+ * Byzantine-robust gradient-aggregation hot path of LPD-EPFL/ByzantineMomentum.
+ *
+ * This is the drop-in boundary. Every entry point is what the reference's
+ * `native` hook (aggregators/krum.py:22-26,82-96; bulyan.py:22-26,86-100;
+ * median.py:22-26,41-49; brute.py:23-27,82-91) or its registry
+ * (aggregators/__init__.py:71-86) would bind through an FFI for this path.
+ * The reference-side binding (a ctypes stub) is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - `rows`   : HOST array of n DEVICE pointers, one per worker gradient
+ *                (reference: `gradients: list[Tensor(d)]`, entries may alias,
+ *                attacks/identical.py:86). Never written. n <= BM_MAX_ROWS.
+ *   - `d`      : coordinates per gradient (fp32, contiguous).
+ *   - `out`    : DEVICE pointer, caller-allocated, never aliases an input
+ *                (aggregators/__init__.py:19).
+ *   - `stream` : hipStream_t of the caller (torch.cuda.current_stream().cuda_stream);
+ *                every launch goes there, no entry point synchronises the device.
+ *   - return   : 0 on success; a negative value -hipError_t on a HIP failure;
+ *                BM_EINVAL for an argument the kernels cannot serve.
+ *   - The library owns no memory across calls; workspaces are caller-owned and
+ *     sized by bm_workspace_bytes().
+ */
+#ifndef BM_GAR_H
+#define BM_GAR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BM_MAX_ROWS 64
+#define BM_EINVAL   (-100000)
+
+/* Column-wise rules (coordinate-per-coordinate over the worker axis). */
+enum bm_colwise_op {
+  BM_OP_MEDIAN = 0, /* aggregators/median.py:31-39  lower median, rank (n-1)//2      */
+  BM_OP_TRMEAN = 1, /* aggregators/trmean.py:24-33  mean of sorted ranks f..n-f-1    */
+  BM_OP_PHOCAS = 2, /* aggregators/trmean.py:81-94  n-f closest to the trimmed mean  */
+  BM_OP_MEAMED = 3  /* aggregators/trmean.py:96-109 n-f closest to the median        */
+};
+
+/* ABI version of this header; bumped on any signature change. */
+int bm_abi_version(void);
+
+/* Human-readable text for a code returned by any entry point. */
+const char* bm_error_string(int code);
+
+/* out[j] = op over {rows[i][j]}_i, 0 <= j < d.  f ignored for BM_OP_MEDIAN. */
+int bm_colwise(int op, const float* const* rows, int n, int64_t d, int f,
+               float* out, void* stream);
+
+/* Workspace sizes (bytes) for the entry points below. kind: */
+enum bm_ws_kind {
+  BM_WS_PAIRWISE = 0, /* bm_pairwise_sqdist            */
+  BM_WS_AKSEL    = 1, /* bm_aksel_pass1                */
+  BM_WS_STATS    = 2, /* bm_stack_stats                */
+  BM_WS_DOT      = 3  /* bm_multi_dot                  */
+};
+int64_t bm_workspace_bytes(int kind, int n, int64_t d);
+
+/* sq[i*n+j] = sum_k (rows[i][k]-rows[j][k])^2 as fp64, full symmetric n x n matrix,
+ * zero diagonal.  Replaces the n(n-1)/2 x (sub, norm, .item()) loop of
+ * aggregators/krum.py:41-48, bulyan.py:48-54, brute.py:43-45 (which take sqrt on top).
+ * Deterministic: bitwise-equal rows give bitwise-equal distances. */
+int bm_pairwise_sqdist(const float* const* rows, int n, int64_t d,
+                       double* sq_nxn, void* ws, void* stream);
+
+/* Score + stable rank on the device (one workgroup), from the squared distances.
+ * mode BM_RANK_KRUM  : score_i = sum of the (n-f-1) smallest distances of row i
+ *                      (aggregators/krum.py:50-62)
+ * mode BM_RANK_BULYAN: score_i = sum of the m smallest distances of row i
+ *                      (aggregators/bulyan.py:56-62)
+ * Distances are sqrt(sq) in fp64, non-finite -> +inf (krum.py:46-47); sums are
+ * fp64 in ascending order; order_out is the stable (lower index first) argsort of
+ * the scores.  scores_out (n doubles) may be NULL. */
+enum bm_rank_mode { BM_RANK_KRUM = 0, BM_RANK_BULYAN = 1 };
+int bm_krum_rank(const double* sq_nxn, int n, int f, int m, int mode,
+                 int32_t* order_out, double* scores_out, void* stream);
+
+/* out = (((0 + rows[idx[0]]) + rows[idx[1]]) + ...)/m, sequential fp32 like
+ * `sum(...).div_(m)` at aggregators/krum.py:80, brute.py:80, aksel.py:64.
+ * idx is a DEVICE array of m int32 (so no host sync between rank and mean). */
+int bm_selected_mean(const float* const* rows, int n, const int32_t* idx, int m,
+                     int64_t d, float* out, void* stream);
+
+/* Bulyan pass 2 (aggregators/bulyan.py:64-84 with static scores): with
+ * m_max = n-f-2, theta = n-2f-2, beta = theta-2f, for every coordinate
+ *   sel[i] = mean(rows[order[i .. i+min(m, m_max-i)-1]]),  i < theta
+ *   out    = mean of the beta values of sel closest to the lower median of sel.
+ * order is the DEVICE output of bm_krum_rank(mode BULYAN). */
+int bm_bulyan_pass2(const float* const* rows, int n, const int32_t* order, int f, int m,
+                    int64_t d, float* out, void* stream);
+
+/* Aksel pass 1 (aggregators/aksel.py:35-41): coordinate-wise lower median
+ * (written to median_out if non-NULL) and sq[i] = sum_j (rows[i][j]-median[j])^2. */
+int bm_aksel_pass1(const float* const* rows, int n, int64_t d, float* median_out,
+                   double* sq_out, void* ws, void* stream);
+
+/* tools/pytorch.py:97-125 in one pass: avg_out = sequential mean of the k rows;
+ * out3 = { sum_j avg_j^2, sum_i sum_j (rows[i][j]-avg_j)^2, max_j |avg_j| }. */
+int bm_stack_stats(const float* const* rows, int k, int64_t d, float* avg_out,
+                   double* out3, void* ws, void* stream);
+
+/* The dot products of the study block (attack.py:851-868) in one pass:
+ *   out[a*nc+b]   = <core[a], core[b]>   for the nc (<= 4) "core" vectors (symmetric, the
+ *                   diagonal holds the squared norms), then
+ *   out[nc*nc+e]  = <core[0], extra[e]>  for ne (<= 32) more vectors (the past sampled
+ *                   averages of the curvature term, attack.py:863-865).  All fp64. */
+int bm_multi_dot(const float* const* core, int nc, const float* const* extra, int ne,
+                 int64_t d, double* out, void* ws, void* stream);
+
+/* order_out = stable argsort (ties to the lower index, NaN last) of n fp64 keys that live on
+ * the device: the `d.sort(key=...)` of aggregators/aksel.py:48 without a host round trip. */
+int bm_stable_argsort(const double* keys, int n, int32_t* order_out, void* stream);
+
+/* y[i] = a*y[i] + b*x[i] for k vectors at once: worker momentum
+ * `gmtm.mul_(mu).add_(grad, alpha=1-damp)` at attack.py:800-804. */
+int bm_multi_axpby(float* const* y, const float* const* x, int k, int64_t d,
+                   float a, float b, void* stream);
+
+/* Brute subset search on the host (aggregators/brute.py:47-68): over all
+ * C(n, n-f) subsets in lexicographic order, first subset of smallest diameter;
+ * subsets touching a non-finite distance are skipped.  dist_nxn holds sqrt'ed
+ * distances (host memory).  Writes n-f ascending indices; returns 0, or
+ * BM_EINVAL if no finite subset exists. */
+int bm_brute_select(const double* dist_nxn, int n, int f, int32_t* sel_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BM_GAR_H */
