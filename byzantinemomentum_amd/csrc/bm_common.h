@@ -184,6 +184,7 @@ struct Tuning {
   int force_vec;       // BM_FORCE_VEC: 0 auto, 1 or 2 force a narrower column vector
   int col_max_blocks;  // BM_COL_MAX_BLOCKS: grid cap of the column kernels
   int pair_blocks;     // BM_PAIR_BLOCKS: persistent grid of the pairwise-distance kernel
+  int pair_unroll;     // BM_PAIR_UNROLL: 1 (default) or 2 slots per inner-loop trip
 };
 const Tuning& tuning();
 }  // namespace bm

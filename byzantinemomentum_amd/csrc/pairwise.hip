@@ -24,7 +24,7 @@
 
 namespace bm {
 
-constexpr int kPairMaxThreads = 512;
+constexpr int kPairMaxThreads = 256;
 constexpr int kTileR = 4;  // rows per group; pair tile = kTileR x kTileR
 
 struct PairGeom {
@@ -83,8 +83,8 @@ __device__ __forceinline__ void lane_unit(int lane, int& unit, int& pos) {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <bool ALIGNED>
-__global__ __launch_bounds__(kPairMaxThreads) void pairwise_partial_kernel(
+template <bool ALIGNED, int UNROLL>
+__global__ __launch_bounds__(kPairMaxThreads, 2) void pairwise_partial_kernel(
     RowTable rows, PairGeom g, int64_t d, double* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x;
@@ -157,21 +157,24 @@ __global__ __launch_bounds__(kPairMaxThreads) void pairwise_partial_kernel(
     __syncthreads();
     // ---- 16 slots of 4 coordinates, canonical order for every pair ----
     if (active) {
-#pragma unroll 4
+#pragma unroll UNROLL
       for (int k = 0; k < 16; ++k) {
-        f32x4 xi[kTileR], xj[kTileR];
+        f32x2 xil[kTileR], xih[kTileR], xjl[kTileR], xjh[kTileR];
 #pragma unroll
         for (int a = 0; a < kTileR; ++a) {
-          xi[a] = *reinterpret_cast<const f32x4*>(li[a] + k * 4);
-          xj[a] = *reinterpret_cast<const f32x4*>(lj[a] + k * 4);
+          const f32x4 vi = *reinterpret_cast<const f32x4*>(li[a] + k * 4);
+          const f32x4 vj = *reinterpret_cast<const f32x4*>(lj[a] + k * 4);
+          xil[a] = f32x2{vi.x, vi.y};
+          xih[a] = f32x2{vi.z, vi.w};
+          xjl[a] = f32x2{vj.x, vj.y};
+          xjh[a] = f32x2{vj.z, vj.w};
         }
 #pragma unroll
         for (int a = 0; a < kTileR; ++a)
 #pragma unroll
           for (int b = 0; b < kTileR; ++b) {
-            const f32x4 df = xi[a] - xj[b];
-            const f32x2 lo = {df.x, df.y};
-            const f32x2 hi = {df.z, df.w};
+            const f32x2 lo = xil[a] - xjl[b];  // v_pk_add_f32 with neg modifier
+            const f32x2 hi = xih[a] - xjh[b];
             acc[a][b] = __builtin_elementwise_fma(lo, lo, acc[a][b]);
             acc[a][b] = __builtin_elementwise_fma(hi, hi, acc[a][b]);
           }
@@ -315,12 +318,10 @@ extern "C" int bm_pairwise_sqdist(const float* const* rows, int n, int64_t d, do
   const bool aligned =
       common_vec_width(reinterpret_cast<const void* const*>(rows), n, nullptr) == 4;
   double* partial = static_cast<double*>(ws);
-  if (aligned)
-    hipLaunchKernelGGL(pairwise_partial_kernel<true>, dim3(blocks), dim3(g.threads), lds_bytes, s,
-                       tab, g, d, partial);
-  else
-    hipLaunchKernelGGL(pairwise_partial_kernel<false>, dim3(blocks), dim3(g.threads), lds_bytes, s,
-                       tab, g, d, partial);
+  const bool deep = tuning().pair_unroll >= 2;  // experiment knob BM_PAIR_UNROLL
+  auto kern = aligned ? (deep ? pairwise_partial_kernel<true, 2> : pairwise_partial_kernel<true, 1>)
+                      : (deep ? pairwise_partial_kernel<false, 2> : pairwise_partial_kernel<false, 1>);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(g.threads), lds_bytes, s, tab, g, d, partial);
   BM_LAUNCH_CHECK();
   const int per_block = g.tiles * 16;
   hipLaunchKernelGGL(pairwise_reduce_kernel, dim3((per_block + 63) / 64), dim3(64 * kRedWaves), 0, s,

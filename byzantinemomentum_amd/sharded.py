@@ -1,0 +1,166 @@
+"""Dimension-sharded aggregation over several GPUs (one process per GPU, RCCL over xGMI).
+
+The reference has no multi-GPU aggregation; this is the MI355X scaling axis of
+the path.  Every rank holds the SAME n workers but only its slice [lo, hi) of the d coordinates:
+
+  * coordinate-wise rules (median, trmean, phocas, meamed), Bulyan pass 2, selected means and
+    momentum are independent per coordinate  -> no communication at all;
+  * distance-based selection needs ONE exchange: each rank computes partial SQUARED distances over
+    its slice, a single all-reduce(sum) of an n x n fp64 buffer (<= 32 KB, latency-bound on xGMI —
+    never a d-sized collective) gives every rank the same matrix, and every rank runs the same
+    deterministic score/rank kernel -> identical selections without further traffic;
+  * Aksel: all-reduce of the n partial squared distances to the (local) median slices;
+  * statistics: all-reduce(sum) of the two sums, all-reduce(max) of max|avg|;
+  * the full aggregated vector, when a consumer needs it on every rank, is ONE all-gather of the
+    d/P slices (the only bandwidth collective: 7 peers on 7 links in parallel).
+
+The compute legs are injected (`backend`): the product uses the HIP backend below; the CPU/gloo
+tests of tests/test_sharded_gloo.py inject an oracle-backed one to exercise partitioning and
+collectives without a GPU.  With world_size 1 no collective is ever issued.
+"""
+
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+__all__ = ["shard_bounds", "ShardedAggregator", "HipBackend"]
+
+
+def shard_bounds(d, world_size, rank, align=64):
+  """Contiguous slice [lo, hi) of rank `rank`: ceil(d/P) rounded up to `align` coordinates
+  (256 B, keeps every shard 16-byte aligned for the float4 kernels). Trailing ranks may be empty."""
+  per = -(-d // world_size)
+  per = -(-per // align) * align
+  lo = min(rank * per, d)
+  hi = min(lo + per, d)
+  return lo, hi
+
+
+class HipBackend:
+  """Compute legs on the local MI355X (libbm_gar.so).  No CPU fallback."""
+
+  def __init__(self):
+    from . import gars, stats
+    self.gars = gars
+    self.stats = stats
+
+  def pairwise_sqdist(self, gradients):
+    return self.gars.pairwise_sqdist(gradients)
+
+  def rank(self, sq, n, f, m, mode):
+    order, _ = self.gars.rank_from_sqdist(sq, n, f, m, mode)
+    return order
+
+  def selected_mean(self, gradients, order, m):
+    return self.gars.selected_mean(gradients, order, m)
+
+  def bulyan_pass2(self, gradients, order, f, m):
+    return self.gars.bulyan_pass2(gradients, order, f, m)
+
+  def colwise(self, rule, gradients, f):
+    return getattr(self.gars, rule)(gradients, f=f) if rule != "median" else self.gars.median(gradients)
+
+  def aksel_sqdist(self, gradients):
+    return self.gars.aksel_sqdist(gradients)[:len(gradients)]
+
+  def argsort(self, keys, n):
+    return self.gars.stable_argsort(keys, n)
+
+  def stack_stats(self, samples):
+    return self.stats.stack_stats_async(samples)
+
+
+class ShardedAggregator:
+  """Aggregation rules over gradients whose coordinates are sharded across the ranks of `group`."""
+
+  def __init__(self, backend=None, group=None):
+    self.backend = backend if backend is not None else HipBackend()
+    self.group = group
+    self.world_size = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    self.rank = dist.get_rank(group) if self.world_size > 1 else 0
+
+  # -- collectives (never called when world_size == 1) ----------------------- #
+
+  def _all_reduce(self, tensor, op=None):
+    if self.world_size > 1:
+      dist.all_reduce(tensor, op=(op or dist.ReduceOp.SUM), group=self.group)
+    return tensor
+
+  def all_gather_output(self, local_out, d):
+    """Full d-vector on every rank from the per-rank slices (shard_bounds layout)."""
+    if self.world_size == 1:
+      return local_out
+    lo0, hi0 = shard_bounds(d, self.world_size, 0)
+    per = hi0 - lo0
+    padded = torch.zeros(per, dtype=local_out.dtype, device=local_out.device)
+    padded[:local_out.shape[0]] = local_out
+    full = torch.empty(per * self.world_size, dtype=local_out.dtype, device=local_out.device)
+    dist.all_gather_into_tensor(full, padded, group=self.group)
+    return full[:d]
+
+  # -- rules ------------------------------------------------------------------ #
+
+  def median(self, local):
+    return self.backend.colwise("median", local, 0)
+
+  def trmean(self, local, f):
+    return self.backend.colwise("trmean", local, f)
+
+  def phocas(self, local, f):
+    return self.backend.colwise("phocas", local, f)
+
+  def meamed(self, local, f):
+    return self.backend.colwise("meamed", local, f)
+
+  def global_sqdist(self, local):
+    """All-reduced n x n squared-distance matrix (every rank gets the same bits: the sum runs over
+    the same P partial matrices in the collective's fixed order)."""
+    sq = self.backend.pairwise_sqdist(local)
+    if self.world_size > 1:
+      sq = sq.clone()
+      self._all_reduce(sq)
+    return sq
+
+  def krum(self, local, f, m=None):
+    n = len(local)
+    if m is None:
+      m = n - f - 2
+    order = self.backend.rank(self.global_sqdist(local), n, f, m, _lib.RANK_KRUM)
+    return self.backend.selected_mean(local, order, m)
+
+  def bulyan(self, local, f, m=None):
+    n = len(local)
+    if m is None:
+      m = n - f - 2
+    order = self.backend.rank(self.global_sqdist(local), n, f, m, _lib.RANK_BULYAN)
+    return self.backend.bulyan_pass2(local, order, f, m)
+
+  def aksel(self, local, f, mode="mid"):
+    n = len(local)
+    count = (n + 1) // 2 if mode == "mid" else n - f
+    sq = self.backend.aksel_sqdist(local)
+    if self.world_size > 1:
+      sq = sq.clone()
+      self._all_reduce(sq)
+    return self.backend.selected_mean(local, self.backend.argsort(sq, n), count)
+
+  def compute_avg_dev_max(self, local_samples):
+    """Sharded tools.compute_avg_dev_max: (local slice of the average, norm, deviation, max)."""
+    k = len(local_samples)
+    if k == 0:
+      return None, math.nan, math.nan, math.nan
+    avg, out3 = self.backend.stack_stats(local_samples)
+    if self.world_size > 1:
+      sums = out3[:2].clone()
+      mx = out3[2:].clone()
+      self._all_reduce(sums)
+      self._all_reduce(mx, dist.ReduceOp.MAX)
+      norm2, dev2 = sums.tolist()
+      amax = mx.item()
+    else:
+      norm2, dev2, amax = out3.tolist()
+    dev = math.sqrt(dev2 / (k - 1)) if k >= 2 else math.nan
+    return avg, math.sqrt(norm2), dev, amax

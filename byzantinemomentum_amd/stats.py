@@ -1,0 +1,91 @@
+"""Per-step gradient statistics and momentum of the simulation loop, on the HIP path.
+
+Mirrors tools/pytorch.py:97-125 (`compute_avg_dev_max`), the study block of attack.py:842-868
+(norms, max-abs, six cosines, past-gradient cosine and curvature) and the worker-side momentum
+update of attack.py:800-804.  One fused pass per stack and one fused pass for all the dot
+products; results stay on the device until the caller asks for Python floats (one sync).
+"""
+
+import ctypes
+import math
+
+import torch
+
+from . import _lib
+from . import gars
+
+__all__ = ["compute_avg_dev_max", "stack_stats_async", "study_dots", "multi_axpby", "row_sqnorms"]
+
+_ptr = gars._ptr
+
+
+def stack_stats_async(samples):
+  """avg vector + device tensor [sum avg^2, sum_i ||s_i-avg||^2, max|avg|] (fp64), no sync."""
+  k, d, device = gars._validate(samples)
+  lib = _lib.load()
+  avg = torch.empty(d, dtype=torch.float32, device=device)
+  out3 = torch.empty(3, dtype=torch.float64, device=device)
+  ws = gars._workspace(device, _lib.WS_STATS, k, d, "ws_stats")
+  with torch.cuda.device(device):
+    _lib.check(lib.bm_stack_stats(_lib.pointer_table(samples), k, d, _ptr(avg), _ptr(out3), _ptr(ws),
+                                  gars._stream(device)), "bm_stack_stats")
+  return avg, out3
+
+
+def compute_avg_dev_max(samples):
+  """Drop-in for tools.compute_avg_dev_max (tools/pytorch.py:97-125).
+
+  Returns (average gradient or None, norm of the average, norm standard deviation, max |coord|).
+  """
+  if len(samples) == 0:
+    return None, math.nan, math.nan, math.nan
+  avg, out3 = stack_stats_async(samples)
+  norm2, dev2, amax = out3.tolist()  # the only synchronisation
+  k = len(samples)
+  norm_dev = math.sqrt(dev2 / (k - 1)) if k >= 2 else math.nan
+  return avg, math.sqrt(norm2), norm_dev, amax
+
+
+def study_dots(core, extra=()):
+  """Gram matrix (fp64, nc x nc) of up to 4 vectors and dot(core[0], e) for up to 32 more.
+
+  Covers every `torch.dot`/`norm` of attack.py:851-868 in one pass over the vectors.
+  Returns (gram tensor nc x nc, extras tensor ne), both on the device.
+  """
+  core = list(core)
+  extra = list(extra)
+  nc, d, device = gars._validate(core)
+  if extra:
+    gars._validate(extra + [core[0]])
+  lib = _lib.load()
+  out = torch.empty(nc * nc + len(extra), dtype=torch.float64, device=device)
+  ws = gars._workspace(device, _lib.WS_DOT, 1, d, "ws_dot")
+  with torch.cuda.device(device):
+    _lib.check(lib.bm_multi_dot(_lib.pointer_table(core), nc,
+                                _lib.pointer_table(extra) if extra else None, len(extra), d, _ptr(out),
+                                _ptr(ws), gars._stream(device)), "bm_multi_dot")
+  return out[:nc * nc].view(nc, nc), out[nc * nc:]
+
+
+def row_sqnorms(gradients):
+  """Squared L2 norm of every gradient (fp64, on the device): one read of the stack."""
+  n, d, device = gars._validate(gradients)
+  res = torch.empty(_lib.MAX_ROWS, dtype=torch.float64, device=device)
+  for lo in range(0, n, 4):
+    gram, _ = study_dots(gradients[lo:lo + 4])
+    res[lo:lo + gram.shape[0]] = gram.diagonal()
+  return res[:n]
+
+
+def multi_axpby(ys, xs, a, b):
+  """In place y_i <- a*y_i + b*x_i for every pair: `gmtm.mul_(mu).add_(grad, alpha=1-damp)`."""
+  k, d, device = gars._validate(list(ys))
+  gars._validate(list(xs) + [ys[0]])
+  if len(xs) != k:
+    raise gars.GarInputError("multi_axpby needs as many x as y vectors")
+  lib = _lib.load()
+  gars.invalidate_rank_cache()
+  with torch.cuda.device(device):
+    _lib.check(lib.bm_multi_axpby(_lib.pointer_table(ys), _lib.pointer_table(xs), k, d,
+                                  ctypes.c_float(a), ctypes.c_float(b), gars._stream(device)),
+               "bm_multi_axpby")

@@ -1,0 +1,340 @@
+"""Parity of the HIP path (through the C ABI and the host mirror) with the oracle / the golden
+fixtures of the real reference.  Needs an MI355X: `pytest -m gpu`.
+
+Bars (BASELINE.json north_star): selected index sets bit-identical; median bit-exact; means and
+statistics within 1e-5 — tightened here to what is achievable: sequential means are bit-exact,
+sorted-order means within 1e-6 (summation order only).
+"""
+
+import math
+
+import pytest
+import torch
+
+from oracle import gar_oracle as O
+from tests.golden_io import CASES, HAND_CASES, Golden, same_bits
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def bm():
+  import byzantinemomentum_amd
+  byzantinemomentum_amd._lib.load()  # must be the in-tree HIP library, loudly
+  return byzantinemomentum_amd
+
+
+def close(x, ref, tol, scale=None):
+  """|x - ref| <= tol * max(|ref|, scale) elementwise, NaN matching NaN."""
+  x = torch.as_tensor(x).detach().cpu().to(torch.float64)
+  ref = torch.as_tensor(ref).detach().cpu().to(torch.float64)
+  nx, nr = torch.isnan(x), torch.isnan(ref)
+  if not bool((nx == nr).all()):
+    return False
+  if scale is None:
+    scale = float(ref[~nr].abs().max()) if (~nr).any() else 1.0
+  bound = tol * torch.maximum(ref.abs(), torch.tensor(scale, dtype=torch.float64))
+  return bool(((x - ref).abs()[~nr] <= bound[~nr]).all())
+
+
+def to_dev(gradients):
+  """Move a list to the GPU keeping the aliasing structure (same object -> same object)."""
+  seen = {}
+  out = []
+  for g in gradients:
+    if id(g) not in seen:
+      seen[id(g)] = g.to(DEV)
+    out.append(seen[id(g)])
+  return out
+
+
+# ---------------------------------------------------------------------------- #
+# Golden fixtures of the real reference
+
+@pytest.mark.parametrize("name", CASES + HAND_CASES)
+def test_golden_colwise(bm, name):
+  g = Golden(name)
+  dev = to_dev(g.gradients)
+  assert same_bits(bm.median(dev), g.tensor("median"))  # bit-exact, NaN columns included
+  if g.has("trmean"):
+    assert close(bm.trmean(dev, g.f), g.tensor("trmean"), 1e-6)
+    st = torch.stack(g.gradients)
+    for rule, centre in (("phocas", O.trmean(g.gradients, g.f)), ("meamed", O.median(g.gradients))):
+      got = bm.gars.__dict__[rule](dev, g.f).cpu()
+      want = g.tensor(rule)
+      _, amb = O.closest_window(torch.nan_to_num(st, nan=math.inf), g.n - g.f, centre)
+      scale = float(st[torch.isfinite(st)].abs().max())
+      per_col = ((got.double() - want.double()).abs() <= 2e-6 * scale) | (torch.isnan(got) & torch.isnan(want))
+      assert bool((per_col | amb | torch.isnan(centre)).all()), rule
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_krum(bm, name):
+  g = Golden(name)
+  dev = to_dev(g.gradients)
+  m = g.n - g.f - 2
+  want_order = g.array("krum_order").tolist()
+  got_sel = bm.gars.krum_selection(dev, g.f)
+  if name.startswith("iid"):
+    # iid rows: scores within rounding of each other, the order is ill-conditioned;
+    # require agreement with the float64 oracle instead, gated by the decisive gap
+    order64, scores64 = O.krum_order(g.gradients, g.f, "f64")
+    srt = sorted(scores64)
+    if srt[m] - srt[m - 1] > 1e-6 * srt[m]:
+      assert sorted(got_sel) == sorted(order64[:m])
+  else:
+    assert got_sel == want_order[:m]  # bit-identical selection, in score order
+    assert same_bits(bm.krum(dev, g.f), g.tensor("krum"))        # hence a bit-identical average
+    assert same_bits(bm.krum(dev, g.f, 1), g.tensor("krum_m1"))
+    # scores: ours use exact distances, the reference's fp32 norm is ~1e-6 off at this d
+    _, scores = bm.gars._rank(dev, g.f, m, bm._lib.RANK_KRUM)
+    got_scores = [scores[i].item() for i in want_order]
+    for a, b in zip(got_scores, g.array("krum_scores").tolist()):
+      assert (math.isinf(a) and math.isinf(b)) or abs(a - b) <= 1e-5 * abs(b)
+
+
+@pytest.mark.parametrize("name", [c for c in CASES if Golden(c).has("bulyan") and not c.startswith("iid")])
+def test_golden_bulyan(bm, name):
+  g = Golden(name)
+  dev = to_dev(g.gradients)
+  ref_order, _ = O.bulyan_order(g.gradients, g.f)
+  assert bm.gars.bulyan_ranking(dev, g.f) == ref_order
+  scale = float(torch.stack(g.honests).abs().max())
+  assert close(bm.bulyan(dev, g.f), g.tensor("bulyan"), 2e-6, scale)
+  assert close(bm.bulyan(dev, g.f, 3), g.tensor("bulyan_m3"), 2e-6, scale)
+
+
+@pytest.mark.parametrize("name", [c for c in CASES if not c.startswith("iid")])
+def test_golden_brute_aksel_average_cge(bm, name):
+  g = Golden(name)
+  dev = to_dev(g.gradients)
+  if g.has("brute"):
+    assert bm.gars.brute_selection(dev, g.f) == g.array("brute_selection").tolist()
+    assert same_bits(bm.brute(dev, g.f), g.tensor("brute"))
+  if not name.startswith("nan"):  # NaN distances: the reference's own order is unspecified (Python sort of NaN)
+    assert bm.gars.aksel_selection(dev, g.f, "n-f") == g.array("aksel_order").tolist()[:g.n - g.f]
+    assert same_bits(bm.aksel(dev, g.f, "mid"), g.tensor("aksel_mid"))
+    assert same_bits(bm.aksel(dev, g.f, "n-f"), g.tensor("aksel_n-f"))
+    assert same_bits(bm.cge(dev, g.f), g.tensor("cge"))
+  assert same_bits(bm.average(dev), g.tensor("average"))
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_golden_stats(bm, name):
+  g = Golden(name)
+  for prefix, samples in (("honest", g.honests), ("attack", g.attacks)):
+    if not g.has(prefix + "_stats"):
+      continue
+    avg, norm, dev, mx = bm.compute_avg_dev_max(to_dev(samples))
+    assert same_bits(avg, g.tensor(prefix + "_avg"))  # sequential mean: bit-exact
+    want = g.array(prefix + "_stats").tolist()
+    scale = want[0] if math.isfinite(want[0]) else 1.0
+    for a, b in zip((norm, dev, mx), want):
+      assert (math.isnan(a) and math.isnan(b)) or abs(a - b) <= 1e-5 * max(abs(b), scale), (prefix, a, b)
+
+
+# ---------------------------------------------------------------------------- #
+# Every row count the kernels are instantiated for, odd lengths, unaligned views
+
+@pytest.mark.parametrize("n", list(range(1, 65)))
+def test_every_n_median_trmean(bm, n):
+  gen = torch.Generator().manual_seed(1000 + n)
+  d = 2051  # not a multiple of 4: vector body + scalar tail
+  rows = [torch.randn(d, generator=gen) for _ in range(n)]
+  dev = [r.to(DEV) for r in rows]
+  assert torch.equal(bm.median(dev).cpu(), torch.stack(rows).median(dim=0).values)
+  f = (n - 1) // 2
+  if f >= 1:
+    for ff in sorted({1, f}):
+      assert close(bm.trmean(dev, ff), O.trmean(rows, ff), 1e-6)
+      st = torch.stack(rows)
+      got = bm.meamed(dev, ff).cpu().double()
+      win, amb = O.closest_window(st, n - ff, st.median(dim=0).values)
+      assert bool((((got - win).abs() <= 2e-6 * float(st.abs().max())) | amb).all())
+
+
+@pytest.mark.parametrize("offset", [0, 1, 2, 3])
+def test_unaligned_rows_and_tails(bm, offset):
+  """Rows that are views at 4/8/12-byte offsets (e.g. slices of one flat buffer) take the narrower
+  vector paths; results must not change."""
+  n, f, d = 13, 3, 4099
+  gen = torch.Generator().manual_seed(77)
+  flat = torch.randn(n * (d + 8), generator=gen).to(DEV)
+  dev = [flat[i * (d + 8) + offset: i * (d + 8) + offset + d] for i in range(n)]
+  rows = [t.cpu() for t in dev]
+  assert torch.equal(bm.median(dev).cpu(), O.median(rows))
+  assert close(bm.trmean(dev, f), O.trmean(rows, f), 1e-6)
+  assert bm.gars.krum_selection(dev, f) == O.krum_order(rows, f, "f64")[0][:n - f - 2]
+  assert torch.equal(bm.krum(dev, f).cpu(), O.krum(rows, f))
+  assert torch.equal(bm.average(dev).cpu(), O.average(rows))
+  avg, norm, devi, mx = bm.compute_avg_dev_max(dev)
+  wavg, wnorm, wdev, wmx = O.compute_avg_dev_max(rows, "f64")
+  assert torch.equal(avg.cpu(), O.compute_avg_dev_max(rows)[0])
+  assert abs(norm - wnorm) <= 1e-6 * wnorm and abs(devi - wdev) <= 1e-6 * wdev and abs(mx - wmx) <= 1e-6 * wmx
+
+
+def test_empty_and_tiny_lengths(bm):
+  rows = [torch.zeros(0, device=DEV) for _ in range(5)]
+  assert bm.median(rows).shape == (0,)
+  assert bm.trmean(rows, 1).shape == (0,)
+  one = [torch.tensor([float(i)], device=DEV) for i in (3, 1, 2, 5, 4)]
+  assert bm.median(one).item() == 3.0 and bm.trmean(one, 1).item() == 3.0
+  assert math.isfinite(bm.krum(one, 1).item())
+
+
+def test_nan_semantics(bm):
+  """torch 2.10: median propagates NaN; sort puts NaN last so trmean is NaN iff > f NaNs."""
+  n, f, d = 9, 2, 1030
+  gen = torch.Generator().manual_seed(5)
+  rows = [torch.randn(d, generator=gen) for _ in range(n)]
+  rows[1][::7] = math.nan
+  rows[4][::7] = math.nan
+  rows[6][::21] = math.nan        # 3 NaNs in every 21st column (> f)
+  rows[2][5] = math.inf
+  rows[3][5] = -math.inf
+  dev = [r.to(DEV) for r in rows]
+  assert same_bits(bm.median(dev), O.median(rows))
+  got, want = bm.trmean(dev, f).cpu(), O.trmean(rows, f)
+  assert bool((torch.isnan(got) == torch.isnan(want)).all())
+  assert close(got, want, 1e-6)
+  got, want = bm.phocas(dev, f).cpu(), O.phocas(rows, f)
+  ok = torch.isnan(want) | ((got - want).abs() <= 1e-5)   # where the reference is finite we agree
+  assert bool(ok.all())
+
+
+# ---------------------------------------------------------------------------- #
+# Seeded stacks at a moderate size against both oracle modes
+
+@pytest.mark.parametrize("kind,n,f", [("hetero", 25, 5), ("little", 25, 5), ("hetero", 51, 12), ("hetero", 11, 2)])
+def test_seeded_stack_100k(bm, kind, n, f):
+  d = 100003
+  rows, h = O.make_stack(kind, n, f, d, seed=99)
+  dev = to_dev(rows)
+  m = n - f - 2
+  # selections: identical to the reference-faithful f32 oracle AND the float64 truth
+  o32, _ = O.krum_order(rows, f, "f32")
+  o64, _ = O.krum_order(rows, f, "f64")
+  sel = bm.gars.krum_selection(dev, f)
+  assert sel == o32[:m] == o64[:m]
+  assert torch.equal(bm.krum(dev, f).cpu(), O.krum(rows, f))
+  if n >= 4 * f + 3:
+    assert bm.gars.bulyan_ranking(dev, f) == O.bulyan_order(rows, f, None, "f64")[0]
+    scale = float(torch.stack(rows[:h]).abs().max())
+    assert close(bm.bulyan(dev, f), O.bulyan(rows, f), 2e-6, scale)
+  assert bm.gars.aksel_selection(dev, f) == O.aksel_order(rows, "f64")[0][:(n + 1) // 2]
+  assert torch.equal(bm.aksel(dev, f).cpu(), O.aksel(rows, f))
+  assert torch.equal(bm.median(dev).cpu(), O.median(rows))
+  assert close(bm.trmean(dev, f), O.trmean(rows, f), 1e-6)
+  # squared distances against float64
+  sq = bm.gars.pairwise_sqdist(dev).cpu()
+  d64 = torch.from_numpy(O.pairwise_distances(rows, "f64")) ** 2
+  assert close(sq, d64, 1e-6, float(d64.max()) * 1e-3)
+  assert bool((sq.diagonal() == 0).all()) and torch.equal(sq, sq.T)
+  # aliased Byzantine rows: exact zeros between them, bitwise-equal distances to everyone else
+  for a in range(h + 1, n):
+    assert sq[h, a].item() == 0.0
+    assert torch.equal(sq[h, :h], sq[a, :h])
+
+
+def test_study_block_and_momentum(bm):
+  n, f, d = 25, 5, 50021
+  rows, h = O.make_stack("hetero", n, f, d, seed=3)
+  dev = to_dev(rows)
+  gen = torch.Generator().manual_seed(8)
+  pasts = [torch.randn(d, generator=gen) for _ in range(5)]
+  defense = O.krum(rows, f)
+  want = O.study_block(rows[:h], rows[:h], rows[h:], defense, [(p, p.norm().item()) for p in pasts], 0.9, "f64")
+  s_avg, s_norm, s_dev, s_max = bm.compute_avg_dev_max(dev[:h])
+  a_avg, a_norm, a_dev, a_max = bm.compute_avg_dev_max(dev[h:])
+  gram, extra = bm.stats.study_dots([s_avg, a_avg, defense.to(DEV)], [p.to(DEV) for p in pasts])
+  gram, extra = gram.cpu(), extra.cpu()
+  assert abs(math.sqrt(gram[0, 0]) - want["sampled_norm_avg"]) <= 1e-6 * want["sampled_norm_avg"]
+  assert abs(s_dev - want["sampled_norm_dev"]) <= 1e-6 * want["sampled_norm_dev"]
+  assert abs(a_dev - want["attack_norm_dev"]) <= 1e-5 * max(want["attack_norm_dev"], a_norm)
+  cos_sa = gram[0, 1].item() / math.sqrt(gram[0, 0].item()) / math.sqrt(gram[1, 1].item())
+  assert abs(cos_sa - want["cosin_splatt"]) <= 1e-5
+  cos_sd = gram[0, 2].item() / math.sqrt(gram[0, 0].item()) / math.sqrt(gram[2, 2].item())
+  assert abs(cos_sd - want["cosin_spldef"]) <= 1e-5
+  curv = 0.9 * sum(0.9 ** i * extra[i].item() for i in range(len(pasts)))
+  assert abs(curv - want["curv_sampled"]) <= 1e-5 * max(abs(want["curv_sampled"]), 1.0)
+  # worker momentum, in place, bit-exact against torch's fused mul_/add_
+  bufs = [torch.randn(d, generator=gen) for _ in range(h)]
+  dbufs = [b.to(DEV) for b in bufs]
+  bm.stats.multi_axpby(dbufs, dev[:h], 0.99, 1.0 - 0.1)
+  O.worker_momentum(bufs, rows[:h], 0.99, 0.1)
+  for a, b in zip(dbufs, bufs):
+    assert close(a, b, 1e-6)
+
+
+def test_generic_bulyan_kernel_equals_specialised(bm, monkeypatch):
+  """(n, f) outside the register-resident table and m != m_max go through the LDS kernel."""
+  for n, f, m in ((13, 2, None), (25, 5, 7), (29, 6, None)):
+    rows, h = O.make_stack("hetero", n, f, 3001, seed=21)
+    dev = to_dev(rows)
+    scale = float(torch.stack(rows[:h]).abs().max())
+    assert close(bm.bulyan(dev, f, m), O.bulyan(rows, f, m), 2e-6, scale)
+
+
+# ---------------------------------------------------------------------------- #
+# Full size (BASELINE.json configs 2-4): size-independent properties + torch on the same GPU
+
+@pytest.fixture(scope="module")
+def full_stack():
+  n, f, d = 25, 5, 11173962
+  gen = torch.Generator(device=DEV).manual_seed(99)
+  mu = 0.1 * torch.randn(d, device=DEV, generator=gen)
+  h = n - f
+  sig = torch.linspace(0.5, 1.5, h)
+  honest = [mu + sig[i].item() * torch.randn(d, device=DEV, generator=gen) for i in range(h)]
+  byz = torch.stack(honest).mean(dim=0).mul_(-0.1)
+  return honest + [byz] * f, h, f
+
+
+def test_full_size_colwise_properties(bm, full_stack):
+  rows, h, f = full_stack
+  n = len(rows)
+  med = bm.median(rows)
+  st = torch.stack(rows)
+  assert torch.equal(med, st.median(dim=0).values)                 # same GPU, torch's own kernel
+  tm = bm.trmean(rows, f)
+  ref_tm = st.sort(dim=0).values[f:n - f].mean(dim=0)
+  assert close(tm, ref_tm, 1e-6)
+  del st, ref_tm
+  perm = [rows[i] for i in torch.randperm(n).tolist()]
+  assert torch.equal(bm.median(perm), med)                          # permutation invariance, bitwise
+  assert torch.equal(bm.trmean(perm, f), tm)                        # sorted-order sum: also bitwise
+  doubled = [r * 2 for r in rows[:h]] + [rows[h] * 2] * f
+  assert torch.equal(bm.median(doubled), med * 2)                   # exact scaling by a power of two
+  assert torch.equal(bm.trmean(doubled, f), tm * 2)
+  assert torch.equal(bm.median([rows[3]] * n), rows[3])             # idempotence
+  assert close(bm.trmean([rows[3]] * n, f), rows[3], 1e-6)          # (15 r)/15 rounds in fp32
+  lo = torch.stack(rows).min(dim=0).values
+  assert bool((med >= lo).all())
+
+
+def test_full_size_krum_bulyan_properties(bm, full_stack):
+  rows, h, f = full_stack
+  n = len(rows)
+  sq = bm.gars.pairwise_sqdist(rows).cpu()
+  assert torch.equal(sq, sq.T) and bool((sq.diagonal() == 0).all())
+  for a in range(h + 1, n):
+    assert sq[h, a].item() == 0.0 and torch.equal(sq[h, :h], sq[a, :h])
+  # a few entries against float64 on the GPU
+  for (i, j) in ((0, 1), (3, 17), (7, 22), (19, 24)):
+    want = (rows[i].double() - rows[j].double()).pow(2).sum().item()
+    assert abs(sq[i, j].item() - want) <= 1e-6 * want
+  sel = bm.gars.krum_selection(rows, f)
+  # empire Byzantine rows sit at -0.1*mean: they are the closest to everyone and get selected first,
+  # tied scores resolved by index (the reference's stable sort)
+  assert sel[:f] == list(range(h, n))
+  # the average of the selected rows equals torch's sequential sum on the same GPU
+  want = sum(rows[i] for i in sel)                                  # same order, same fp32 adds
+  assert close(bm.krum(rows, f), want / len(sel), 2e-7)             # torch-GPU divides by reciprocal
+  order = bm.gars.bulyan_ranking(rows, f)
+  assert sorted(order) == list(range(n))
+  out = bm.bulyan(rows, f)
+  assert bool(torch.isfinite(out).all())
+  top = torch.stack([rows[i] for i in order[:n - f - 2]])
+  assert bool((out <= top.max(dim=0).values).all() and (out >= top.min(dim=0).values).all())

@@ -1,0 +1,105 @@
+"""Host-side logic that needs no GPU: input validation (loud failure instead of a CPU fallback),
+the Brute subset search of the C ABI (pure host code), and the drop-in registration into the
+reference's registry."""
+
+import ctypes
+import itertools
+import math
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gar_oracle as O
+from tests.golden_io import CASES, Golden
+
+
+def test_cpu_tensors_are_refused_loudly():
+  import byzantinemomentum_amd as bm
+  g = [torch.randn(16) for _ in range(7)]
+  for call in (lambda: bm.median(g), lambda: bm.trmean(g, 1), lambda: bm.krum(g, 1), lambda: bm.bulyan(g, 1),
+               lambda: bm.brute(g, 1), lambda: bm.aksel(g, 1), lambda: bm.compute_avg_dev_max(g)):
+    with pytest.raises(bm.gars.GarInputError, match="no CPU fallback"):
+      call()
+
+
+def test_product_never_imports_the_oracle():
+  """Static check: nothing under byzantinemomentum_amd/ or native/ mentions the oracle package."""
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  for pkg in ("byzantinemomentum_amd", "native"):
+    for dirpath, _, files in os.walk(os.path.join(root, pkg)):
+      for name in files:
+        if name.endswith(".py"):
+          text = open(os.path.join(dirpath, name)).read()
+          assert "import oracle" not in text and "from oracle" not in text, os.path.join(dirpath, name)
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+  from byzantinemomentum_amd import _lib
+  monkeypatch.setattr(_lib, "_lib", None)
+  monkeypatch.setattr(_lib, "LIB_PATH", tmp_path / "libbm_gar.so")
+  with pytest.raises(_lib.NativeLibraryError, match="no CPU fallback"):
+    _lib.load()
+
+
+def _brute_select(dist, n, f):
+  from byzantinemomentum_amd import _lib
+  lib = _lib.load()
+  dist = np.ascontiguousarray(dist, dtype=np.float64)
+  sel = (ctypes.c_int32 * (n - f))()
+  rc = lib.bm_brute_select(dist.ctypes.data_as(ctypes.c_void_p), n, f, ctypes.cast(sel, ctypes.c_void_p))
+  return rc, list(sel)
+
+
+@pytest.mark.parametrize("name", [c for c in CASES if Golden(c).has("brute_selection")])
+def test_brute_select_matches_reference_fixture(name):
+  g = Golden(name)
+  dist = O.pairwise_distances(g.gradients, "f32", clamp_nonfinite=False)
+  rc, sel = _brute_select(dist, g.n, g.f)
+  assert rc == 0 and sel == g.array("brute_selection").tolist()
+
+
+def test_brute_select_random_matrices_against_exhaustive_search():
+  rng = np.random.default_rng(3)
+  for n, f in ((6, 1), (8, 3), (10, 2), (12, 5)):
+    for trial in range(20):
+      pts = rng.integers(0, 6, size=(n, 2)).astype(np.float64)  # many exact ties
+      dist = np.sqrt(((pts[:, None] - pts[None]) ** 2).sum(-1))
+      if trial % 5 == 0:
+        bad = rng.integers(0, n)
+        dist[bad, :] = dist[:, bad] = math.nan
+        dist[bad, bad] = 0
+      best, best_d = None, None
+      for sub in itertools.combinations(range(n), n - f):
+        blk = dist[np.ix_(sub, sub)]
+        if not np.isfinite(blk).all():
+          continue
+        dm = blk.max()
+        if best is None or dm < best_d:
+          best, best_d = list(sub), dm
+      rc, sel = _brute_select(dist, n, f)
+      if best is None:
+        assert rc != 0
+      else:
+        assert rc == 0 and sel == best
+
+
+@pytest.mark.reference
+def test_reference_discovers_native_package():
+  """`import aggregators` of the UNMODIFIED reference with the repo on PYTHONPATH registers the
+  native-* rules (aggregators/krum.py:22-26,159-166 and our own calls to aggregators.register)."""
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  code = ("import aggregators, sys\n"
+          "names = sorted(n for n in aggregators.gars if n.startswith('native-'))\n"
+          "print(','.join(names))\n"
+          "assert aggregators.gars['native-aksel'].influence is not None\n"
+          "assert aggregators.gars['native-trmean'].check(gradients=[1], f=1) is not None\n")
+  env = dict(os.environ, PYTHONPATH=os.pathsep.join([root, "/root/reference"]))
+  out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd="/tmp")
+  assert out.returncode == 0, out.stderr
+  names = out.stdout.strip().splitlines()[-1].split(",")
+  assert names == ["native-aksel", "native-average", "native-brute", "native-bulyan", "native-cge", "native-krum",
+                   "native-meamed", "native-median", "native-phocas", "native-trmean"]

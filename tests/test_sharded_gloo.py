@@ -1,0 +1,108 @@
+"""The N>1 path on CPU: two processes, gloo backend, each holding half of the coordinates.
+Selections must equal the single-process result, coordinate-wise outputs must equal the
+corresponding slices, and the all-gathered vector must equal the unsharded aggregation."""
+
+import math
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import gar_oracle as O
+
+N, F, D = 11, 2, 1000
+
+
+def _free_port():
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    return s.getsockname()[1]
+
+
+def _worker(rank, world, port, queue):
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  try:
+    from byzantinemomentum_amd.sharded import ShardedAggregator, shard_bounds
+    from tests.sharded_backend import OracleBackend
+    rows, h = O.make_stack("hetero", N, F, D, seed=42)
+    lo, hi = shard_bounds(D, world, rank)
+    seen = {}
+    local = []
+    for g in rows:  # keep the aliasing of the Byzantine rows
+      if id(g) not in seen:
+        seen[id(g)] = g[lo:hi].clone()
+      local.append(seen[id(g)])
+    agg = ShardedAggregator(backend=OracleBackend())
+    assert agg.world_size == world
+    res = {}
+    for name, fn in (("median", lambda: agg.median(local)), ("trmean", lambda: agg.trmean(local, F)),
+                     ("krum", lambda: agg.krum(local, F)), ("krum1", lambda: agg.krum(local, F, 1)),
+                     ("bulyan", lambda: agg.bulyan(local, F)), ("aksel", lambda: agg.aksel(local, F))):
+      res[name] = agg.all_gather_output(fn(), D)
+    avg, norm, dev, mx = agg.compute_avg_dev_max(local[:h])
+    res["avg"] = agg.all_gather_output(avg, D)
+    res["stats"] = (norm, dev, mx)
+    res["sq"] = agg.global_sqdist(local)
+    queue.put((rank, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in res.items()}))
+    dist.barrier()
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_sharded_aggregation_matches_single_process():
+  world = 2
+  ctx = mp.get_context("spawn")
+  queue = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_worker, args=(r, world, port, queue)) for r in range(world)]
+  for p in procs:
+    p.start()
+  results = dict(queue.get(timeout=240) for _ in range(world))
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  rows, h = O.make_stack("hetero", N, F, D, seed=42)
+  want = {"median": O.median(rows), "trmean": O.trmean(rows, F), "krum": O.krum(rows, F), "krum1": O.krum(rows, F, 1),
+          "bulyan": O.bulyan(rows, F), "aksel": O.aksel(rows, F)}
+  for r in range(world):
+    got = results[r]
+    for name, ref in want.items():
+      assert got[name].shape == ref.shape
+      if name in ("median", "krum", "krum1", "aksel"):
+        assert torch.equal(got[name], ref), (r, name)      # same selection, same sequential sums
+      else:
+        assert torch.allclose(got[name], ref, rtol=0, atol=2e-6), (r, name)
+    avg, norm, dev, mx = O.compute_avg_dev_max(rows[:h], "f64")
+    assert torch.allclose(got["avg"].double(), avg, atol=1e-6)
+    assert abs(got["stats"][0] - norm) <= 1e-6 * norm and abs(got["stats"][1] - dev) <= 1e-6 * dev
+    assert abs(got["stats"][2] - mx) <= 1e-6 * mx
+    d64 = torch.from_numpy(O.pairwise_distances(rows, "f64")) ** 2
+    assert torch.allclose(got["sq"], d64, rtol=1e-12)
+  assert torch.equal(results[0]["sq"], results[1]["sq"])   # every rank ranks the same bits
+
+
+def test_shard_bounds_cover_everything_once():
+  from byzantinemomentum_amd.sharded import shard_bounds
+  for d in (1, 63, 64, 65, 1000, 11173962, 36546980):
+    for world in (1, 2, 4, 8):
+      spans = [shard_bounds(d, world, r) for r in range(world)]
+      assert spans[0][0] == 0 and spans[-1][1] == d
+      for (a, b), (c, e) in zip(spans, spans[1:]):
+        assert b == c and a <= b and c <= e
+      assert all(lo % 64 == 0 or lo == d for lo, _ in spans)  # empty trailing shards sit at d
+
+
+def test_single_process_issues_no_collective():
+  from byzantinemomentum_amd.sharded import ShardedAggregator
+  from tests.sharded_backend import OracleBackend
+  assert not dist.is_initialized()
+  agg = ShardedAggregator(backend=OracleBackend())
+  rows, _ = O.make_stack("hetero", N, F, 257, seed=1)
+  assert agg.world_size == 1
+  assert torch.equal(agg.krum(rows, F), O.krum(rows, F))
+  assert torch.equal(agg.all_gather_output(agg.median(rows), 257), O.median(rows))
