@@ -159,7 +159,7 @@ def selected_mean(gradients, idx, m):
   if d == 0:
     return out
   with torch.cuda.device(device):
-    _lib.check(lib.bmselected_mean(_lib.pointer_table(gradients), n, _ptr(idx), m, d, _ptr(out),
+    _lib.check(lib.bm_selected_mean(_lib.pointer_table(gradients), n, _ptr(idx), m, d, _ptr(out),
                                     _stream(device)), "bm_selected_mean")
   return out
 
