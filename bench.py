@@ -80,29 +80,51 @@ class KernelTimer:
     return sum(a.elapsed_time(b) for a, b in ps) / len(ps)
 
 
+def _pick_threads(fn):
+  """The host has far more hardware threads than torch's CPU kernels can use on these shapes;
+  time a small sample at a few thread counts and keep the fastest (reported as `cores`)."""
+  total = os.cpu_count() or 1
+  best, best_t = total, None
+  for threads in sorted({min(total, c) for c in (16, 32, 64, total // 2, total)}):
+    if threads < 1:
+      continue
+    torch.set_num_threads(threads)
+    fn()
+    t0 = time.perf_counter()
+    fn()
+    dt = time.perf_counter() - t0
+    if best_t is None or dt < best_t:
+      best, best_t = threads, dt
+  torch.set_num_threads(best)
+  return best
+
+
 def cpu_baseline_colwise(stack, f):
   from oracle import gar_oracle as O
-  torch.set_num_threads(os.cpu_count())
   rows = [g.cpu() for g in stack[:len(stack) - f]] + [stack[-1].cpu()] * f
-  O.median(rows)  # warm
+  d = rows[0].shape[0]
+  small = [r[:d // 16] for r in rows[:len(rows) - f]] + [rows[-1][:d // 16]] * f
+  threads = _pick_threads(lambda: (O.median(small), O.trmean(small, f)))
   t0 = time.perf_counter()
   reps = 2
   for _ in range(reps):
     O.median(rows)
     O.trmean(rows, f)
   dt = (time.perf_counter() - t0) / reps
-  return {"value": 2.0 / dt, "unit": "agg/s", "cores": torch.get_num_threads(), "kind": "port",
+  return {"value": 2.0 / dt, "unit": "agg/s", "cores": threads, "kind": "port",
           "sample": f"oracle f32 port (torch.stack+median, torch.stack+sort+mean: the reference's ops) on the same "
-                    f"n={len(rows)} x d={rows[0].shape[0]} stack, {reps} passes of median+trmean, "
-                    f"{dt:.3f} s per pass"}
+                    f"n={len(rows)} x d={d} stack, {reps} passes of median+trmean, {dt:.3f} s per pass, "
+                    f"{threads} torch threads (fastest of 16/32/64/{(os.cpu_count() or 2) // 2}/{os.cpu_count()} "
+                    f"on a d/16 sample; host has {os.cpu_count()} hardware threads)"}
 
 
 def cpu_baseline_distance(stack, f, rule, d_sample):
   from oracle import gar_oracle as O
-  torch.set_num_threads(os.cpu_count())
   n = len(stack)
   byz = stack[-1][:d_sample].cpu()
   rows = [g[:d_sample].cpu() for g in stack[:n - f]] + [byz] * f
+  tiny = [r[:d_sample // 16] for r in rows[:n - f]] + [byz[:d_sample // 16]] * f
+  _pick_threads(lambda: O.krum(tiny, f))
   t0 = time.perf_counter()
   (O.krum if rule == "krum" else O.bulyan)(rows, f)
   dt = time.perf_counter() - t0

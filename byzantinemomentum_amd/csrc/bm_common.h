@@ -13,6 +13,21 @@ namespace bm {
 // trmean.py:79) — the n x d copy is never made.
 struct RowTable {
   const float* p[BM_MAX_ROWS];
+  // Row pointer for a run-time row index.  The table lives in the kernarg segment; a divergent
+  // index would make the compiler spill the whole table to scratch, so the lookup is done per
+  // wave-uniform value (one s_load per distinct index in the wave, usually 1-2).
+  __device__ __forceinline__ const float* p_dyn(int r) const {
+    const float* res = nullptr;
+    bool done = false;
+    while (!done) {
+      const int ur = __builtin_amdgcn_readfirstlane(r);
+      if (r == ur) {
+        res = p[ur];
+        done = true;
+      }
+    }
+    return res;
+  }
 };
 struct MutRowTable {
   float* p[BM_MAX_ROWS];
@@ -184,7 +199,7 @@ struct Tuning {
   int force_vec;       // BM_FORCE_VEC: 0 auto, 1 or 2 force a narrower column vector
   int col_max_blocks;  // BM_COL_MAX_BLOCKS: grid cap of the column kernels
   int pair_blocks;     // BM_PAIR_BLOCKS: persistent grid of the pairwise-distance kernel
-  int pair_unroll;     // BM_PAIR_UNROLL: 1 (default) or 2 slots per inner-loop trip
+  int pair_strips;     // BM_PAIR_STRIPS: force 1, 2 or 4 strips per LDS tile (0 = automatic)
 };
 const Tuning& tuning();
 }  // namespace bm

@@ -21,19 +21,21 @@
 namespace bm {
 
 template <int N, int OP, int VEC>
-static int launch_colwise_vec(const RowTable& rows, int64_t nvec, int f, float* out,
+static int launch_colwise_vec(const RowTable& rows, int64_t d, int f, float* out,
                               hipStream_t stream) {
-  if (nvec <= 0) return 0;
+  const int64_t nvec = d / VEC;
+  const int tail = (int)(d - nvec * VEC);
   const int keep = (OP == BM_OP_TRMEAN) ? (N - 2 * f) : (N - f);
   const float inv_keep = 1.0f / (float)(keep > 0 ? keep : 1);
   const int grid = stream_grid(nvec, kColBlock, tuning().col_max_blocks);
   hipLaunchKernelGGL((colwise_kernel<N, OP, VEC>), dim3(grid), dim3(kColBlock), 0, stream, rows,
-                     nvec, f, inv_keep, out);
+                     nvec, tail, f, inv_keep, out);
   BM_LAUNCH_CHECK();
   return 0;
 }
 
-// Body with the widest vector the pointers allow, remaining (d % VEC) columns one by one.
+// One launch: vector body with the widest vector the pointers allow, the d % VEC trailing
+// columns are handled by the last workgroup of the same kernel.
 template <int N, int OP>
 static int launch_colwise_n(const float* const* rows_host, int64_t d, int f, float* out,
                             hipStream_t stream) {
@@ -45,22 +47,11 @@ static int launch_colwise_n(const float* const* rows_host, int64_t d, int f, flo
   if (vec > kMaxVec) vec = kMaxVec;
   const int forced = tuning().force_vec;  // experiment knob (BM_FORCE_VEC), 0 = automatic
   if (forced == 1 || (forced == 2 && vec >= 2)) vec = forced;
-  int64_t body = 0;
-  int rc = 0;
-  if (vec == 4 && kMaxVec >= 4) {
-    body = (d / 4) * 4;
-    rc = launch_colwise_vec < N, OP, (kMaxVec >= 4 ? 4 : 1) > (tab, d / 4, f, out, stream);
-  } else if (vec == 2 && kMaxVec >= 2) {
-    body = (d / 2) * 2;
-    rc = launch_colwise_vec < N, OP, (kMaxVec >= 2 ? 2 : 1) > (tab, d / 2, f, out, stream);
-  }
-  if (rc != 0) return rc;
-  if (body < d) {
-    RowTable tail{};
-    for (int i = 0; i < N; ++i) tail.p[i] = rows_host[i] + body;
-    rc = launch_colwise_vec<N, OP, 1>(tail, d - body, f, out + body, stream);
-  }
-  return rc;
+  if (vec == 4 && kMaxVec >= 4)
+    return launch_colwise_vec < N, OP, (kMaxVec >= 4 ? 4 : 1) > (tab, d, f, out, stream);
+  if (vec == 2 && kMaxVec >= 2)
+    return launch_colwise_vec < N, OP, (kMaxVec >= 2 ? 2 : 1) > (tab, d, f, out, stream);
+  return launch_colwise_vec<N, OP, 1>(tab, d, f, out, stream);
 }
 
 template <int OP, int... Ns>

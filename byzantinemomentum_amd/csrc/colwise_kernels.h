@@ -74,8 +74,8 @@ __device__ __forceinline__ float column_rule(float (&x)[N], int f, float inv_kee
 }
 
 template <int N, int OP, int VEC>
-__global__ __launch_bounds__(kColBlock) void colwise_kernel(RowTable rows, int64_t nvec, int f,
-                                                            float inv_keep,
+__global__ __launch_bounds__(kColBlock) void colwise_kernel(RowTable rows, int64_t nvec, int tail,
+                                                            int f, float inv_keep,
                                                             float* __restrict__ out) {
   constexpr bool kNeedsLds = (OP == BM_OP_PHOCAS || OP == BM_OP_MEAMED);
   __shared__ float scratch[kNeedsLds ? N * kColBlock : 1];
@@ -95,6 +95,14 @@ __global__ __launch_bounds__(kColBlock) void colwise_kernel(RowTable rows, int64
 #pragma unroll
     for (int c = 0; c < VEC; ++c) r[c] = column_rule<N, OP>(x[c], f, inv_keep, lds);
     store_stream<VEC>(out + v * VEC, r);
+  }
+  // the d % VEC trailing columns: one lane each, in the last workgroup (no second launch)
+  if (VEC > 1 && blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < tail) {
+    const int64_t j = nvec * VEC + threadIdx.x;
+    float x[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = rows.p[i][j];
+    out[j] = column_rule<N, OP>(x, f, inv_keep, lds);
   }
 }
 

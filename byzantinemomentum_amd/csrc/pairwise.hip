@@ -10,11 +10,12 @@
 // ties, broken by index like the reference's stable sort, krum.py:62).
 //
 // Kernel shape (gfx950):
-//   * a workgroup stages a [rows][64*S coords] tile in LDS (coalesced float4 global reads);
+//   * a workgroup stages a [rows][64*S coords] tile in LDS with the LDS-DMA engine
+//     (global_load_lds_dwordx4, 1 KiB per wave instruction, no staging VGPRs, no ds_write);
 //   * the n rows are cut in groups of 4; a lane owns ONE 4x4 pair tile (I <= J) and one
 //     64-coordinate strip, keeps its 16 (x2, packed even/odd) fp32 accumulators in VGPRs for the
 //     whole kernel, and per step reads 8 x ds_read_b128 and issues 32 v_pk_add + 32 v_pk_fma;
-//   * LDS rows are stored group-major (row 4I+a at index a*NG+I) with a one-slot (16 B) pad, and
+//   * LDS rows live in 1 KiB DMA blocks padded by one 16-B slot, block(I, a) = I + NG*(a/rb), and
 //     lanes are mapped so that each hardware ds_read_b128 service group of 16 lanes sees one
 //     strip and 16 distinct pair tiles: every read is bank-conflict free, and every pair
 //     accumulates its coordinates in the same canonical order (needed for the exact ties);
@@ -24,18 +25,21 @@
 
 namespace bm {
 
-constexpr int kPairMaxThreads = 256;
-constexpr int kTileR = 4;  // rows per group; pair tile = kTileR x kTileR
+constexpr int kPairMaxThreads = 512;
+constexpr int kTileR = 4;          // rows per group; pair tile = kTileR x kTileR
+constexpr int kDmaBlock = 1024;    // bytes moved by one wave-wide global_load_lds_dwordx4
+constexpr int kDmaPitch = 1024 + 16;  // LDS pitch of a DMA block: one 16-B slot of padding
 
 struct PairGeom {
   int n;        // rows
   int ng;       // row groups = ceil(n/4)
   int tiles;    // ng*(ng+1)/2 pair tiles (I <= J)
   int ut;       // 16-lane units per strip = ceil(tiles/16)
-  int strips;   // S
+  int strips;   // S in {1, 2, 4}: 64-coordinate strips per LDS tile
   int threads;  // 16*ut*S rounded up to 64
   int width;    // coordinates per LDS tile = 64*S
-  int stride;   // floats per LDS row = width + 4
+  int rb;       // rows per DMA block = 4/S
+  int nb;       // DMA blocks per tile = ng*S
 };
 
 static PairGeom pair_geometry(int n) {
@@ -44,15 +48,30 @@ static PairGeom pair_geometry(int n) {
   g.ng = (n + kTileR - 1) / kTileR;
   g.tiles = g.ng * (g.ng + 1) / 2;
   g.ut = (g.tiles + 15) / 16;
-  // as many strips as fit in <= 256 lanes (more lanes per workgroup = fewer LDS tile bytes per
-  // lane), at least one
-  int s = 256 / (16 * g.ut);
-  if (s < 1) s = 1;
-  if (s > 4) s = 4;
-  g.strips = s;
-  g.threads = ((16 * g.ut * s + 63) / 64) * 64;
-  g.width = 64 * s;
-  g.stride = g.width + 4;
+  // strips: best lane utilisation among S = 4, 2, 1 (ties to the wider tile = fewer barriers per
+  // byte), at most 512 lanes and 48 KB of LDS tile per workgroup
+  int best_s = 1;
+  double best_u = -1.0;
+  const int forced = tuning().pair_strips;
+  for (int s = 4; s >= 1; s >>= 1) {
+    const int lanes = 16 * g.ut * s;
+    const int thr = ((lanes + 63) / 64) * 64;
+    if (thr > kPairMaxThreads || g.ng * s * kDmaPitch > 48 * 1024) continue;
+    const double u = (double)lanes / thr;
+    if (forced == s) {
+      best_s = s;
+      break;
+    }
+    if (u > best_u + 1e-9) {
+      best_u = u;
+      best_s = s;
+    }
+  }
+  g.strips = best_s;
+  g.threads = ((16 * g.ut * best_s + 63) / 64) * 64;
+  g.width = 64 * best_s;
+  g.rb = 4 / best_s;
+  g.nb = g.ng * best_s;
   return g;
 }
 
@@ -83,22 +102,48 @@ __device__ __forceinline__ void lane_unit(int lane, int& unit, int& pos) {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <bool ALIGNED, int UNROLL>
-__global__ __launch_bounds__(kPairMaxThreads, 2) void pairwise_partial_kernel(
+// Byte offset, inside the LDS tile, of coordinate 0 of logical row 4*I + a.
+// DMA block = I + ng*(a / rb); a block holds rb rows of 256*S bytes.  Its bank slot class is
+// (I + ng*(a/rb)) mod 16: for a fixed `a`, rows of different groups I never share a 16-byte slot,
+// so a ds_read_b128 whose 16 lanes read 16 different groups is conflict free.
+__device__ __forceinline__ int row_offset_bytes(const PairGeom& g, int I, int a) {
+  const int blk = I + g.ng * (a / g.rb);
+  return blk * kDmaPitch + (a % g.rb) * (256 * g.strips);
+}
+
+// ALIGNED: every row pointer is 16-byte aligned -> full tiles are brought in by the LDS-DMA
+// engine (global_load_lds_dwordx4: no staging VGPRs, no ds_write).  Ragged last tiles and
+// unaligned inputs use a plain load + ds_write loop.
+template <bool ALIGNED>
+__global__ __launch_bounds__(kPairMaxThreads) void pairwise_partial_kernel(
     RowTable rows, PairGeom g, int64_t d, double* __restrict__ partial) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const float** row_ptr = reinterpret_cast<const float**>(smem);  // 512 B pointer table
+  char* tile = smem + BM_MAX_ROWS * sizeof(float*);
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
+  const int nwaves = blockDim.x >> 6;
+  const int tile_bytes = g.nb * kDmaPitch;
+
+  // one-time: pointer table, zeroed tile (rows >= n and block padding are never written again)
+  for (int r = tid; r < BM_MAX_ROWS; r += blockDim.x) row_ptr[r] = nullptr;
+  for (int o = tid * 16; o < tile_bytes; o += blockDim.x * 16)
+    *reinterpret_cast<f32x4*>(tile + o) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  __syncthreads();
+  if (tid == 0)
+    for (int r = 0; r < g.n; ++r) row_ptr[r] = rows.p[r];  // uniform index: scalar loads
+  __syncthreads();
+
   int unit_in_wave, pos;
   lane_unit(lane, unit_in_wave, pos);
   const int unit = wave * 4 + unit_in_wave;  // global 16-lane unit
   const int strip = unit / g.ut;
-  const int tile = (unit % g.ut) * 16 + pos;
-  const bool active = (strip < g.strips) && (tile < g.tiles);
-  // tile -> (I, J), I <= J, enumerated row-major over the upper triangle
+  const int ptile = (unit % g.ut) * 16 + pos;
+  const bool active = (strip < g.strips) && (ptile < g.tiles);
+  // pair tile -> (I, J), I <= J, enumerated row-major over the upper triangle
   int ti = 0, tj = 0;
   {
-    int t = active ? tile : 0, row_len = g.ng;
+    int t = active ? ptile : 0, row_len = g.ng;
     while (t >= row_len) {
       t -= row_len;
       --row_len;
@@ -106,13 +151,12 @@ __global__ __launch_bounds__(kPairMaxThreads, 2) void pairwise_partial_kernel(
     }
     tj = ti + t;
   }
-  const int nrows_lds = g.ng * kTileR;
-  const float* li[kTileR];
-  const float* lj[kTileR];
+  const char* li[kTileR];
+  const char* lj[kTileR];
 #pragma unroll
   for (int a = 0; a < kTileR; ++a) {
-    li[a] = lds + (a * g.ng + ti) * g.stride + strip * 64;
-    lj[a] = lds + (a * g.ng + tj) * g.stride + strip * 64;
+    li[a] = tile + row_offset_bytes(g, ti, a) + strip * 256;
+    lj[a] = tile + row_offset_bytes(g, tj, a) + strip * 256;
   }
 
   f32x2 acc[kTileR][kTileR];
@@ -122,11 +166,10 @@ __global__ __launch_bounds__(kPairMaxThreads, 2) void pairwise_partial_kernel(
     for (int b = 0; b < kTileR; ++b) acc[a][b] = f32x2{0.0f, 0.0f};
 
   const int width = g.width;
-  const int vec_per_row = width / 4;                    // 16*S float4 per LDS row
-  const int rows_per_pass = blockDim.x / vec_per_row;   // >= 1 for every geometry
-  const int sub_row = tid / vec_per_row;
-  const int col = (tid - sub_row * vec_per_row) * 4;
-  const bool loader = sub_row < rows_per_pass;
+  // DMA lane geometry: a 1 KiB block = rb rows x (16*S lanes x 16 B)
+  const int lanes_per_row = 16 * g.strips;
+  const int dma_w = lane / lanes_per_row;                 // row within the block
+  const int dma_col = (lane - dma_w * lanes_per_row) * 4;  // first coordinate of this lane
 
   // chunk c of this workgroup = blockIdx.x + c*gridDim.x (neighbouring workgroups stream
   // neighbouring addresses); the per-pair accumulation order is the same for every pair.
@@ -134,36 +177,49 @@ __global__ __launch_bounds__(kPairMaxThreads, 2) void pairwise_partial_kernel(
     const int64_t base = chunk * width;
     if (base >= d) break;
     __syncthreads();  // previous tile fully consumed
-    // ---- stage rows[*][base .. base+width) into LDS (zero fill past d and past n) ----
-    if (loader) {
-      for (int r = sub_row; r < nrows_lds; r += rows_per_pass) {
-        const int lrow = (r & (kTileR - 1)) * g.ng + (r >> 2);  // group-major LDS row
-        f32x4 val = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (ALIGNED && base + width <= d) {
+      for (int blk = wave; blk < g.nb; blk += nwaves) {
+        const int I = blk % g.ng;
+        const int a = (blk / g.ng) * g.rb + dma_w;
+        const int r = I * kTileR + a;
         if (r < g.n) {
-          const float* src = rows.p[r] + base + col;
-          const int64_t left = d - (base + col);
-          if (ALIGNED && left >= 4) {
-            val = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src));
-          } else {
-            if (left > 0) val.x = src[0];
-            if (left > 1) val.y = src[1];
-            if (left > 2) val.z = src[2];
-            if (left > 3) val.w = src[3];
-          }
+          const float* src = row_ptr[r] + base + dma_col;
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)src,
+              (__attribute__((address_space(3))) void*)(tile + blk * kDmaPitch), 16, 0, 0);
         }
-        *reinterpret_cast<f32x4*>(lds + lrow * g.stride + col) = val;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      // ragged tail / unaligned rows: plain loads with zero fill, same LDS layout
+      const int vpr = width / 4;
+      for (int idx = tid; idx < g.n * vpr; idx += blockDim.x) {
+        const int r = idx / vpr;
+        const int col = (idx - r * vpr) * 4;
+        const float* src = row_ptr[r] + base + col;
+        const int64_t left = d - (base + col);
+        f32x4 val = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (ALIGNED && left >= 4) {
+          val = *reinterpret_cast<const f32x4*>(src);
+        } else {
+          if (left > 0) val.x = src[0];
+          if (left > 1) val.y = src[1];
+          if (left > 2) val.z = src[2];
+          if (left > 3) val.w = src[3];
+        }
+        *reinterpret_cast<f32x4*>(tile + row_offset_bytes(g, r >> 2, r & 3) + col * 4) = val;
       }
     }
     __syncthreads();
     // ---- 16 slots of 4 coordinates, canonical order for every pair ----
     if (active) {
-#pragma unroll UNROLL
+#pragma unroll 1
       for (int k = 0; k < 16; ++k) {
         f32x2 xil[kTileR], xih[kTileR], xjl[kTileR], xjh[kTileR];
 #pragma unroll
         for (int a = 0; a < kTileR; ++a) {
-          const f32x4 vi = *reinterpret_cast<const f32x4*>(li[a] + k * 4);
-          const f32x4 vj = *reinterpret_cast<const f32x4*>(lj[a] + k * 4);
+          const f32x4 vi = *reinterpret_cast<const f32x4*>(li[a] + k * 16);
+          const f32x4 vj = *reinterpret_cast<const f32x4*>(lj[a] + k * 16);
           xil[a] = f32x2{vi.x, vi.y};
           xih[a] = f32x2{vi.z, vi.w};
           xjl[a] = f32x2{vj.x, vj.y};
@@ -183,13 +239,13 @@ __global__ __launch_bounds__(kPairMaxThreads, 2) void pairwise_partial_kernel(
   }
   // ---- combine strips in a fixed order, emit this workgroup's partial (fp64) ----
   __syncthreads();
-  float* red = lds;  // reuse: [strip][tile][16]
+  float* red = reinterpret_cast<float*>(tile);  // reuse: [strip][tile][16]
   if (active) {
 #pragma unroll
     for (int a = 0; a < kTileR; ++a)
 #pragma unroll
       for (int b = 0; b < kTileR; ++b)
-        red[(strip * g.tiles + tile) * 16 + a * kTileR + b] = acc[a][b].x + acc[a][b].y;
+        red[(strip * g.tiles + ptile) * 16 + a * kTileR + b] = acc[a][b].x + acc[a][b].y;
   }
   __syncthreads();
   const int per_block = g.tiles * 16;
@@ -252,50 +308,60 @@ static int pair_grid_blocks(const PairGeom& g, int64_t d) {
 }
 
 // ---------------------------------------------------------------------------
-// Score + stable rank, one workgroup of 64 lanes (lane i = row i).
+// Score + stable rank in one workgroup.  Distances of a row are ranked by counting (all n^2
+// elements in parallel), then lane i adds the `take` smallest of row i in ascending order in
+// fp64 — the same sequence of additions as the reference's `sum(sorted(...)[:take])`.
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void krum_rank_kernel(const double* __restrict__ sq, int n, int f,
-                                                       int m, int mode,
-                                                       int32_t* __restrict__ order,
-                                                       double* __restrict__ scores_out) {
+constexpr int kRankThreads = 1024;
+__global__ __launch_bounds__(kRankThreads) void krum_rank_kernel(const double* __restrict__ sq, int n,
+                                                                 int f, int m, int mode,
+                                                                 int32_t* __restrict__ order,
+                                                                 double* __restrict__ scores_out) {
   __shared__ double dist[BM_MAX_ROWS][BM_MAX_ROWS + 1];
+  __shared__ unsigned char pos[BM_MAX_ROWS][BM_MAX_ROWS];
   __shared__ double score[BM_MAX_ROWS];
-  const int i = threadIdx.x;
   const double kInf = __builtin_inf();
-  if (i < n) {
-    // distances of row i to every other row: sqrt in fp64, non-finite -> +inf (krum.py:46-47)
-    int cnt = 0;
-    for (int j = 0; j < n; ++j) {
-      if (j == i) continue;
-      double v = sqrt(sq[i * n + j]);
-      if (!(v == v) || v == kInf || v == -kInf) v = kInf;
-      // insertion sort, ascending (equal values keep arrival order; irrelevant for the sum)
-      int p = cnt++;
-      while (p > 0 && dist[i][p - 1] > v) {
-        dist[i][p] = dist[i][p - 1];
-        --p;
-      }
-      dist[i][p] = v;
-    }
-    // krum: n-f-1 smallest (krum.py:59-60); bulyan: m smallest (bulyan.py:58-61)
-    int take = (mode == BM_RANK_KRUM) ? (n - f - 1) : m;
-    if (take > cnt) take = cnt;
-    if (take < 0) take = 0;
-    double s = 0.0;
-    for (int t = 0; t < take; ++t) s += dist[i][t];
-    score[i] = s;
-    if (scores_out != nullptr) scores_out[i] = s;
+  const int tid = threadIdx.x;
+  for (int e = tid; e < n * n; e += kRankThreads) {
+    const int i = e / n, j = e - i * n;
+    // sqrt in fp64, non-finite -> +inf (krum.py:46-47)
+    double v = sqrt(sq[e]);
+    if (!(v == v) || v == kInf || v == -kInf) v = kInf;
+    dist[i][j] = v;
   }
   __syncthreads();
-  if (i < n) {
+  for (int e = tid; e < n * n; e += kRankThreads) {
+    const int i = e / n, j = e - i * n;
+    if (i == j) continue;
+    const double v = dist[i][j];
+    int rank = 0;
+    for (int l = 0; l < n; ++l) {
+      const double o = dist[i][l];
+      rank += (l != i && (o < v || (o == v && l < j))) ? 1 : 0;
+    }
+    pos[i][rank] = (unsigned char)j;
+  }
+  __syncthreads();
+  if (tid < n) {
+    // krum: n-f-1 smallest (krum.py:59-60); bulyan: m smallest (bulyan.py:58-61)
+    int take = (mode == BM_RANK_KRUM) ? (n - f - 1) : m;
+    if (take > n - 1) take = n - 1;
+    if (take < 0) take = 0;
+    double s = 0.0;
+    for (int t = 0; t < take; ++t) s += dist[tid][pos[tid][t]];
+    score[tid] = s;
+    if (scores_out != nullptr) scores_out[tid] = s;
+  }
+  __syncthreads();
+  if (tid < n) {
     // stable argsort: rank = #rows with a smaller score, ties to the lower index
-    const double si = score[i];
+    const double si = score[tid];
     int rank = 0;
     for (int j = 0; j < n; ++j) {
       const double sj = score[j];
-      rank += (sj < si || (sj == si && j < i)) ? 1 : 0;
+      rank += (sj < si || (sj == si && j < tid)) ? 1 : 0;
     }
-    order[rank] = i;
+    order[rank] = tid;
   }
 }
 
@@ -311,17 +377,19 @@ extern "C" int bm_pairwise_sqdist(const float* const* rows, int n, int64_t d, do
   RowTable tab{};
   for (int i = 0; i < n; ++i) tab.p[i] = rows[i];
   const int blocks = pair_grid_blocks(g, d);
-  const int nrows_lds = g.ng * kTileR;
-  size_t lds_bytes = (size_t)nrows_lds * g.stride * sizeof(float);
+  size_t lds_bytes = (size_t)g.nb * kDmaPitch;
   const size_t red_bytes = (size_t)g.strips * g.tiles * 16 * sizeof(float);
   if (red_bytes > lds_bytes) lds_bytes = red_bytes;
+  lds_bytes += BM_MAX_ROWS * sizeof(float*);  // row pointer table in front
   const bool aligned =
       common_vec_width(reinterpret_cast<const void* const*>(rows), n, nullptr) == 4;
   double* partial = static_cast<double*>(ws);
-  const bool deep = tuning().pair_unroll >= 2;  // experiment knob BM_PAIR_UNROLL
-  auto kern = aligned ? (deep ? pairwise_partial_kernel<true, 2> : pairwise_partial_kernel<true, 1>)
-                      : (deep ? pairwise_partial_kernel<false, 2> : pairwise_partial_kernel<false, 1>);
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(g.threads), lds_bytes, s, tab, g, d, partial);
+  if (aligned)
+    hipLaunchKernelGGL(pairwise_partial_kernel<true>, dim3(blocks), dim3(g.threads), lds_bytes, s,
+                       tab, g, d, partial);
+  else
+    hipLaunchKernelGGL(pairwise_partial_kernel<false>, dim3(blocks), dim3(g.threads), lds_bytes, s,
+                       tab, g, d, partial);
   BM_LAUNCH_CHECK();
   const int per_block = g.tiles * 16;
   hipLaunchKernelGGL(pairwise_reduce_kernel, dim3((per_block + 63) / 64), dim3(64 * kRedWaves), 0, s,
@@ -336,7 +404,7 @@ extern "C" int bm_krum_rank(const double* sq_nxn, int n, int f, int m, int mode,
   if (sq_nxn == nullptr || order_out == nullptr || n < 1 || n > BM_MAX_ROWS || f < 0 ||
       (mode != BM_RANK_KRUM && mode != BM_RANK_BULYAN))
     return BM_EINVAL;
-  hipLaunchKernelGGL(krum_rank_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(krum_rank_kernel, dim3(1), dim3(kRankThreads), 0, static_cast<hipStream_t>(stream),
                      sq_nxn, n, f, m, mode, order_out, scores_out);
   BM_LAUNCH_CHECK();
   return 0;
