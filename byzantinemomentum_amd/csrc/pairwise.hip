@@ -31,15 +31,17 @@ constexpr int kDmaBlock = 1024;    // bytes moved by one wave-wide global_load_l
 constexpr int kDmaPitch = 1024 + 16;  // LDS pitch of a DMA block: one 16-B slot of padding
 
 struct PairGeom {
-  int n;        // rows
-  int ng;       // row groups = ceil(n/4)
-  int tiles;    // ng*(ng+1)/2 pair tiles (I <= J)
-  int ut;       // 16-lane units per strip = ceil(tiles/16)
-  int strips;   // S in {1, 2, 4}: 64-coordinate strips per LDS tile
-  int threads;  // 16*ut*S rounded up to 64
-  int width;    // coordinates per LDS tile = 64*S
-  int rb;       // rows per DMA block = 4/S
-  int nb;       // DMA blocks per tile = ng*S
+  int n;          // rows
+  int ng;         // row groups = ceil(n/4)
+  int tiles;      // ng*(ng+1)/2 pair tiles (I <= J)
+  int ut;         // 16-lane units per strip = ceil(tiles/16)
+  int strips;     // S: coordinate strips per LDS tile, one strip per 16-lane unit
+  int slots;      // 16-byte slots (4 coordinates) a lane walks per tile: 8 or 16
+  int threads;    // 16*ut*S rounded up to 64
+  int width;      // coordinates per LDS tile = 4*slots*S
+  int row_bytes;  // 16*slots*S in {256, 512, 1024}
+  int rb;         // rows per 1 KiB DMA block = 1024/row_bytes in {4, 2, 1}
+  int nb;         // DMA blocks per tile = ng * (4/rb)
 };
 
 static PairGeom pair_geometry(int n) {
@@ -48,30 +50,43 @@ static PairGeom pair_geometry(int n) {
   g.ng = (n + kTileR - 1) / kTileR;
   g.tiles = g.ng * (g.ng + 1) / 2;
   g.ut = (g.tiles + 15) / 16;
-  // strips: best lane utilisation among S = 4, 2, 1 (ties to the wider tile = fewer barriers per
-  // byte), at most 512 lanes and 48 KB of LDS tile per workgroup
-  int best_s = 1;
-  double best_u = -1.0;
+  // Candidates (strips, slots) with row_bytes = 16*slots*strips in {256, 512, 1024}.  Pick the best
+  // lane utilisation; among equals the largest tile whose two buffers stay within 32 KB (so that
+  // four or five workgroups fit in the 160 KB of LDS of a CU).
+  static const int cand[][2] = {{2, 8}, {4, 8}, {8, 8}, {1, 16}, {2, 16}, {4, 16}};
   const int forced = tuning().pair_strips;
-  for (int s = 4; s >= 1; s >>= 1) {
+  double best_u = -1.0;
+  int best = -1, best_bytes = 0;
+  for (int c = 0; c < 6; ++c) {
+    const int s = cand[c][0], sl = cand[c][1];
     const int lanes = 16 * g.ut * s;
     const int thr = ((lanes + 63) / 64) * 64;
-    if (thr > kPairMaxThreads || g.ng * s * kDmaPitch > 48 * 1024) continue;
-    const double u = (double)lanes / thr;
-    if (forced == s) {
-      best_s = s;
-      break;
+    const int rowb = 16 * sl * s;
+    const int tile_bytes = g.ng * (4 * rowb / kDmaBlock) * kDmaPitch;
+    if (thr > kPairMaxThreads) continue;
+    if (forced > 0) {
+      if (forced == s * 100 + sl) {
+        best = c;
+        break;
+      }
+      continue;
     }
-    if (u > best_u + 1e-9) {
+    if (2 * tile_bytes > 32 * 1024) continue;
+    const double u = (double)lanes / thr;
+    if (u > best_u + 1e-9 || (u > best_u - 1e-9 && tile_bytes > best_bytes)) {
       best_u = u;
-      best_s = s;
+      best = c;
+      best_bytes = tile_bytes;
     }
   }
-  g.strips = best_s;
-  g.threads = ((16 * g.ut * best_s + 63) / 64) * 64;
-  g.width = 64 * best_s;
-  g.rb = 4 / best_s;
-  g.nb = g.ng * best_s;
+  if (best < 0) best = 0;
+  g.strips = cand[best][0];
+  g.slots = cand[best][1];
+  g.threads = ((16 * g.ut * g.strips + 63) / 64) * 64;
+  g.width = 4 * g.slots * g.strips;
+  g.row_bytes = 16 * g.slots * g.strips;
+  g.rb = kDmaBlock / g.row_bytes;
+  g.nb = g.ng * (kTileR / g.rb);
   return g;
 }
 
@@ -102,33 +117,36 @@ __device__ __forceinline__ void lane_unit(int lane, int& unit, int& pos) {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Byte offset, inside the LDS tile, of coordinate 0 of logical row 4*I + a.
-// DMA block = I + ng*(a / rb); a block holds rb rows of 256*S bytes.  Its bank slot class is
-// (I + ng*(a/rb)) mod 16: for a fixed `a`, rows of different groups I never share a 16-byte slot,
-// so a ds_read_b128 whose 16 lanes read 16 different groups is conflict free.
+// Byte offset, inside an LDS tile, of coordinate 0 of logical row 4*I + a.
+// DMA block = I + ng*(a / rb); a block holds rb rows of row_bytes.  Its bank-slot class is
+// (I + ng*(a/rb)) mod 16 (row_bytes and the 128-byte strip offset are multiples of 8 slots, and
+// a ds_read_b128 service group always sits in one strip): for a fixed `a`, rows of different
+// groups I never share a 16-byte bank slot, so a read whose 16 lanes touch 16 different groups is
+// conflict free (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.2 % measured).
 __device__ __forceinline__ int row_offset_bytes(const PairGeom& g, int I, int a) {
   const int blk = I + g.ng * (a / g.rb);
-  return blk * kDmaPitch + (a % g.rb) * (256 * g.strips);
+  return blk * kDmaPitch + (a % g.rb) * g.row_bytes;
 }
 
 // ALIGNED: every row pointer is 16-byte aligned -> full tiles are brought in by the LDS-DMA
-// engine (global_load_lds_dwordx4: no staging VGPRs, no ds_write).  Ragged last tiles and
-// unaligned inputs use a plain load + ds_write loop.
-template <bool ALIGNED>
+// engine (global_load_lds_dwordx4: no staging VGPRs, no ds_write) into the OTHER of two tile
+// buffers while the workgroup computes on the current one.  Ragged last tiles and unaligned inputs
+// use a plain load + ds_write loop (same layout, not overlapped).
+template <bool ALIGNED, int ABLATE = 0>
 __global__ __launch_bounds__(kPairMaxThreads) void pairwise_partial_kernel(
     RowTable rows, PairGeom g, int64_t d, double* __restrict__ partial) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const float** row_ptr = reinterpret_cast<const float**>(smem);  // 512 B pointer table
-  char* tile = smem + BM_MAX_ROWS * sizeof(float*);
+  char* tiles = smem + BM_MAX_ROWS * sizeof(float*);
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
   const int nwaves = blockDim.x >> 6;
   const int tile_bytes = g.nb * kDmaPitch;
 
-  // one-time: pointer table, zeroed tile (rows >= n and block padding are never written again)
+  // one-time: pointer table, zeroed tiles (rows >= n and block padding are never written again)
   for (int r = tid; r < BM_MAX_ROWS; r += blockDim.x) row_ptr[r] = nullptr;
-  for (int o = tid * 16; o < tile_bytes; o += blockDim.x * 16)
-    *reinterpret_cast<f32x4*>(tile + o) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int o = tid * 16; o < 2 * tile_bytes; o += blockDim.x * 16)
+    *reinterpret_cast<f32x4*>(tiles + o) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   __syncthreads();
   if (tid == 0)
     for (int r = 0; r < g.n; ++r) row_ptr[r] = rows.p[r];  // uniform index: scalar loads
@@ -151,12 +169,11 @@ __global__ __launch_bounds__(kPairMaxThreads) void pairwise_partial_kernel(
     }
     tj = ti + t;
   }
-  const char* li[kTileR];
-  const char* lj[kTileR];
+  int oi[kTileR], oj[kTileR];  // byte offsets of this lane's 4+4 rows inside a tile buffer
 #pragma unroll
   for (int a = 0; a < kTileR; ++a) {
-    li[a] = tile + row_offset_bytes(g, ti, a) + strip * 256;
-    lj[a] = tile + row_offset_bytes(g, tj, a) + strip * 256;
+    oi[a] = row_offset_bytes(g, ti, a) + strip * g.slots * 16;
+    oj[a] = row_offset_bytes(g, tj, a) + strip * g.slots * 16;
   }
 
   f32x2 acc[kTileR][kTileR];
@@ -166,17 +183,14 @@ __global__ __launch_bounds__(kPairMaxThreads) void pairwise_partial_kernel(
     for (int b = 0; b < kTileR; ++b) acc[a][b] = f32x2{0.0f, 0.0f};
 
   const int width = g.width;
-  // DMA lane geometry: a 1 KiB block = rb rows x (16*S lanes x 16 B)
-  const int lanes_per_row = 16 * g.strips;
-  const int dma_w = lane / lanes_per_row;                 // row within the block
+  // DMA lane geometry: a 1 KiB block = rb rows x (row_bytes/16 lanes x 16 B)
+  const int lanes_per_row = g.row_bytes / 16;
+  const int dma_w = lane / lanes_per_row;                  // row within the block
   const int dma_col = (lane - dma_w * lanes_per_row) * 4;  // first coordinate of this lane
 
-  // chunk c of this workgroup = blockIdx.x + c*gridDim.x (neighbouring workgroups stream
-  // neighbouring addresses); the per-pair accumulation order is the same for every pair.
-  for (int64_t chunk = blockIdx.x;; chunk += gridDim.x) {
-    const int64_t base = chunk * width;
-    if (base >= d) break;
-    __syncthreads();  // previous tile fully consumed
+  // Bring chunk `base` into tile buffer `buf`.  Returns without waiting when the DMA path is used.
+  auto stage = [&](int64_t base, char* buf) {
+    if (ABLATE == 2) return;  // experiment: no staging at all
     if (ALIGNED && base + width <= d) {
       for (int blk = wave; blk < g.nb; blk += nwaves) {
         const int I = blk % g.ng;
@@ -186,10 +200,9 @@ __global__ __launch_bounds__(kPairMaxThreads) void pairwise_partial_kernel(
           const float* src = row_ptr[r] + base + dma_col;
           __builtin_amdgcn_global_load_lds(
               (const __attribute__((address_space(1))) void*)src,
-              (__attribute__((address_space(3))) void*)(tile + blk * kDmaPitch), 16, 0, 0);
+              (__attribute__((address_space(3))) void*)(buf + blk * kDmaPitch), 16, 0, 0);
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
       // ragged tail / unaligned rows: plain loads with zero fill, same LDS layout
       const int vpr = width / 4;
@@ -207,39 +220,78 @@ __global__ __launch_bounds__(kPairMaxThreads) void pairwise_partial_kernel(
           if (left > 2) val.z = src[2];
           if (left > 3) val.w = src[3];
         }
-        *reinterpret_cast<f32x4*>(tile + row_offset_bytes(g, r >> 2, r & 3) + col * 4) = val;
+        *reinterpret_cast<f32x4*>(buf + row_offset_bytes(g, r >> 2, r & 3) + col * 4) = val;
       }
     }
-    __syncthreads();
-    // ---- 16 slots of 4 coordinates, canonical order for every pair ----
-    if (active) {
-#pragma unroll 1
-      for (int k = 0; k < 16; ++k) {
-        f32x2 xil[kTileR], xih[kTileR], xjl[kTileR], xjh[kTileR];
+  };
+
+  struct Slot {
+    f32x2 il[kTileR], ih[kTileR], jl[kTileR], jh[kTileR];
+  };
+
+  // chunk c of this workgroup = blockIdx.x + c*gridDim.x (neighbouring workgroups stream
+  // neighbouring addresses); the per-pair accumulation order is the same for every pair.
+  int64_t chunk = blockIdx.x;
+  if (chunk * width < d) stage(chunk * width, tiles);
+  for (int it = 0;; ++it) {
+    const int64_t base = chunk * width;
+    if (base >= d) break;
+    char* cur = tiles + (it & 1) * tile_bytes;
+    char* nxt = tiles + ((it + 1) & 1) * tile_bytes;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of `cur` have landed
+    __syncthreads();  // ... everyone's have, and everyone is done reading `nxt`
+    chunk += gridDim.x;
+    if (chunk * width < d) stage(chunk * width, nxt);  // overlaps the compute below
+
+    // ---- `slots` steps of 4 coordinates, canonical order for every pair ----
+    if (active && ABLATE != 1) {
+      // Software pipeline: the 8 ds_read_b128 of the next slot are issued before the 64 packed ops
+      // of the current one (two register sets in ping-pong, no copies).  Within a slot all 16 "lo"
+      // updates precede all 16 "hi" updates, so dependent v_pk_fma are 30+ instructions apart.
+      auto load_slot = [&](Slot& v, int slot) {
 #pragma unroll
         for (int a = 0; a < kTileR; ++a) {
-          const f32x4 vi = *reinterpret_cast<const f32x4*>(li[a] + k * 16);
-          const f32x4 vj = *reinterpret_cast<const f32x4*>(lj[a] + k * 16);
-          xil[a] = f32x2{vi.x, vi.y};
-          xih[a] = f32x2{vi.z, vi.w};
-          xjl[a] = f32x2{vj.x, vj.y};
-          xjh[a] = f32x2{vj.z, vj.w};
+          const f32x4 vi = *reinterpret_cast<const f32x4*>(cur + oi[a] + slot * 16);
+          const f32x4 vj = *reinterpret_cast<const f32x4*>(cur + oj[a] + slot * 16);
+          v.il[a] = f32x2{vi.x, vi.y};
+          v.ih[a] = f32x2{vi.z, vi.w};
+          v.jl[a] = f32x2{vj.x, vj.y};
+          v.jh[a] = f32x2{vj.z, vj.w};
         }
+      };
+      auto accumulate = [&](const Slot& v) {
 #pragma unroll
         for (int a = 0; a < kTileR; ++a)
 #pragma unroll
           for (int b = 0; b < kTileR; ++b) {
-            const f32x2 lo = xil[a] - xjl[b];  // v_pk_add_f32 with neg modifier
-            const f32x2 hi = xih[a] - xjh[b];
+            const f32x2 lo = v.il[a] - v.jl[b];  // v_pk_add_f32 with neg modifier
             acc[a][b] = __builtin_elementwise_fma(lo, lo, acc[a][b]);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < kTileR; ++a)
+#pragma unroll
+          for (int b = 0; b < kTileR; ++b) {
+            const f32x2 hi = v.ih[a] - v.jh[b];
             acc[a][b] = __builtin_elementwise_fma(hi, hi, acc[a][b]);
           }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      Slot sa, sb;
+      load_slot(sa, 0);
+      const int last = g.slots - 1;
+#pragma unroll 1
+      for (int k = 0; k < g.slots; k += 2) {
+        load_slot(sb, k + 1);
+        accumulate(sa);
+        load_slot(sa, (k + 2) & last);  // the wrap-around read of slot 0 is harmless
+        accumulate(sb);
       }
     }
   }
   // ---- combine strips in a fixed order, emit this workgroup's partial (fp64) ----
   __syncthreads();
-  float* red = reinterpret_cast<float*>(tile);  // reuse: [strip][tile][16]
+  float* red = reinterpret_cast<float*>(tiles);  // reuse: [strip][tile][16]
   if (active) {
 #pragma unroll
     for (int a = 0; a < kTileR; ++a)
@@ -367,29 +419,42 @@ __global__ __launch_bounds__(kRankThreads) void krum_rank_kernel(const double* _
 
 }  // namespace bm
 
+namespace bm {
+int gram_sqdist(const float* const* rows, int n, int64_t d, double* sq_nxn, void* ws, hipStream_t s);
+int64_t gram_workspace_bytes(int n);
+}  // namespace bm
+
 extern "C" int bm_pairwise_sqdist(const float* const* rows, int n, int64_t d, double* sq_nxn,
                                   void* ws, void* stream) {
   using namespace bm;
   if (rows == nullptr || sq_nxn == nullptr || ws == nullptr || n < 1 || n > BM_MAX_ROWS || d < 0)
     return BM_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // Default: Gram contraction on the fp32 matrix cores (gram.hip).  BM_PAIR_MODE=1 selects the
+  // direct-difference VALU kernel below (kept as the measured alternative).
+  if (tuning().pair_mode == 0) return gram_sqdist(rows, n, d, sq_nxn, ws, s);
   const PairGeom g = pair_geometry(n);
   RowTable tab{};
   for (int i = 0; i < n; ++i) tab.p[i] = rows[i];
   const int blocks = pair_grid_blocks(g, d);
-  size_t lds_bytes = (size_t)g.nb * kDmaPitch;
+  size_t lds_bytes = (size_t)2 * g.nb * kDmaPitch;  // two tile buffers
   const size_t red_bytes = (size_t)g.strips * g.tiles * 16 * sizeof(float);
   if (red_bytes > lds_bytes) lds_bytes = red_bytes;
   lds_bytes += BM_MAX_ROWS * sizeof(float*);  // row pointer table in front
   const bool aligned =
       common_vec_width(reinterpret_cast<const void* const*>(rows), n, nullptr) == 4;
   double* partial = static_cast<double*>(ws);
-  if (aligned)
-    hipLaunchKernelGGL(pairwise_partial_kernel<true>, dim3(blocks), dim3(g.threads), lds_bytes, s,
-                       tab, g, d, partial);
-  else
-    hipLaunchKernelGGL(pairwise_partial_kernel<false>, dim3(blocks), dim3(g.threads), lds_bytes, s,
-                       tab, g, d, partial);
+  const int ablate = tuning().pair_ablate;  // experiments only (BM_PAIR_ABLATE)
+  auto kern = !aligned ? pairwise_partial_kernel<false>
+                       : (ablate == 1 ? pairwise_partial_kernel<true, 1>
+                                      : (ablate == 2 ? pairwise_partial_kernel<true, 2>
+                                                     : pairwise_partial_kernel<true, 0>));
+  if (lds_bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return hip_code(e);
+  }
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(g.threads), lds_bytes, s, tab, g, d, partial);
   BM_LAUNCH_CHECK();
   const int per_block = g.tiles * 16;
   hipLaunchKernelGGL(pairwise_reduce_kernel, dim3((per_block + 63) / 64), dim3(64 * kRedWaves), 0, s,
@@ -417,6 +482,8 @@ int64_t pairwise_workspace_bytes(int n, int64_t d) {
   int blocks = tuning().pair_blocks > 0 ? tuning().pair_blocks : 256 * 4;
   if (blocks < 4096) blocks = 4096;
   (void)d;
-  return (int64_t)blocks * g.tiles * 16 * (int64_t)sizeof(double);
+  const int64_t direct = (int64_t)blocks * g.tiles * 16 * (int64_t)sizeof(double);
+  const int64_t gram = gram_workspace_bytes(n);
+  return direct > gram ? direct : gram;
 }
 }  // namespace bm
