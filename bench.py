@@ -1,6 +1,6 @@
 """Benchmark of the aggregation hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload colwise|krum|bulyan]
+    python bench.py --gpus N --steps K --warmup W [--workload colwise|krum|bulyan|step [--gar RULE]]
 
 Default workload = BASELINE.json configs[1]: coordinate-wise median + trimmed mean (f=5) over a
 synthetic stack of n=25 worker gradients x d=11 173 962 coordinates (ResNet-18-sized), fp32, inputs
@@ -11,7 +11,9 @@ N > 1 (launched by torch.distributed.run, one rank per GPU): the path shards alo
 data-path collective for the coordinate-wise rules — every rank aggregates its own d-slice of a
 N-times-larger model ("weak" scaling, per-GPU work fixed); `value` counts one aggregation per
 rank-shard pass.  `--workload bulyan` is the dim-sharded rule WITH its one real exchange (a single
-all-reduce of the 25x25 fp64 squared-distance partials over RCCL).
+all-reduce of the 25x25 fp64 squared-distance partials over RCCL).  `--workload step` is BASELINE.json
+configs[4] on one GPU: the attack.py:800-878 mirror (worker momentum, empire attack, rule, study
+statistics) at d = 36 546 980 (WRN-28-10 / CIFAR-100), n=25, f=5.
 
 The JSON line also carries `roofline` (algorithmic bytes / HIP-event kernel time vs 8 TB/s HBM)
 and `cpu_baseline` (the oracle's reference-faithful PyTorch-CPU port on this box's host cores,
@@ -39,15 +41,23 @@ def parse():
   p.add_argument("--gpus", type=int, default=1)
   p.add_argument("--steps", type=int, default=50)
   p.add_argument("--warmup", type=int, default=5)
-  p.add_argument("--workload", default="colwise", choices=["colwise", "krum", "bulyan"])
+  p.add_argument("--workload", default="colwise", choices=["colwise", "krum", "bulyan", "step"])
+  p.add_argument("--gar", default="krum", help="aggregation rule of --workload step")
   p.add_argument("--d", type=int, default=D_RESNET18)
   p.add_argument("--no-cpu-baseline", action="store_true")
+  p.add_argument("--aliased-byz", action="store_true",
+                 help="make the f Byzantine rows ONE aliased tensor as the reference's attacks do "
+                      "(attacks/identical.py:86); they are then served from cache and the HBM traffic "
+                      "drops below the algorithmic bytes. Default: every row is a distinct buffer, so "
+                      "that algorithmic bytes == bytes that must come from HBM.")
   return p.parse_args()
 
 
-def make_stacks(n, f, d, device, count, seed):
+def make_stacks(n, f, d, device, count, seed, aliased):
   """`count` independent stacks (rotated between steps so that the 256 MB Infinity Cache never
-  holds the next input). Honest rows N(mu, sigma_i), the f Byzantine rows alias ONE tensor."""
+  holds the next input). Honest rows N(mu, sigma_i); the f Byzantine rows are -0.1*mean(honest)
+  ("empire", factor 1.1), either ONE aliased tensor (aliased=True, the reference's layout) or f
+  distinct buffers with a 1e-3 relative jitter (default: every row costs its HBM bytes)."""
   gen = torch.Generator(device=device).manual_seed(seed)
   stacks = []
   for _ in range(count):
@@ -56,7 +66,11 @@ def make_stacks(n, f, d, device, count, seed):
     sig = torch.linspace(0.5, 1.5, h).tolist()
     honest = [mu + s * torch.randn(d, device=device, generator=gen) for s in sig]
     byz = torch.stack(honest).mean(dim=0).mul_(-0.1)
-    stacks.append(honest + [byz] * f)
+    if aliased:
+      stacks.append(honest + [byz] * f)
+    else:
+      stacks.append(honest + [byz + 1e-3 * byz.abs().mean() * torch.randn(d, device=device, generator=gen)
+                              for _ in range(f)])
   return stacks
 
 
@@ -101,9 +115,9 @@ def _pick_threads(fn):
 
 def cpu_baseline_colwise(stack, f):
   from oracle import gar_oracle as O
-  rows = [g.cpu() for g in stack[:len(stack) - f]] + [stack[-1].cpu()] * f
+  rows = [g.cpu() for g in stack]
   d = rows[0].shape[0]
-  small = [r[:d // 16] for r in rows[:len(rows) - f]] + [rows[-1][:d // 16]] * f
+  small = [r[:d // 16] for r in rows]
   threads = _pick_threads(lambda: (O.median(small), O.trmean(small, f)))
   t0 = time.perf_counter()
   reps = 2
@@ -121,9 +135,8 @@ def cpu_baseline_colwise(stack, f):
 def cpu_baseline_distance(stack, f, rule, d_sample):
   from oracle import gar_oracle as O
   n = len(stack)
-  byz = stack[-1][:d_sample].cpu()
-  rows = [g[:d_sample].cpu() for g in stack[:n - f]] + [byz] * f
-  tiny = [r[:d_sample // 16] for r in rows[:n - f]] + [byz[:d_sample // 16]] * f
+  rows = [g[:d_sample].cpu() for g in stack]
+  tiny = [r[:d_sample // 16] for r in rows]
   _pick_threads(lambda: O.krum(tiny, f))
   t0 = time.perf_counter()
   (O.krum if rule == "krum" else O.bulyan)(rows, f)
@@ -154,7 +167,7 @@ def main():
   timer = KernelTimer()
   if args.workload == "colwise":
     n, f = 25, 5
-    stacks = make_stacks(n, f, d, device, 2, 1234 + rank)
+    stacks = make_stacks(n, f, d, device, 2, 1234 + rank, args.aliased_byz)
     aggs_per_step = 2
     algo_bytes = {"median": 4 * d * (n + 1), "trmean": 4 * d * (n + 1)}
 
@@ -167,6 +180,32 @@ def main():
         bm.median(st)
         bm.trmean(st, f)
     workload_name = f"C2 colwise: median + trmean(f={f}), n={n}, d={d} per GPU"
+  elif args.workload == "step":
+    from byzantinemomentum_amd.step import AggregationStep
+    n, f = 25, 5
+    h = n - f
+    if args.d == D_RESNET18:
+      d = 36546980  # WRN-28-10 on CIFAR-100
+    runner = AggregationStep(n, f, f, gar=args.gar, momentum=0.99, dampening=0.99, attack_factor=1.1, nb_past=25)
+    gen = torch.Generator(device=device).manual_seed(77 + rank)
+    mu_vec = 0.1 * torch.randn(d, device=device, generator=gen)
+    sets = [[mu_vec + s * torch.randn(d, device=device, generator=gen) for s in torch.linspace(0.5, 1.5, h).tolist()]
+            for _ in range(2)]
+    aggs_per_step = 1
+    m = n - f - 2
+    gar_units = {"krum": n + m + 1, "bulyan": n + m + 1, "median": n + 1, "trmean": n + 1}.get(args.gar, n + 1)
+    # 4-byte units of d per step: momentum 3h, attack+honest stats h+2, rule,
+    # sampled stats h+1, attack stats 2, defense stats 1, dots 4+25
+    algo_bytes = {"step": 4 * d * (3 * h + (h + 2) + gar_units + (h + 1) + 2 + 1 + 29)}
+
+    def step(i, timed):
+      if timed:
+        timer.run("step", lambda: (runner.run(sets[i & 1]), runner.floats()))
+      else:
+        runner.run(sets[i & 1])
+        runner.floats()
+    workload_name = (f"C5 full step mirror (attack.py:800-878): worker momentum 0.99, empire 1.1, rule {args.gar}, "
+                     f"study statistics with 25 past gradients; n={n}, f={f}, d={d}")
   else:
     from byzantinemomentum_amd.sharded import ShardedAggregator
     agg = ShardedAggregator()
@@ -175,18 +214,17 @@ def main():
     else:
       n, f = 25, 5
     m = n - f - 2
-    stacks = make_stacks(n, f, d, device, 2, 4321 + rank)
+    stacks = make_stacks(n, f, d, device, 2, 4321 + rank, args.aliased_byz)
     aggs_per_step = 1
     algo_bytes = {args.workload: 4 * d * n + 4 * d * (m + 1)}
     rule = agg.krum if args.workload == "krum" else agg.bulyan
 
     def step(i, timed):
       st = stacks[i & 1]
-      # a fresh list object per step defeats the ranking cache: every step recomputes the distances
       if timed:
-        timer.run(args.workload, lambda: rule(list(st), f))
+        timer.run(args.workload, lambda: rule(st, f))
       else:
-        rule(list(st), f)
+        rule(st, f)
     workload_name = (f"{'C3 multi-krum' if args.workload == 'krum' else 'C4 bulyan'}: n={n}, f={f}, m={m}, "
                      f"d={d} per GPU, dim-sharded, one all-reduce of the {n}x{n} fp64 partial matrix")
 
@@ -232,6 +270,7 @@ def main():
       "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
       "dtype": "f32", "data": "synthetic",
       "config": {"workload": workload_name, "n_workers": n, "f": f, "d_per_gpu": d,
+                 "byzantine_rows": "aliased" if args.aliased_byz else "distinct buffers",
                  "parallelism": f"dim-shard x{world}" if world > 1 else "single GPU"},
       "roofline": {"bound": "hbm", "kernel": dominant, "achieved": dk["gbps"], "peak": HBM_PEAK_GBPS,
                    "unit": "GB/s", "frac": dk["frac_of_8TBps"], "traffic": traffic},
@@ -240,6 +279,8 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
       if args.workload == "colwise":
         line["cpu_baseline"] = cpu_baseline_colwise(stacks[0], f)
+      elif args.workload == "step":
+        pass  # the CPU baseline of the full step is the reference's attack.py itself
       else:
         line["cpu_baseline"] = cpu_baseline_distance(stacks[0], f, args.workload, min(d, 1 << 20))
     print(json.dumps(line))

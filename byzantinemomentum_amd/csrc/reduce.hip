@@ -62,6 +62,8 @@ static int launch_selected_mean(const RowTable& tab, const int32_t* idx, int m, 
 template <int KMAX, int VEC>
 __global__ __launch_bounds__(kRedBlock) void stack_stats_kernel(RowTable rows, int k, int64_t nvec,
                                                                 float* __restrict__ avg_out,
+                                                                float* __restrict__ scaled_out,
+                                                                float scale,
                                                                 double* __restrict__ partial) {
   __shared__ double red[kRedBlock / 64];
   const float fk = (float)k;
@@ -96,6 +98,15 @@ __global__ __launch_bounds__(kRedBlock) void stack_stats_kernel(RowTable rows, i
       dev2 += q;
     }
     if (avg_out != nullptr) store_stream<VEC>(avg_out + v * VEC, avg);
+    if (scaled_out != nullptr) {
+      float sc[VEC];
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) {
+        const float att = (-avg[c]) * scale;  // grad_att = grad_avg.neg(); grad_att.mul_(factor)
+        sc[c] = avg[c] + att;                 // byz_grad = grad_avg.add_(grad_att)
+      }
+      store_stream<VEC>(scaled_out + v * VEC, sc);
+    }
   }
   // torch's abs().max() propagates NaN; fmaxf does not
   if (seen_nan) amax = __builtin_nanf("");
@@ -153,23 +164,24 @@ __global__ void stats_finish_kernel(const double* __restrict__ partial, int npar
 }
 
 template <int KMAX, int VEC>
-static int launch_stack_stats(const RowTable& tab, int k, int64_t nvec, float* avg, double* partial,
-                              int grid, hipStream_t s) {
+static int launch_stack_stats(const RowTable& tab, int k, int64_t nvec, float* avg, float* scaled,
+                              float scale, double* partial, int grid, hipStream_t s) {
   hipLaunchKernelGGL((stack_stats_kernel<KMAX, VEC>), dim3(grid), dim3(kRedBlock), 0, s, tab, k, nvec,
-                     avg, partial);
+                     avg, scaled, scale, partial);
   BM_LAUNCH_CHECK();
   return 0;
 }
 
 template <int VEC>
-static int dispatch_stack_stats(const RowTable& tab, int k, int64_t nvec, float* avg, double* partial,
-                                int grid, hipStream_t s) {
-  if (k <= 8) return launch_stack_stats<8, VEC>(tab, k, nvec, avg, partial, grid, s);
-  if (k <= 16) return launch_stack_stats<16, VEC>(tab, k, nvec, avg, partial, grid, s);
-  if (k <= 24) return launch_stack_stats<24, VEC>(tab, k, nvec, avg, partial, grid, s);
-  if (k <= 32) return launch_stack_stats<32, (VEC > 2 ? 2 : VEC)>(tab, k, nvec * (VEC > 2 ? VEC / 2 : 1),
-                                                                   avg, partial, grid, s);
-  return launch_stack_stats<64, 1>(tab, k, nvec * VEC, avg, partial, grid, s);
+static int dispatch_stack_stats(const RowTable& tab, int k, int64_t nvec, float* avg, float* scaled,
+                                float scale, double* partial, int grid, hipStream_t s) {
+  if (k <= 8) return launch_stack_stats<8, VEC>(tab, k, nvec, avg, scaled, scale, partial, grid, s);
+  if (k <= 16) return launch_stack_stats<16, VEC>(tab, k, nvec, avg, scaled, scale, partial, grid, s);
+  if (k <= 24) return launch_stack_stats<24, VEC>(tab, k, nvec, avg, scaled, scale, partial, grid, s);
+  if (k <= 32)
+    return launch_stack_stats<32, (VEC > 2 ? 2 : VEC)>(tab, k, nvec * (VEC > 2 ? VEC / 2 : 1), avg, scaled,
+                                                        scale, partial, grid, s);
+  return launch_stack_stats<64, 1>(tab, k, nvec * VEC, avg, scaled, scale, partial, grid, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -337,7 +349,7 @@ extern "C" int bm_selected_mean(const float* const* rows, int n, const int32_t* 
 }
 
 extern "C" int bm_stack_stats(const float* const* rows, int k, int64_t d, float* avg_out,
-                              double* out3, void* ws, void* stream) {
+                              float* scaled_out, float scale, double* out3, void* ws, void* stream) {
   using namespace bm;
   if (rows == nullptr || out3 == nullptr || ws == nullptr || k < 1 || k > BM_MAX_ROWS || d < 1)
     return BM_EINVAL;
@@ -345,7 +357,8 @@ extern "C" int bm_stack_stats(const float* const* rows, int k, int64_t d, float*
   RowTable tab{};
   for (int i = 0; i < k; ++i) tab.p[i] = rows[i];
   double* partial = static_cast<double*>(ws);
-  const int vec = common_vec_width(reinterpret_cast<const void* const*>(rows), k, avg_out);
+  int vec = common_vec_width(reinterpret_cast<const void* const*>(rows), k, avg_out);
+  if ((reinterpret_cast<uintptr_t>(scaled_out) & 15u) != 0) vec = (reinterpret_cast<uintptr_t>(scaled_out) & 7u) ? 1 : (vec > 2 ? 2 : vec);
   int64_t body = 0;
   int nparts = 0;
   int rc = 0;
@@ -353,8 +366,8 @@ extern "C" int bm_stack_stats(const float* const* rows, int k, int64_t d, float*
     const int64_t nvec = d / vec;
     if (nvec > 0) {
       const int grid = stream_grid(nvec, kRedBlock, kMaxPartialBlocks - 1);
-      rc = (vec == 4) ? dispatch_stack_stats<4>(tab, k, nvec, avg_out, partial, grid, s)
-                      : dispatch_stack_stats<2>(tab, k, nvec, avg_out, partial, grid, s);
+      rc = (vec == 4) ? dispatch_stack_stats<4>(tab, k, nvec, avg_out, scaled_out, scale, partial, grid, s)
+                      : dispatch_stack_stats<2>(tab, k, nvec, avg_out, scaled_out, scale, partial, grid, s);
       if (rc != 0) return rc;
       nparts = grid;
       body = nvec * vec;
@@ -366,6 +379,7 @@ extern "C" int bm_stack_stats(const float* const* rows, int k, int64_t d, float*
     const int64_t rest = d - body;
     const int grid = (body == 0) ? stream_grid(rest, kRedBlock, kMaxPartialBlocks) : 1;
     rc = dispatch_stack_stats<1>(tail, k, rest, avg_out ? avg_out + body : nullptr,
+                                 scaled_out ? scaled_out + body : nullptr, scale,
                                  partial + (int64_t)nparts * 3, grid, s);
     if (rc != 0) return rc;
     nparts += grid;

@@ -19,16 +19,25 @@ __all__ = ["compute_avg_dev_max", "stack_stats_async", "study_dots", "multi_axpb
 _ptr = gars._ptr
 
 
-def stack_stats_async(samples):
-  """avg vector + device tensor [sum avg^2, sum_i ||s_i-avg||^2, max|avg|] (fp64), no sync."""
+def stack_stats_async(samples, scale=None):
+  """avg vector + device tensor [sum avg^2, sum_i ||s_i-avg||^2, max|avg|] (fp64), no sync.
+
+  With `scale`, also returns avg + scale*(-avg) computed in the same pass (third element of the
+  tuple): the "empire" Byzantine vector with factor = scale (attacks/identical.py:63-86,129-134).
+  """
   k, d, device = gars._validate(samples)
   lib = _lib.load()
   avg = torch.empty(d, dtype=torch.float32, device=device)
+  scaled = torch.empty(d, dtype=torch.float32, device=device) if scale is not None else None
   out3 = torch.empty(3, dtype=torch.float64, device=device)
   ws = gars._workspace(device, _lib.WS_STATS, k, d, "ws_stats")
   with torch.cuda.device(device):
-    _lib.check(lib.bm_stack_stats(_lib.pointer_table(samples), k, d, _ptr(avg), _ptr(out3), _ptr(ws),
+    _lib.check(lib.bm_stack_stats(_lib.pointer_table(samples), k, d, _ptr(avg),
+                                  _ptr(scaled) if scaled is not None else None,
+                                  ctypes.c_float(scale if scale is not None else 0.0), _ptr(out3), _ptr(ws),
                                   gars._stream(device)), "bm_stack_stats")
+  if scale is not None:
+    return avg, out3, scaled
   return avg, out3
 
 

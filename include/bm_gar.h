@@ -100,9 +100,14 @@ int bm_aksel_pass1(const float* const* rows, int n, int64_t d, float* median_out
                    double* sq_out, void* ws, void* stream);
 
 /* tools/pytorch.py:97-125 in one pass: avg_out = sequential mean of the k rows;
- * out3 = { sum_j avg_j^2, sum_i sum_j (rows[i][j]-avg_j)^2, max_j |avg_j| }. */
+ * out3 = { sum_j avg_j^2, sum_i sum_j (rows[i][j]-avg_j)^2, max_j |avg_j| }.
+ * If scaled_out is non-NULL it receives avg + scale * (-avg) in the same pass, rounded like the
+ * reference's `grad_att = grad_avg.neg(); grad_att.mul_(factor); byz = grad_avg.add_(grad_att)`:
+ * the Byzantine vector of the "empire" attack with factor = scale (attacks/identical.py:63-86,
+ * 129-134) comes for free with the honest-stack statistics the study block needs anyway
+ * (attack.py:847). */
 int bm_stack_stats(const float* const* rows, int k, int64_t d, float* avg_out,
-                   double* out3, void* ws, void* stream);
+                   float* scaled_out, float scale, double* out3, void* ws, void* stream);
 
 /* The dot products of the study block (attack.py:851-868) in one pass:
  *   out[a*nc+b]   = <core[a], core[b]>   for the nc (<= 4) "core" vectors (symmetric, the

@@ -338,3 +338,42 @@ def test_full_size_krum_bulyan_properties(bm, full_stack):
   assert bool(torch.isfinite(out).all())
   top = torch.stack([rows[i] for i in order[:n - f - 2]])
   assert bool((out <= top.max(dim=0).values).all() and (out >= top.min(dim=0).values).all())
+
+
+def test_aggregation_step_matches_oracle_simulation(bm):
+  """Three steps of the attack.py:800-878 mirror (worker momentum, empire attack, Krum, study
+  statistics with past gradients) against the same loop written with the oracle."""
+  from byzantinemomentum_amd.step import AggregationStep
+  n, f, d, mu, damp, factor = 11, 2, 30011, 0.9, 0.9, 1.1
+  h = n - f
+  step = AggregationStep(n, f, f, gar="krum", momentum=mu, dampening=damp, attack_factor=factor, nb_past=3)
+  gen = torch.Generator().manual_seed(123)
+  bufs = [torch.zeros(d) for _ in range(h)]
+  pasts = []
+  for it in range(3):
+    base = 0.2 * torch.randn(d, generator=gen)
+    sampled = [base + (0.5 + 0.1 * i) * torch.randn(d, generator=gen) for i in range(h)]
+    defense = step.run([g.to(DEV) for g in sampled])
+    got = step.floats()
+    # oracle loop
+    O.worker_momentum(bufs, sampled, mu, damp)
+    avg = torch.stack(bufs).mean(dim=0)
+    att = avg.neg()
+    att.mul_(factor)
+    byz = avg.add(att)
+    grads = list(bufs) + [byz] * f
+    want_def = O.krum(grads, f)
+    want = O.study_block(sampled, bufs, grads[h:], want_def, pasts, mu, "f64")
+    scale = float(torch.stack(bufs).abs().max())
+    assert close(defense, want_def, 2e-6, scale)
+    for key in ("sampled_norm_avg", "honest_norm_avg", "attack_norm_avg", "defense_norm_avg", "sampled_norm_dev",
+                "honest_norm_dev", "sampled_norm_max", "honest_norm_max", "attack_norm_max", "defense_norm_max"):
+      assert abs(got[key] - want[key]) <= 1e-5 * max(abs(want[key]), 1e-3), (it, key, got[key], want[key])
+    assert abs(got["attack_norm_dev"] - want["attack_norm_dev"]) <= 1e-5 * want["attack_norm_avg"]
+    for key in ("cosin_splhon", "cosin_splatt", "cosin_spldef", "cosin_honatt", "cosin_hondef", "cosin_attdef",
+                "cosin_sampled"):
+      assert (math.isnan(got[key]) and math.isnan(want[key])) or abs(got[key] - want[key]) <= 1e-5, (it, key)
+    if it > 0:
+      assert abs(got["curv_sampled"] - want["curv_sampled"]) <= 1e-5 * max(abs(want["curv_sampled"]), 1.0)
+    pasts.insert(0, (want["sampled_grad_avg"], want["sampled_norm_avg"]))
+    pasts = pasts[:3]
