@@ -83,9 +83,14 @@ struct MergeExchange {
   static constexpr Table table = make();
 };
 
+// One comparator = v_min_f32 + v_max_f32.  Written as (non-volatile, hence DCE-able) inline asm:
+// through fminf/fmaxf the compiler first canonicalises every loaded value (one extra v_max x,x per
+// input, +10 % VALU on the median) because it must quiet signalling NaNs; columns that contain a
+// NaN never use the network's result, so that is wasted work here.
 __device__ __forceinline__ void cmp_exchange(float& a, float& b) {
-  const float lo = fminf(a, b);
-  const float hi = fmaxf(a, b);
+  float lo, hi;
+  asm("v_min_f32 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+  asm("v_max_f32 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
   a = lo;
   b = hi;
 }
@@ -142,6 +147,17 @@ __device__ __forceinline__ void load_stream(const float* p, float (&dst)[VEC]) {
   }
 }
 
+// Same with a wave-uniform base pointer and a 32-bit per-lane BYTE offset: the compiler emits
+// `global_load_dwordx4 v, v_off, s[base:base+1]` (saddr form) — no 64-bit VALU address arithmetic
+// and one offset register shared by all the rows of a column.
+template <int VEC>
+__device__ __forceinline__ void load_stream_off(const float* base, uint32_t byte_off, float (&dst)[VEC]) {
+  load_stream<VEC>(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off), dst);
+}
+
+template <int VEC>
+__device__ __forceinline__ void store_stream_off(float* base, uint32_t byte_off, const float (&src)[VEC]);
+
 template <int VEC>
 __device__ __forceinline__ void store_stream(float* p, const float (&src)[VEC]) {
   using T = typename VecLoad<VEC>::T;
@@ -154,6 +170,14 @@ __device__ __forceinline__ void store_stream(float* p, const float (&src)[VEC]) 
   }
   __builtin_nontemporal_store(v, reinterpret_cast<T*>(p));
 }
+
+template <int VEC>
+__device__ __forceinline__ void store_stream_off(float* base, uint32_t byte_off, const float (&src)[VEC]) {
+  store_stream<VEC>(reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off), src);
+}
+
+// Columns per launch such that every byte offset fits 32 bits (saddr addressing).
+constexpr int64_t kMaxColsPerLaunch = (int64_t)1 << 29;
 
 // Largest vector width (4, 2 or 1 floats) every pointer of the table and `extra` allow.
 static inline int common_vec_width(const void* const* ptrs, int n, const void* extra) {

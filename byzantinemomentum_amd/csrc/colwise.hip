@@ -21,16 +21,22 @@
 namespace bm {
 
 template <int N, int OP, int VEC>
-static int launch_colwise_vec(const RowTable& rows, int64_t d, int f, float* out,
+static int launch_colwise_vec(const RowTable& rows_all, int64_t d_all, int f, float* out_all,
                               hipStream_t stream) {
-  const int64_t nvec = d / VEC;
-  const int tail = (int)(d - nvec * VEC);
   const int keep = (OP == BM_OP_TRMEAN) ? (N - 2 * f) : (N - f);
   const float inv_keep = 1.0f / (float)(keep > 0 ? keep : 1);
-  const int grid = stream_grid(nvec, kColBlock, tuning().col_max_blocks);
-  hipLaunchKernelGGL((colwise_kernel<N, OP, VEC>), dim3(grid), dim3(kColBlock), 0, stream, rows,
-                     nvec, tail, f, inv_keep, out);
-  BM_LAUNCH_CHECK();
+  // pieces of at most 2^29 columns so that byte offsets fit 32 bits inside the kernel
+  for (int64_t lo = 0; lo < d_all; lo += kMaxColsPerLaunch) {
+    const int64_t d = (d_all - lo < kMaxColsPerLaunch) ? (d_all - lo) : kMaxColsPerLaunch;
+    RowTable rows = rows_all;
+    for (int i = 0; i < N; ++i) rows.p[i] += lo;
+    const int64_t nvec = d / VEC;
+    const int tail = (int)(d - nvec * VEC);
+    const int grid = stream_grid(nvec, kColBlock, tuning().col_max_blocks);
+    hipLaunchKernelGGL((colwise_kernel<N, OP, VEC>), dim3(grid), dim3(kColBlock), 0, stream, rows,
+                       nvec, tail, f, inv_keep, out_all + lo);
+    BM_LAUNCH_CHECK();
+  }
   return 0;
 }
 

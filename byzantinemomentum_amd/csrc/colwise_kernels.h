@@ -6,6 +6,18 @@ namespace bm {
 
 constexpr int kColBlock = 256;
 
+// Trimmed mean when the wave holds neither NaN nor infinity (checked by the caller, i.e. always in
+// practice): the trimmed sum is one v_fmac per rank with a wave-uniform 0/1 weight instead of a
+// v_cndmask + v_add pair (0 * inf would be NaN, hence the infinity check), and no NaN bookkeeping.
+template <int N>
+__device__ __forceinline__ float trmean_finite(float (&x)[N], int f, float inv_keep) {
+  sort_network<N>(x);
+  float tsum = 0.0f;
+#pragma unroll
+  for (int i = 0; i < N; ++i) tsum = __builtin_fmaf(x[i], (i >= f && i < N - f) ? 1.0f : 0.0f, tsum);
+  return div_small_int(tsum, (float)(N - 2 * f), inv_keep);
+}
+
 // Per-column rule on N register-resident values.  `lds` points at this lane's slot of a
 // [N][kColBlock] scratch array (only used by the closest-to-centre rules).
 template <int N, int OP>
@@ -81,20 +93,26 @@ __global__ __launch_bounds__(kColBlock) void colwise_kernel(RowTable rows, int64
   __shared__ float scratch[kNeedsLds ? N * kColBlock : 1];
   float* lds = scratch + (kNeedsLds ? threadIdx.x : 0);
 
-  const int64_t stride = (int64_t)gridDim.x * kColBlock;
-  for (int64_t v = (int64_t)blockIdx.x * kColBlock + threadIdx.x; v < nvec; v += stride) {
+  // nvec * VEC * 4 < 2^32 (the host splits longer gradients): 32-bit byte offsets, saddr loads
+  const uint32_t nv = (uint32_t)nvec;
+  const uint32_t stride = gridDim.x * kColBlock;
+  for (uint32_t v = blockIdx.x * kColBlock + threadIdx.x; v < nv; v += stride) {
+    const uint32_t off = v * (uint32_t)(VEC * sizeof(float));
     float x[VEC][N];
+    auto load_columns = [&]() {
 #pragma unroll
-    for (int i = 0; i < N; ++i) {
-      float t[VEC];
-      load_stream<VEC>(rows.p[i] + v * VEC, t);
+      for (int i = 0; i < N; ++i) {
+        float t[VEC];
+        load_stream_off<VEC>(rows.p[i], off, t);
 #pragma unroll
-      for (int c = 0; c < VEC; ++c) x[c][i] = t[c];
-    }
+        for (int c = 0; c < VEC; ++c) x[c][i] = t[c];
+      }
+    };
+    load_columns();
     float r[VEC];
 #pragma unroll
     for (int c = 0; c < VEC; ++c) r[c] = column_rule<N, OP>(x[c], f, inv_keep, lds);
-    store_stream<VEC>(out + v * VEC, r);
+    store_stream_off<VEC>(out, off, r);
   }
   // the d % VEC trailing columns: one lane each, in the last workgroup (no second launch)
   if (VEC > 1 && blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < tail) {
