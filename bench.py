@@ -156,7 +156,9 @@ def main():
     raise SystemExit("bench.py needs an MI355X: no GPU visible")
   device = torch.device("cuda", local_rank)
   torch.cuda.set_device(device)
-  distributed = world > 1
+  # under torch.distributed.run the process group is created even for one rank, so that a single-GPU
+  # run exercises exactly the RCCL code path of the N>1 runs
+  distributed = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ
   if distributed:
     import torch.distributed as dist
     dist.init_process_group("nccl", device_id=device)
@@ -208,7 +210,7 @@ def main():
                      f"study statistics with 25 past gradients; n={n}, f={f}, d={d}")
   else:
     from byzantinemomentum_amd.sharded import ShardedAggregator
-    agg = ShardedAggregator()
+    agg = ShardedAggregator(force_collectives=distributed)
     if args.workload == "krum":
       n, f = 51, 12
     else:

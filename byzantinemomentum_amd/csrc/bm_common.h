@@ -225,6 +225,7 @@ struct Tuning {
   int pair_blocks;     // BM_PAIR_BLOCKS: persistent grid of the pairwise-distance kernel
   int pair_strips;     // BM_PAIR_STRIPS: force a tile shape, strips*100+slots (e.g. 208), 0 = automatic
   int pair_ablate;     // BM_PAIR_ABLATE: 1 = no compute, 2 = no staging (experiments)
+  int pair_nbuf;       // BM_PAIR_NBUF: LDS tile buffers of the Gram kernel, 2 (default, measured best) or 3
   int pair_mode;       // BM_PAIR_MODE: 0 = MFMA Gram contraction (default), 1 = direct differences on the VALU
 };
 const Tuning& tuning();

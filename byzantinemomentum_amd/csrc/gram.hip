@@ -22,8 +22,8 @@
 //     reduction at the end emits the workgroup's partial Gram (upper triangle only).
 //
 // Numerics:
-//   * two-level fp32 accumulation (<= 256-coordinate chains inside the MFMA accumulator, then a
-//     per-wave fp32 sum of a few dozen chains), fp64 across waves, workgroups and GPUs:
+//   * two-level fp32 accumulation (16..64-coordinate chains inside the MFMA accumulator, then a
+//     per-wave fp32 sum of those chains), fp64 across waves, workgroups and GPUs:
 //     error ~3e-9 * (G_ii + G_jj) measured, i.e. ~1e-6 relative on a distance even for rows whose
 //     distance is 30x smaller than their norms;
 //   * bitwise-equal rows give bitwise-equal G entries (same instruction sequence, same k order),
@@ -59,7 +59,32 @@ __device__ __forceinline__ int gram_row_offset(const GramGeom& g, int r) {
   return (r / g.rows_per_dma) * kGramDmaPitch + (r % g.rows_per_dma) * g.row_bytes;
 }
 
-template <int RB, bool ALIGNED>
+// s_waitcnt vmcnt(k) with a run-time (wave-uniform) k: "all but the k most recent VMEM ops are done"
+__device__ __forceinline__ void wait_vmem_all_but(int k) {
+  switch (k) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+    case 15: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    case 16: asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;  // conservative
+  }
+}
+
+// NBUF tile buffers per workgroup: the DMA of tile t+NBUF-1 is issued while tile t is contracted.
+template <int RB, int NBUF, bool ALIGNED>
 __global__ __launch_bounds__(64 * kGramWaves) void gram_partial_kernel(RowTable rows, GramGeom g, int64_t d,
                                                                        double* __restrict__ partial) {
   constexpr int NP = gram_pairs(RB);
@@ -74,7 +99,7 @@ __global__ __launch_bounds__(64 * kGramWaves) void gram_partial_kernel(RowTable 
   const int tile_bytes = (g.nb + 1) * kGramDmaPitch;  // + one block that stays zero
 
   for (int r = tid; r < BM_MAX_ROWS; r += blockDim.x) row_ptr[r] = nullptr;
-  for (int o = tid * 16; o < 2 * tile_bytes; o += blockDim.x * 16)
+  for (int o = tid * 16; o < NBUF * tile_bytes; o += blockDim.x * 16)
     *reinterpret_cast<f32x4*>(tiles + o) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   __syncthreads();
   if (tid == 0)
@@ -93,10 +118,7 @@ __global__ __launch_bounds__(64 * kGramWaves) void gram_partial_kernel(RowTable 
 
   f32x4 acc[NP], outer[NP];
 #pragma unroll
-  for (int p = 0; p < NP; ++p) {
-    acc[p] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    outer[p] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  }
+  for (int p = 0; p < NP; ++p) outer[p] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 
   const int width = g.width;
   const int lanes_per_row = g.row_bytes / 16;
@@ -137,23 +159,64 @@ __global__ __launch_bounds__(64 * kGramWaves) void gram_partial_kernel(RowTable 
   };
 
   const int steps = width / 16;  // 16-coordinate steps per tile: 4, 8 or 16
-  int since_flush = 0;
-  int64_t chunk = blockIdx.x;
-  if (chunk * width < d) stage(chunk * width, tiles);
+  // DMA instructions this wave issues per tile (wave-uniform): the counted wait below leaves the
+  // NBUF-2 most recent tiles in flight.
+  int dma_per_tile = 0;
+  for (int blk = wave; blk < g.nb; blk += kGramWaves) ++dma_per_tile;
+  int64_t chunk = blockIdx.x;                                 // chunk being contracted
+  int64_t ahead = chunk;                                      // next chunk to stage
+#pragma unroll
+  for (int b = 0; b < NBUF - 1; ++b) {
+    if (ahead * width < d) stage(ahead * width, tiles + b * tile_bytes);
+    ahead += gridDim.x;
+  }
   for (int it = 0;; ++it) {
     if (chunk * width >= d) break;
-    const char* cur = tiles + (it & 1) * tile_bytes;
-    char* nxt = tiles + ((it + 1) & 1) * tile_bytes;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of `cur` have landed
-    __syncthreads();  // ... everyone's have, and everyone is done reading `nxt`
-    chunk += gridDim.x;
-    if (chunk * width < d) stage(chunk * width, nxt);  // in flight under the MFMAs below
-
-#pragma unroll 1
-    for (int s = wave; s < steps; s += kGramWaves) {
-      f32x4 x[RB];
+    const char* cur = tiles + (it % NBUF) * tile_bytes;
+    char* nxt = tiles + ((it + NBUF - 1) % NBUF) * tile_bytes;
+    // tiles still allowed in flight behind `cur`: those staged for chunks it+1 .. it+NBUF-2
+    int later = 0;
 #pragma unroll
-      for (int R = 0; R < RB; ++R) x[R] = *reinterpret_cast<const f32x4*>(cur + frag_off[R] + s * 64);
+    for (int b = 1; b <= NBUF - 2; ++b)
+      if ((chunk + (int64_t)b * gridDim.x) * width < d) ++later;
+    wait_vmem_all_but(ALIGNED ? later * dma_per_tile : 0);  // this wave's pieces of `cur` have landed
+    __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): LDS reads of the previous tile
+    __builtin_amdgcn_s_barrier();  // ... everyone's have landed, and everyone is done reading `nxt`
+    if (ahead * width < d) stage(ahead * width, nxt);  // in flight under the MFMAs below
+    ahead += gridDim.x;
+    chunk += gridDim.x;
+
+    // This wave's steps of the tile: s = wave, wave+4, ...  The first one starts every accumulator
+    // from the inline constant 0 (no zeroing moves), the fragments of step s+4 are read before the
+    // MFMAs of step s, and at the end of the tile the chains (<= 64 coordinates) are added to the
+    // per-wave fp32 sums unconditionally — no phi copies of 2 x 4*NP registers around a branch.
+    f32x4 x[RB], xn[RB];
+#pragma unroll
+    for (int R = 0; R < RB; ++R) x[R] = *reinterpret_cast<const f32x4*>(cur + frag_off[R] + wave * 64);
+    {
+#pragma unroll
+      for (int R = 0; R < RB; ++R)
+        xn[R] = *reinterpret_cast<const f32x4*>(cur + frag_off[R] + ((wave + kGramWaves) % steps) * 64);
+      const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        int p = 0;
+#pragma unroll
+        for (int I = 0; I < RB; ++I)
+#pragma unroll
+          for (int J = I; J < RB; ++J) {
+            acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[I][t], x[J][t], t == 0 ? zero : acc[p], 0, 0, 0);
+            ++p;
+          }
+      }
+    }
+#pragma unroll 1
+    for (int s = wave + kGramWaves; s < steps; s += kGramWaves) {
+#pragma unroll
+      for (int R = 0; R < RB; ++R) x[R] = xn[R];
+#pragma unroll
+      for (int R = 0; R < RB; ++R)
+        xn[R] = *reinterpret_cast<const f32x4*>(cur + frag_off[R] + ((s + kGramWaves) % steps) * 64);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         int p = 0;
@@ -165,19 +228,10 @@ __global__ __launch_bounds__(64 * kGramWaves) void gram_partial_kernel(RowTable 
             ++p;
           }
       }
-      ++since_flush;
     }
-    if (since_flush >= kGramFlushSteps) {  // once per tile at most: chains of 16..19 steps
 #pragma unroll
-      for (int p = 0; p < NP; ++p) {
-        outer[p] += acc[p];
-        acc[p] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-      }
-      since_flush = 0;
-    }
+    for (int p = 0; p < NP; ++p) outer[p] += acc[p];
   }
-#pragma unroll
-  for (int p = 0; p < NP; ++p) outer[p] += acc[p];
 
   // ---- workgroup reduction, one 16x16 block at a time, fixed order; compact upper triangle ----
   // C/D layout of the 16x16 MFMA: lane l, register v -> row 4*(l>>4)+v, column l&15.
@@ -268,9 +322,11 @@ static GramGeom gram_geometry(int n) {
 template <int RB>
 static int launch_gram(const RowTable& tab, const GramGeom& g, int64_t d, bool aligned, double* partial,
                        int blocks, hipStream_t s) {
+  const int nbuf = tuning().pair_nbuf == 2 ? 2 : 3;
   const size_t lds = BM_MAX_ROWS * sizeof(float*) + kGramWaves * 256 * sizeof(double) +
-                     (size_t)2 * (g.nb + 1) * kGramDmaPitch;
-  auto kern = aligned ? gram_partial_kernel<RB, true> : gram_partial_kernel<RB, false>;
+                     (size_t)nbuf * (g.nb + 1) * kGramDmaPitch;
+  auto kern = !aligned ? gram_partial_kernel<RB, 2, false>
+                       : (nbuf == 2 ? gram_partial_kernel<RB, 2, true> : gram_partial_kernel<RB, 3, true>);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -76,22 +76,26 @@ class HipBackend:
 class ShardedAggregator:
   """Aggregation rules over gradients whose coordinates are sharded across the ranks of `group`."""
 
-  def __init__(self, backend=None, group=None):
+  def __init__(self, backend=None, group=None, force_collectives=False):
     self.backend = backend if backend is not None else HipBackend()
     self.group = group
-    self.world_size = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
-    self.rank = dist.get_rank(group) if self.world_size > 1 else 0
+    initialised = dist.is_available() and dist.is_initialized()
+    self.world_size = dist.get_world_size(group) if initialised else 1
+    self.rank = dist.get_rank(group) if initialised else 0
+    # force_collectives: issue the all-reduce / all-gather calls even with one rank (used to
+    # exercise the RCCL path on a single-GPU box); never set in production with world_size 1
+    self.collective = self.world_size > 1 or (force_collectives and initialised)
 
   # -- collectives (never called when world_size == 1) ----------------------- #
 
   def _all_reduce(self, tensor, op=None):
-    if self.world_size > 1:
+    if self.collective:
       dist.all_reduce(tensor, op=(op or dist.ReduceOp.SUM), group=self.group)
     return tensor
 
   def all_gather_output(self, local_out, d):
     """Full d-vector on every rank from the per-rank slices (shard_bounds layout)."""
-    if self.world_size == 1:
+    if not self.collective:
       return local_out
     lo0, hi0 = shard_bounds(d, self.world_size, 0)
     per = hi0 - lo0
@@ -119,7 +123,7 @@ class ShardedAggregator:
     """All-reduced n x n squared-distance matrix (every rank gets the same bits: the sum runs over
     the same P partial matrices in the collective's fixed order)."""
     sq = self.backend.pairwise_sqdist(local)
-    if self.world_size > 1:
+    if self.collective:
       sq = sq.clone()
       self._all_reduce(sq)
     return sq
@@ -142,7 +146,7 @@ class ShardedAggregator:
     n = len(local)
     count = (n + 1) // 2 if mode == "mid" else n - f
     sq = self.backend.aksel_sqdist(local)
-    if self.world_size > 1:
+    if self.collective:
       sq = sq.clone()
       self._all_reduce(sq)
     return self.backend.selected_mean(local, self.backend.argsort(sq, n), count)
@@ -153,7 +157,7 @@ class ShardedAggregator:
     if k == 0:
       return None, math.nan, math.nan, math.nan
     avg, out3 = self.backend.stack_stats(local_samples)
-    if self.world_size > 1:
+    if self.collective:
       sums = out3[:2].clone()
       mx = out3[2:].clone()
       self._all_reduce(sums)

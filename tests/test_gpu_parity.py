@@ -377,3 +377,48 @@ def test_aggregation_step_matches_oracle_simulation(bm):
       assert abs(got["curv_sampled"] - want["curv_sampled"]) <= 1e-5 * max(abs(want["curv_sampled"]), 1.0)
     pasts.insert(0, (want["sampled_grad_avg"], want["sampled_norm_avg"]))
     pasts = pasts[:3]
+
+
+def test_sharded_aggregator_hip_backend_single_rank(bm):
+  """World size 1: the sharded front end must give exactly the plain rules and issue no collective."""
+  from byzantinemomentum_amd.sharded import ShardedAggregator
+  rows, h = O.make_stack("hetero", 25, 5, 40007, seed=17)
+  dev = to_dev(rows)
+  agg = ShardedAggregator()
+  assert agg.world_size == 1 and not agg.collective
+  assert torch.equal(agg.median(dev), bm.median(dev))
+  assert torch.equal(agg.trmean(dev, 5), bm.trmean(dev, 5))
+  assert torch.equal(agg.krum(dev, 5), bm.krum(dev, 5))
+  assert torch.equal(agg.bulyan(dev, 5), bm.bulyan(dev, 5))
+  assert torch.equal(agg.aksel(dev, 5), bm.aksel(dev, 5))
+  avg, norm, devi, mx = agg.compute_avg_dev_max(dev[:h])
+  want = bm.compute_avg_dev_max(dev[:h])
+  assert torch.equal(avg, want[0]) and (norm, devi, mx) == want[1:]
+
+
+def test_rccl_path_on_one_gpu(bm):
+  """One-rank NCCL(=RCCL) process group with forced collectives: the exact code path of the
+  multi-GPU runs (all-reduce of the fp64 distance matrix, all-gather of the output)."""
+  import torch.distributed as dist
+  from byzantinemomentum_amd.sharded import ShardedAggregator
+  import os
+  import socket
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+  dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+  try:
+    rows, h = O.make_stack("hetero", 25, 5, 40007, seed=18)
+    dev = to_dev(rows)
+    agg = ShardedAggregator(force_collectives=True)
+    assert agg.collective
+    out = agg.bulyan(dev, 5)
+    assert torch.equal(out, bm.bulyan(dev, 5))
+    assert torch.equal(agg.all_gather_output(out, 40007), out)
+    assert torch.equal(agg.krum(dev, 5), bm.krum(dev, 5))
+    want = bm.compute_avg_dev_max(dev[:h])
+    got = agg.compute_avg_dev_max(dev[:h])
+    assert torch.equal(got[0], want[0]) and got[1:] == want[1:]
+  finally:
+    dist.destroy_process_group()
