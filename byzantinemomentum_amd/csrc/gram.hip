@@ -84,14 +84,14 @@ __device__ __forceinline__ void wait_vmem_all_but(int k) {
 }
 
 // NBUF tile buffers per workgroup: the DMA of tile t+NBUF-1 is issued while tile t is contracted.
-template <int RB, int NBUF, bool ALIGNED>
-__global__ __launch_bounds__(64 * kGramWaves) void gram_partial_kernel(RowTable rows, GramGeom g, int64_t d,
-                                                                       double* __restrict__ partial) {
+template <int RB, int NBUF, bool ALIGNED, int W = kGramWaves>
+__global__ __launch_bounds__(64 * W) void gram_partial_kernel(RowTable rows, GramGeom g, int64_t d,
+                                                              double* __restrict__ partial) {
   constexpr int NP = gram_pairs(RB);
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const float** row_ptr = reinterpret_cast<const float**>(smem);  // 512 B pointer table
   double* red = reinterpret_cast<double*>(smem + BM_MAX_ROWS * sizeof(float*));  // [waves][256]
-  char* tiles = smem + BM_MAX_ROWS * sizeof(float*) + kGramWaves * 256 * sizeof(double);
+  char* tiles = smem + BM_MAX_ROWS * sizeof(float*) + W * 256 * sizeof(double);
   const int n = g.n;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63;
@@ -125,15 +125,25 @@ __global__ __launch_bounds__(64 * kGramWaves) void gram_partial_kernel(RowTable 
   const int dma_w = lane / lanes_per_row;
   const int dma_col = (lane - dma_w * lanes_per_row) * 4;
 
+  // Per-lane source pointers of this wave's DMA pieces (piece k = DMA block wave + k*W), resolved
+  // once: inside the loop a piece costs one 64-bit add, no LDS pointer lookup and no wait.
+  constexpr int kMaxDma = 8;
+  const float* dma_src[kMaxDma];
+#pragma unroll
+  for (int k = 0; k < kMaxDma; ++k) {
+    const int blk = wave + k * W;
+    const int r = blk * g.rows_per_dma + dma_w;
+    dma_src[k] = (blk < g.nb && r < n) ? row_ptr[r] + dma_col : nullptr;
+  }
   auto stage = [&](int64_t base, char* buf) {
     if (ALIGNED && base + width <= d) {
-      for (int blk = wave; blk < g.nb; blk += kGramWaves) {
-        const int r = blk * g.rows_per_dma + dma_w;
-        if (r < n) {
-          const float* src = row_ptr[r] + base + dma_col;
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                           (__attribute__((address_space(3))) void*)(buf + blk * kGramDmaPitch),
-                                           16, 0, 0);
+#pragma unroll
+      for (int k = 0; k < kMaxDma; ++k) {
+        if (wave + k * W < g.nb) {  // wave-uniform
+          if (dma_src[k] != nullptr)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(dma_src[k] + base),
+                (__attribute__((address_space(3))) void*)(buf + (wave + k * W) * kGramDmaPitch), 16, 0, 0);
         }
       }
     } else {
@@ -162,7 +172,7 @@ __global__ __launch_bounds__(64 * kGramWaves) void gram_partial_kernel(RowTable 
   // DMA instructions this wave issues per tile (wave-uniform): the counted wait below leaves the
   // NBUF-2 most recent tiles in flight.
   int dma_per_tile = 0;
-  for (int blk = wave; blk < g.nb; blk += kGramWaves) ++dma_per_tile;
+  for (int blk = wave; blk < g.nb; blk += W) ++dma_per_tile;
   int64_t chunk = blockIdx.x;                                 // chunk being contracted
   int64_t ahead = chunk;                                      // next chunk to stage
 #pragma unroll
@@ -196,7 +206,7 @@ __global__ __launch_bounds__(64 * kGramWaves) void gram_partial_kernel(RowTable 
     {
 #pragma unroll
       for (int R = 0; R < RB; ++R)
-        xn[R] = *reinterpret_cast<const f32x4*>(cur + frag_off[R] + ((wave + kGramWaves) % steps) * 64);
+        xn[R] = *reinterpret_cast<const f32x4*>(cur + frag_off[R] + ((wave + W) % steps) * 64);
       const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
@@ -211,12 +221,12 @@ __global__ __launch_bounds__(64 * kGramWaves) void gram_partial_kernel(RowTable 
       }
     }
 #pragma unroll 1
-    for (int s = wave + kGramWaves; s < steps; s += kGramWaves) {
+    for (int s = wave + W; s < steps; s += W) {
 #pragma unroll
       for (int R = 0; R < RB; ++R) x[R] = xn[R];
 #pragma unroll
       for (int R = 0; R < RB; ++R)
-        xn[R] = *reinterpret_cast<const f32x4*>(cur + frag_off[R] + ((s + kGramWaves) % steps) * 64);
+        xn[R] = *reinterpret_cast<const f32x4*>(cur + frag_off[R] + ((s + W) % steps) * 64);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         int p = 0;
@@ -246,12 +256,14 @@ __global__ __launch_bounds__(64 * kGramWaves) void gram_partial_kernel(RowTable 
       for (int v = 0; v < 4; ++v) red[wave * 256 + (4 * lq + v) * 16 + li] = (double)outer[p][v];
       __syncthreads();
       {
-        const int rr = tid >> 4, cc = tid & 15;  // 256 threads <-> 16x16 entries
-        double s = red[tid];
+        if (tid < 256) {
+          const int rr = tid >> 4, cc = tid & 15;  // 256 threads <-> 16x16 entries
+          double s = red[tid];
 #pragma unroll
-        for (int w = 1; w < kGramWaves; ++w) s += red[w * 256 + tid];
-        const int gi = 16 * I + rr, gj = 16 * J + cc;
-        if (gi <= gj && gj < n) partial[(int64_t)blockIdx.x * per_block + tri_index(gi, gj, n)] = s;
+          for (int w = 1; w < W; ++w) s += red[w * 256 + tid];
+          const int gi = 16 * I + rr, gj = 16 * J + cc;
+          if (gi <= gj && gj < n) partial[(int64_t)blockIdx.x * per_block + tri_index(gi, gj, n)] = s;
+        }
       }
       __syncthreads();
       ++p;
@@ -322,17 +334,20 @@ static GramGeom gram_geometry(int n) {
 template <int RB>
 static int launch_gram(const RowTable& tab, const GramGeom& g, int64_t d, bool aligned, double* partial,
                        int blocks, hipStream_t s) {
-  const int nbuf = tuning().pair_nbuf == 2 ? 2 : 3;
-  const size_t lds = BM_MAX_ROWS * sizeof(float*) + kGramWaves * 256 * sizeof(double) +
+  if ((g.nb + kGramWaves - 1) / kGramWaves > 8) return BM_EINVAL;  // kMaxDma pieces per wave and tile
+  const int nbuf = tuning().pair_nbuf == 3 ? 3 : 2;
+  const int waves = (tuning().pair_ablate == 8 && g.width / 16 >= 8) ? 8 : kGramWaves;  // experiment knob
+  const size_t lds = BM_MAX_ROWS * sizeof(float*) + waves * 256 * sizeof(double) +
                      (size_t)nbuf * (g.nb + 1) * kGramDmaPitch;
   auto kern = !aligned ? gram_partial_kernel<RB, 2, false>
-                       : (nbuf == 2 ? gram_partial_kernel<RB, 2, true> : gram_partial_kernel<RB, 3, true>);
+                       : (waves == 8 ? gram_partial_kernel<RB, 2, true, 8>
+                                     : (nbuf == 2 ? gram_partial_kernel<RB, 2, true> : gram_partial_kernel<RB, 3, true>));
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return hip_code(e);
   }
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * kGramWaves), lds, s, tab, g, d, partial);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * waves), lds, s, tab, g, d, partial);
   BM_LAUNCH_CHECK();
   return 0;
 }

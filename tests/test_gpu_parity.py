@@ -422,3 +422,29 @@ def test_rccl_path_on_one_gpu(bm):
     assert torch.equal(got[0], want[0]) and got[1:] == want[1:]
   finally:
     dist.destroy_process_group()
+
+
+def test_influence_hooks_match_reference_semantics(bm):
+  """`native` influence functions: fraction of the selected gradients that ARE attack tensors
+  (aggregators/krum.py:126-150, brute.py:118-140, aksel.py:83-105), from the selected indices."""
+  import native
+  rows, h = O.make_stack("hetero", 11, 2, 5003, seed=31)
+  dev = to_dev(rows)
+  honests, attacks = dev[:h], dev[h:]
+  order, _ = O.krum_order(rows, 2)
+  for m in (None, 1, 3):
+    mm = 11 - 2 - 2 if m is None else m
+    want = sum(1 for i in order[:mm] if i >= h) / mm
+    assert native._influence_krum(honests, attacks, 2, m) == want
+  sel = O.brute_selection(rows, 2)
+  assert native._influence_brute(honests, attacks, 2) == sum(1 for i in sel if i >= h) / len(sel)
+  ao, _ = O.aksel_order(rows)
+  assert native._influence_aksel(honests, attacks, 2) == sum(1 for i in ao[:6] if i >= h) / 6
+  assert native._influence_aksel(honests, attacks, 2, mode="n-f") == sum(1 for i in ao[:9] if i >= h) / 9
+  co, _ = O.cge_order(rows)
+  assert native._influence_cge(honests, attacks, 2) == sum(1 for i in co[:9] if i >= h) / 9
+  # the ranking cache must not survive an in-place change of a gradient
+  before = bm.gars.krum_selection(dev, 2)
+  dev[0].mul_(50.0)
+  after = bm.gars.krum_selection(dev, 2)
+  assert 0 in before and 0 not in after
