@@ -162,6 +162,11 @@ def main():
   if distributed:
     import torch.distributed as dist
     dist.init_process_group("nccl", device_id=device)
+  from byzantinemomentum_amd import build as bm_build
+  if rank == 0:
+    bm_build.build()  # no-op when the in-tree libbm_gar.so is current
+  if distributed:
+    dist.barrier()
   import byzantinemomentum_amd as bm
   bm._lib.load()
 
@@ -284,7 +289,7 @@ def main():
       elif args.workload == "step":
         pass  # the CPU baseline of the full step is the reference's attack.py itself
       else:
-        line["cpu_baseline"] = cpu_baseline_distance(stacks[0], f, args.workload, min(d, 1 << 20))
+        line["cpu_baseline"] = cpu_baseline_distance(stacks[0], f, args.workload, min(d, 1 << 20))  # bounded sample
     print(json.dumps(line))
   if distributed:
     dist.destroy_process_group()

@@ -1,24 +1,32 @@
-// pairwise.hip — all n(n-1)/2 squared L2 distances in ONE pass over the n x d gradients,
-// plus the on-device score/rank step of Krum and Bulyan.
+// pairwise.hip — the n x n squared-distance entry point, the DIRECT-DIFFERENCE kernel, the
+// cross-workgroup reduction and the on-device score/rank step of Krum and Bulyan.
 //
 // Replaces the reference's per-pair loop
 //     dist = gradients[x].sub(gradients[y]).norm().item()
 // (aggregators/krum.py:44-48, bulyan.py:49-54, brute.py:43-45): n(n-1)/2 x {alloc d, write d,
 // read d, host sync} ~ 100x the algorithmic traffic.  Here every coordinate is read from HBM
-// once (4*d*n bytes) and the direct-difference form (a-b)^2 is kept, so identical rows give an
-// exact 0 and bitwise-equal rows give bitwise-equal distances to any third row (exact score
-// ties, broken by index like the reference's stable sort, krum.py:62).
+// once (4*d*n bytes).
 //
-// Kernel shape (gfx950):
-//   * a workgroup stages a [rows][64*S coords] tile in LDS with the LDS-DMA engine
-//     (global_load_lds_dwordx4, 1 KiB per wave instruction, no staging VGPRs, no ds_write);
-//   * the n rows are cut in groups of 4; a lane owns ONE 4x4 pair tile (I <= J) and one
-//     64-coordinate strip, keeps its 16 (x2, packed even/odd) fp32 accumulators in VGPRs for the
-//     whole kernel, and per step reads 8 x ds_read_b128 and issues 32 v_pk_add + 32 v_pk_fma;
+// bm_pairwise_sqdist dispatches on BM_PAIR_MODE:
+//   0 (default)  Gram contraction on the fp32 matrix cores, gram.hip;
+//   1            the kernel in this file: the direct form sum_k (a_k - b_k)^2, no cancellation at
+//                all, but two VALU lane-ops per (pair, coordinate) make it VALU-bound on gfx950
+//                (1.05 ms at n=51, d=11.2 M; VALU ~90 % busy).  Kept as the measured alternative.
+// Both give an exact 0 between bitwise-equal rows and bitwise-equal distances from them to any
+// third row (exact score ties, broken by index like the reference's stable sort, krum.py:62).
+//
+// Direct kernel shape (gfx950):
+//   * a workgroup stages a [rows][4*slots*S coords] tile in LDS with the LDS-DMA engine
+//     (global_load_lds_dwordx4, 1 KiB per wave instruction, no staging VGPRs, no ds_write), two
+//     tile buffers, the DMA of tile t+1 in flight under the arithmetic of tile t;
+//   * the n rows are cut in groups of 4; a lane owns ONE 4x4 pair tile (I <= J) and one strip of
+//     coordinates, keeps its 16 (x2, packed even/odd) fp32 accumulators in VGPRs for the whole
+//     kernel, and per 4-coordinate slot reads 8 x ds_read_b128 (software pipelined, ping-pong
+//     register sets) and issues 32 v_pk_add_f32 (neg) + 32 v_pk_fma_f32;
 //   * LDS rows live in 1 KiB DMA blocks padded by one 16-B slot, block(I, a) = I + NG*(a/rb), and
 //     lanes are mapped so that each hardware ds_read_b128 service group of 16 lanes sees one
-//     strip and 16 distinct pair tiles: every read is bank-conflict free, and every pair
-//     accumulates its coordinates in the same canonical order (needed for the exact ties);
+//     strip and 16 distinct pair tiles: every read is bank-conflict free (0.2 % measured), and every
+//     pair accumulates its coordinates in the same canonical order (needed for the exact ties);
 //   * per-workgroup partial sums go to a workspace as fp64 and are reduced in a fixed order by
 //     a second tiny kernel — deterministic, no float atomics.
 #include "bm_common.h"

@@ -124,7 +124,7 @@ def pairwise_sqdist(gradients):
   """n x n fp64 matrix of squared L2 distances, on the device, no host sync."""
   n, d, device = _validate(gradients)
   lib = _lib.load()
-  sq = _Scratch.get(device, "sq", shape=(n, n), dtype=torch.float64)
+  sq = torch.empty((n, n), dtype=torch.float64, device=device)  # result: a fresh tensor per call
   ws = _workspace(device, _lib.WS_PAIRWISE, n, d, "ws_pair")
   with torch.cuda.device(device):
     _lib.check(lib.bm_pairwise_sqdist(_lib.pointer_table(gradients), n, d, _ptr(sq), _ptr(ws),
@@ -137,8 +137,8 @@ def rank_from_sqdist(sq, n, f, m, mode):
   (possibly the all-reduced sum of per-shard partial matrices). Returns (order, scores)."""
   device = sq.device
   lib = _lib.load()
-  order = _Scratch.get(device, "order", shape=(_lib.MAX_ROWS,), dtype=torch.int32)
-  scores = _Scratch.get(device, "scores", shape=(_lib.MAX_ROWS,), dtype=torch.float64)
+  order = torch.empty(_lib.MAX_ROWS, dtype=torch.int32, device=device)
+  scores = torch.empty(_lib.MAX_ROWS, dtype=torch.float64, device=device)
   with torch.cuda.device(device):
     _lib.check(lib.bm_krum_rank(_ptr(sq), n, f, m, mode, _ptr(order), _ptr(scores), _stream(device)),
                "bm_krum_rank")
@@ -193,7 +193,6 @@ def _cached_rank(tag, gradients, f, m, mode):
   order = _rank_cache_get(tag, gradients, (f, m))
   if order is None:
     order, _ = _rank(gradients, f, m, mode)
-    order = order.clone()
     _rank_cache_put(tag, gradients, (f, m), order)
   return order
 
@@ -272,7 +271,7 @@ def aksel_sqdist(gradients):
   """fp64[n] squared distances of every row to the coordinate-wise median (device, no sync)."""
   n, d, device = _validate(gradients)
   lib = _lib.load()
-  sq = _Scratch.get(device, "aksel_sq", shape=(_lib.MAX_ROWS,), dtype=torch.float64)
+  sq = torch.empty(_lib.MAX_ROWS, dtype=torch.float64, device=device)
   ws = _workspace(device, _lib.WS_AKSEL, n, d, "ws_aksel")
   with torch.cuda.device(device):
     _lib.check(lib.bm_aksel_pass1(_lib.pointer_table(gradients), n, d, None, _ptr(sq), _ptr(ws),

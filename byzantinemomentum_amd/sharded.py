@@ -122,10 +122,8 @@ class ShardedAggregator:
   def global_sqdist(self, local):
     """All-reduced n x n squared-distance matrix (every rank gets the same bits: the sum runs over
     the same P partial matrices in the collective's fixed order)."""
-    sq = self.backend.pairwise_sqdist(local)
-    if self.collective:
-      sq = sq.clone()
-      self._all_reduce(sq)
+    sq = self.backend.pairwise_sqdist(local)  # a fresh tensor, reduced in place
+    self._all_reduce(sq)
     return sq
 
   def krum(self, local, f, m=None):
@@ -146,9 +144,7 @@ class ShardedAggregator:
     n = len(local)
     count = (n + 1) // 2 if mode == "mid" else n - f
     sq = self.backend.aksel_sqdist(local)
-    if self.collective:
-      sq = sq.clone()
-      self._all_reduce(sq)
+    self._all_reduce(sq)
     return self.backend.selected_mean(local, self.backend.argsort(sq, n), count)
 
   def compute_avg_dev_max(self, local_samples):

@@ -13,6 +13,16 @@ def pytest_configure(config):
   config.addinivalue_line("markers", "reference: needs the read-only reference checkout at /root/reference")
 
 
+def pytest_sessionstart(session):
+  """Make sure the in-tree HIP library exists and is current before any test imports it
+  (incremental: a no-op when libbm_gar.so is newer than its sources; needs only hipcc)."""
+  from byzantinemomentum_amd import build
+  try:
+    build.build()
+  except Exception as err:  # the ABI tests will then fail loudly with the loader's message
+    print(f"[conftest] could not build libbm_gar.so: {err}", file=sys.stderr)
+
+
 def pytest_collection_modifyitems(config, items):
   import torch
   from oracle import reference_loader
