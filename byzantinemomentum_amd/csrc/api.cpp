@@ -12,6 +12,7 @@ static int env_int(const char* name, int dflt) {
 }
 const Tuning& tuning() {
   static const Tuning t = {env_int("BM_FORCE_VEC", 0), env_int("BM_COL_MAX_BLOCKS", 256 * 64),
+                           env_int("BM_COL_DMA", 0), env_int("BM_COL_DMA_BLOCKS", 256 * 3 * 8),
                            env_int("BM_PAIR_BLOCKS", 0), env_int("BM_PAIR_STRIPS", 0), env_int("BM_PAIR_ABLATE", 0), env_int("BM_PAIR_NBUF", 2),
                            env_int("BM_PAIR_MODE", 0)};
   return t;

@@ -448,3 +448,20 @@ def test_influence_hooks_match_reference_semantics(bm):
   dev[0].mul_(50.0)
   after = bm.gars.krum_selection(dev, 2)
   assert 0 in before and 0 not in after
+
+
+@pytest.mark.parametrize("n,f,d", [(25, 5, 300003), (7, 1, 262145), (28, 6, 270000), (4, 1, 1048577)])
+def test_large_columns_nan_inf_and_lds_dma_variant(bm, n, f, d):
+  """Long columns with NaN / inf sprinkled in, ragged last chunk and d % 4 tail.  Run once with the
+  default kernel; `BM_COL_DMA=1 pytest -k lds_dma` exercises the LDS-DMA variant on the same data."""
+  gen = torch.Generator().manual_seed(n * 1000 + f)
+  rows = [torch.randn(d, generator=gen) for _ in range(n)]
+  rows[0][::1001] = math.nan
+  rows[n - 1][5::7777] = math.inf
+  dev = [r.to(DEV) for r in rows]
+  assert same_bits(bm.median(dev), O.median(rows))
+  got, want = bm.trmean(dev, f).cpu(), O.trmean(rows, f)
+  assert bool((torch.isnan(got) == torch.isnan(want)).all())
+  fin = torch.isfinite(want)
+  assert bool(((got[fin] - want[fin]).abs() <= 1e-6 * 5).all())
+  assert bool((got[~fin & ~torch.isnan(want)] == want[~fin & ~torch.isnan(want)]).all())
