@@ -16,13 +16,14 @@ import torch  # noqa: F401  (must be imported before the CDLL, see above)
 _PKG_DIR = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _PKG_DIR / "libbm_gar.so"
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_ROWS = 64
 EINVAL = -100000
 
 OP_MEDIAN, OP_TRMEAN, OP_PHOCAS, OP_MEAMED = 0, 1, 2, 3
 WS_PAIRWISE, WS_AKSEL, WS_STATS, WS_DOT = 0, 1, 2, 3
 RANK_KRUM, RANK_BULYAN = 0, 1
+ATTACK_EMPIRE, ATTACK_LITTLE = 0, 1
 
 _c_float_pp = ctypes.POINTER(ctypes.c_void_p)
 
@@ -44,7 +45,8 @@ SIGNATURES = {
   "bm_aksel_pass1": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
   "bm_stack_stats": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
-                                    ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+                                    ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_void_p]),
   "bm_multi_dot": (ctypes.c_int, [_c_float_pp, ctypes.c_int, _c_float_pp, ctypes.c_int, ctypes.c_int64,
                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
   "bm_stable_argsort": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),

@@ -12,14 +12,13 @@ static int env_int(const char* name, int dflt) {
 }
 const Tuning& tuning() {
   static const Tuning t = {env_int("BM_FORCE_VEC", 0), env_int("BM_COL_MAX_BLOCKS", 256 * 64),
-                           env_int("BM_COL_DMA", 0), env_int("BM_COL_DMA_BLOCKS", 256 * 3 * 8),
                            env_int("BM_PAIR_BLOCKS", 0), env_int("BM_PAIR_STRIPS", 0), env_int("BM_PAIR_ABLATE", 0), env_int("BM_PAIR_NBUF", 2),
                            env_int("BM_PAIR_MODE", 0)};
   return t;
 }
 }  // namespace bm
 
-extern "C" int bm_abi_version(void) { return 2; }
+extern "C" int bm_abi_version(void) { return 3; }
 
 extern "C" const char* bm_error_string(int code) {
   if (code == 0) return "success";

@@ -222,8 +222,6 @@ namespace bm {
 struct Tuning {
   int force_vec;       // BM_FORCE_VEC: 0 auto, 1 or 2 force a narrower column vector
   int col_max_blocks;  // BM_COL_MAX_BLOCKS: grid cap of the column kernels
-  int col_dma;         // BM_COL_DMA: 1 = LDS-DMA variant of median/trmean for N <= 28 (measured slower: 229 vs 194 us), 0 = plain loads (default)
-  int col_dma_blocks;  // BM_COL_DMA_BLOCKS: grid cap of the LDS-DMA column kernel (2 waves per workgroup)
   int pair_blocks;     // BM_PAIR_BLOCKS: persistent grid of the pairwise-distance kernel
   int pair_strips;     // BM_PAIR_STRIPS: force a tile shape, strips*100+slots (e.g. 208), 0 = automatic
   int pair_ablate;     // BM_PAIR_ABLATE: 1 = no compute, 2 = no staging (experiments)

@@ -40,41 +40,6 @@ static int launch_colwise_vec(const RowTable& rows_all, int64_t d_all, int f, fl
   return 0;
 }
 
-// LDS-DMA variant (median / trmean, N <= 28, 16-byte aligned rows): see colwise_kernels.h.
-template <int N, int OP>
-static int launch_colwise_dma(const RowTable& rows_all, int64_t d_all, int f, float* out_all,
-                              hipStream_t stream) {
-  if constexpr ((OP == BM_OP_MEDIAN || OP == BM_OP_TRMEAN) && N <= 28) {
-    const int keep = (OP == BM_OP_TRMEAN) ? (N - 2 * f) : N;
-    const float inv_keep = 1.0f / (float)(keep > 0 ? keep : 1);
-    const size_t lds = (size_t)kDmaColWaves * N * 1024;
-    auto kern = colwise_dma_kernel<N, OP>;
-    if (lds > 64 * 1024) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return hip_code(e);
-    }
-    for (int64_t lo = 0; lo < d_all; lo += kMaxColsPerLaunch) {
-      const int64_t d = (d_all - lo < kMaxColsPerLaunch) ? (d_all - lo) : kMaxColsPerLaunch;
-      RowTable rows = rows_all;
-      for (int i = 0; i < N; ++i) rows.p[i] += lo;
-      const int64_t nvec = d / 4;
-      const int tail = (int)(d - nvec * 4);
-      const int64_t chunks = (nvec + 63) / 64;
-      int grid = (int)((chunks + kDmaColWaves - 1) / kDmaColWaves);
-      const int cap = tuning().col_dma_blocks;
-      if (grid > cap) grid = cap;
-      if (grid < 1) grid = 1;
-      hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * kDmaColWaves), lds, stream, rows, nvec, tail, f,
-                         inv_keep, out_all + lo);
-      BM_LAUNCH_CHECK();
-    }
-    return 0;
-  } else {
-    return BM_EINVAL;
-  }
-}
-
 // One launch: vector body with the widest vector the pointers allow, the d % VEC trailing
 // columns are handled by the last workgroup of the same kernel.
 template <int N, int OP>
@@ -88,12 +53,8 @@ static int launch_colwise_n(const float* const* rows_host, int64_t d, int f, flo
   if (vec > kMaxVec) vec = kMaxVec;
   const int forced = tuning().force_vec;  // experiment knob (BM_FORCE_VEC), 0 = automatic
   if (forced == 1 || (forced == 2 && vec >= 2)) vec = forced;
-  if (vec == 4 && kMaxVec >= 4) {
-    if constexpr ((OP == BM_OP_MEDIAN || OP == BM_OP_TRMEAN) && N <= 28 && N >= 4) {
-      if (tuning().col_dma != 0 && d >= 256 * 1024) return launch_colwise_dma<N, OP>(tab, d, f, out, stream);
-    }
+  if (vec == 4 && kMaxVec >= 4)
     return launch_colwise_vec < N, OP, (kMaxVec >= 4 ? 4 : 1) > (tab, d, f, out, stream);
-  }
   if (vec == 2 && kMaxVec >= 2)
     return launch_colwise_vec < N, OP, (kMaxVec >= 2 ? 2 : 1) > (tab, d, f, out, stream);
   return launch_colwise_vec<N, OP, 1>(tab, d, f, out, stream);

@@ -124,72 +124,9 @@ __global__ __launch_bounds__(kColBlock) void colwise_kernel(RowTable rows, int64
   }
 }
 
-// ---------------------------------------------------------------------------
-// LDS-DMA variant of the median / trimmed-mean kernel (16-byte aligned rows, VEC = 4).
-//
-// The plain kernel above streams HBM -> VGPR with global_load_dwordx4 and tops out at the
-// ~10 B/clk/CU of that return path (5.97 TB/s measured).  Here every wave owns a private
-// [N][1 KiB] LDS slot: the N row segments of its next 256 columns are fetched by the LDS-DMA
-// engine (global_load_lds_dwordx4, 12-13 B/clk/CU on gfx950), read back with N conflict-free
-// ds_read_b128, and the DMA of the following chunk is issued as soon as those reads have
-// returned — i.e. it is in flight during the whole sorting network.  No workgroup barrier: a
-// slot is private to its wave (s_waitcnt vmcnt/lgkmcnt only).
-// ---------------------------------------------------------------------------
-constexpr int kDmaColWaves = 2;  // waves per workgroup (LDS: N KiB per wave)
-
-template <int N, int OP>
-__global__ __launch_bounds__(64 * kDmaColWaves) void colwise_dma_kernel(RowTable rows, int64_t nvec,
-                                                                        int tail, int f,
-                                                                        float inv_keep,
-                                                                        float* __restrict__ out) {
-  static_assert(OP == BM_OP_MEDIAN || OP == BM_OP_TRMEAN, "DMA variant: rules without LDS scratch");
-  extern __shared__ __attribute__((aligned(16))) char dma_smem[];
-  typedef float f32x4 __attribute__((ext_vector_type(4)));
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  char* slot = dma_smem + wave * (N * 1024);
-  const uint32_t lane_off = (uint32_t)lane * 16u;
-  const uint32_t nchunks = (uint32_t)((nvec + 63) / 64);  // 256 columns (1 KiB per row) each
-  const uint32_t nwaves = gridDim.x * kDmaColWaves;
-  const uint32_t nv = (uint32_t)nvec;
-
-  auto issue = [&](uint32_t chunk) {
-    if (chunk * 64u + (uint32_t)lane < nv) {  // lanes past the end fetch nothing (stale LDS, never stored)
-      const uint32_t off = chunk * 1024u + lane_off;
-#pragma unroll
-      for (int i = 0; i < N; ++i)
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(rows.p[i]) + off),
-            (__attribute__((address_space(3))) void*)(slot + i * 1024), 16, 0, 0);
-    }
-  };
-
-  uint32_t chunk = blockIdx.x * kDmaColWaves + wave;
-  if (chunk < nchunks) issue(chunk);
-  for (; chunk < nchunks; chunk += nwaves) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's N pieces have landed
-    float x[4][N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-      const f32x4 v = *reinterpret_cast<const f32x4*>(slot + i * 1024 + lane_off);
-#pragma unroll
-      for (int c = 0; c < 4; ++c) x[c][i] = v[c];
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // values are in VGPRs: the slot is free
-    if (chunk + nwaves < nchunks) issue(chunk + nwaves);  // in flight during the network below
-    float r[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) r[c] = column_rule<N, OP>(x[c], f, inv_keep, nullptr);
-    const uint32_t col = chunk * 64u + (uint32_t)lane;
-    if (col < nv) store_stream_off<4>(out, col * 16u, r);
-  }
-  // the d % 4 trailing columns: one lane each, in the last workgroup
-  if (blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < tail) {
-    const int64_t j = nvec * 4 + threadIdx.x;
-    float x[N];
-#pragma unroll
-    for (int i = 0; i < N; ++i) x[i] = rows.p[i][j];
-    out[j] = column_rule<N, OP>(x, f, inv_keep, nullptr);
-  }
-}
+// Measured alternative, not kept: an LDS-DMA variant (per-wave private [N][1 KiB] LDS slot filled by
+// global_load_lds_dwordx4, read back with ds_read_b128, next chunk's DMA in flight during the
+// network, no barrier) ran at 229 / 244 us against 194 / 195 us for this kernel at n = 25,
+// d = 11.2 M: LDS capacity limits it to 6 waves per CU and the sorting network no longer overlaps.
 
 }  // namespace bm

@@ -63,7 +63,7 @@ template <int KMAX, int VEC>
 __global__ __launch_bounds__(kRedBlock) void stack_stats_kernel(RowTable rows, int k, int64_t nvec,
                                                                 float* __restrict__ avg_out,
                                                                 float* __restrict__ scaled_out,
-                                                                float scale,
+                                                                float scale, int attack_kind,
                                                                 double* __restrict__ partial) {
   __shared__ double red[kRedBlock / 64];
   const float fk = (float)k;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(kRedBlock) void stack_stats_kernel(RowTable rows, i
 #pragma unroll
     for (int i = 0; i < KMAX; ++i)
       if (i < k) load_stream<VEC>(rows.p[i] + v * VEC, x[i]);
-    float avg[VEC];
+    float avg[VEC], colq[VEC];
 #pragma unroll
     for (int c = 0; c < VEC; ++c) {
       float s = x[0][c];  // grad_avg = samples[0].clone(); add_(...)  (tools/pytorch.py:108-110)
@@ -96,14 +96,17 @@ __global__ __launch_bounds__(kRedBlock) void stack_stats_kernel(RowTable rows, i
           q = __builtin_fmaf(df, df, q);
         }
       dev2 += q;
+      colq[c] = q;
     }
     if (avg_out != nullptr) store_stream<VEC>(avg_out + v * VEC, avg);
     if (scaled_out != nullptr) {
       float sc[VEC];
 #pragma unroll
       for (int c = 0; c < VEC; ++c) {
-        const float att = (-avg[c]) * scale;  // grad_att = grad_avg.neg(); grad_att.mul_(factor)
-        sc[c] = avg[c] + att;                 // byz_grad = grad_avg.add_(grad_att)
+        // empire: grad_att = grad_avg.neg();            little: grad_att = grad_stck.var(dim=0).sqrt_()
+        const float dir = (attack_kind == BM_ATTACK_LITTLE) ? __builtin_sqrtf(colq[c] / (fk - 1.0f)) : -avg[c];
+        const float att = dir * scale;  // grad_att.mul_(factor)
+        sc[c] = avg[c] + att;           // byz_grad = grad_avg.add_(grad_att)
       }
       store_stream<VEC>(scaled_out + v * VEC, sc);
     }
@@ -165,23 +168,23 @@ __global__ void stats_finish_kernel(const double* __restrict__ partial, int npar
 
 template <int KMAX, int VEC>
 static int launch_stack_stats(const RowTable& tab, int k, int64_t nvec, float* avg, float* scaled,
-                              float scale, double* partial, int grid, hipStream_t s) {
+                              float scale, int kind, double* partial, int grid, hipStream_t s) {
   hipLaunchKernelGGL((stack_stats_kernel<KMAX, VEC>), dim3(grid), dim3(kRedBlock), 0, s, tab, k, nvec,
-                     avg, scaled, scale, partial);
+                     avg, scaled, scale, kind, partial);
   BM_LAUNCH_CHECK();
   return 0;
 }
 
 template <int VEC>
 static int dispatch_stack_stats(const RowTable& tab, int k, int64_t nvec, float* avg, float* scaled,
-                                float scale, double* partial, int grid, hipStream_t s) {
-  if (k <= 8) return launch_stack_stats<8, VEC>(tab, k, nvec, avg, scaled, scale, partial, grid, s);
-  if (k <= 16) return launch_stack_stats<16, VEC>(tab, k, nvec, avg, scaled, scale, partial, grid, s);
-  if (k <= 24) return launch_stack_stats<24, VEC>(tab, k, nvec, avg, scaled, scale, partial, grid, s);
+                                float scale, int kind, double* partial, int grid, hipStream_t s) {
+  if (k <= 8) return launch_stack_stats<8, VEC>(tab, k, nvec, avg, scaled, scale, kind, partial, grid, s);
+  if (k <= 16) return launch_stack_stats<16, VEC>(tab, k, nvec, avg, scaled, scale, kind, partial, grid, s);
+  if (k <= 24) return launch_stack_stats<24, VEC>(tab, k, nvec, avg, scaled, scale, kind, partial, grid, s);
   if (k <= 32)
     return launch_stack_stats<32, (VEC > 2 ? 2 : VEC)>(tab, k, nvec * (VEC > 2 ? VEC / 2 : 1), avg, scaled,
-                                                        scale, partial, grid, s);
-  return launch_stack_stats<64, 1>(tab, k, nvec * VEC, avg, scaled, scale, partial, grid, s);
+                                                        scale, kind, partial, grid, s);
+  return launch_stack_stats<64, 1>(tab, k, nvec * VEC, avg, scaled, scale, kind, partial, grid, s);
 }
 
 // ---------------------------------------------------------------------------
@@ -354,9 +357,11 @@ extern "C" int bm_selected_mean(const float* const* rows, int n, const int32_t* 
 }
 
 extern "C" int bm_stack_stats(const float* const* rows, int k, int64_t d, float* avg_out,
-                              float* scaled_out, float scale, double* out3, void* ws, void* stream) {
+                              float* scaled_out, float scale, int attack_kind, double* out3, void* ws,
+                              void* stream) {
   using namespace bm;
-  if (rows == nullptr || out3 == nullptr || ws == nullptr || k < 1 || k > BM_MAX_ROWS || d < 1)
+  if (rows == nullptr || out3 == nullptr || ws == nullptr || k < 1 || k > BM_MAX_ROWS || d < 1 ||
+      (attack_kind != BM_ATTACK_EMPIRE && attack_kind != BM_ATTACK_LITTLE))
     return BM_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   RowTable tab{};
@@ -371,8 +376,9 @@ extern "C" int bm_stack_stats(const float* const* rows, int k, int64_t d, float*
     const int64_t nvec = d / vec;
     if (nvec > 0) {
       const int grid = stream_grid(nvec, kRedBlock, kMaxPartialBlocks - 1);
-      rc = (vec == 4) ? dispatch_stack_stats<4>(tab, k, nvec, avg_out, scaled_out, scale, partial, grid, s)
-                      : dispatch_stack_stats<2>(tab, k, nvec, avg_out, scaled_out, scale, partial, grid, s);
+      rc = (vec == 4)
+               ? dispatch_stack_stats<4>(tab, k, nvec, avg_out, scaled_out, scale, attack_kind, partial, grid, s)
+               : dispatch_stack_stats<2>(tab, k, nvec, avg_out, scaled_out, scale, attack_kind, partial, grid, s);
       if (rc != 0) return rc;
       nparts = grid;
       body = nvec * vec;
@@ -384,7 +390,7 @@ extern "C" int bm_stack_stats(const float* const* rows, int k, int64_t d, float*
     const int64_t rest = d - body;
     const int grid = (body == 0) ? stream_grid(rest, kRedBlock, kMaxPartialBlocks) : 1;
     rc = dispatch_stack_stats<1>(tail, k, rest, avg_out ? avg_out + body : nullptr,
-                                 scaled_out ? scaled_out + body : nullptr, scale,
+                                 scaled_out ? scaled_out + body : nullptr, scale, attack_kind,
                                  partial + (int64_t)nparts * 3, grid, s);
     if (rc != 0) return rc;
     nparts += grid;

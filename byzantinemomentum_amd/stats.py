@@ -19,11 +19,12 @@ __all__ = ["compute_avg_dev_max", "stack_stats_async", "study_dots", "multi_axpb
 _ptr = gars._ptr
 
 
-def stack_stats_async(samples, scale=None):
+def stack_stats_async(samples, scale=None, attack="empire"):
   """avg vector + device tensor [sum avg^2, sum_i ||s_i-avg||^2, max|avg|] (fp64), no sync.
 
-  With `scale`, also returns avg + scale*(-avg) computed in the same pass (third element of the
-  tuple): the "empire" Byzantine vector with factor = scale (attacks/identical.py:63-86,129-134).
+  With `scale`, also returns the Byzantine vector of an "identical" attack computed in the same pass
+  (third element of the tuple): attack="empire" -> avg + scale*(-avg); attack="little" ->
+  avg + scale*sqrt(unbiased column variance) (attacks/identical.py:63-86,129-141).
   """
   k, d, device = gars._validate(samples)
   lib = _lib.load()
@@ -34,8 +35,9 @@ def stack_stats_async(samples, scale=None):
   with torch.cuda.device(device):
     _lib.check(lib.bm_stack_stats(_lib.pointer_table(samples), k, d, _ptr(avg),
                                   _ptr(scaled) if scaled is not None else None,
-                                  ctypes.c_float(scale if scale is not None else 0.0), _ptr(out3), _ptr(ws),
-                                  gars._stream(device)), "bm_stack_stats")
+                                  ctypes.c_float(scale if scale is not None else 0.0),
+                                  _lib.ATTACK_LITTLE if attack == "little" else _lib.ATTACK_EMPIRE, _ptr(out3),
+                                  _ptr(ws), gars._stream(device)), "bm_stack_stats")
   if scale is not None:
     return avg, out3, scaled
   return avg, out3

@@ -2,7 +2,7 @@
 
 Given the sampled honest gradients of a step it performs, without leaving the GPU:
   1. worker-side momentum        buf_i <- mu*buf_i + (1-damp)*g_i            attack.py:800-804
-  2. the "empire" attack          byz = avg_h + factor*(-avg_h), repeated f    attacks/identical.py:63-86
+  2. the "empire" / "little" attack  byz = avg_h + factor*dir, repeated f      attacks/identical.py:63-86,129-141
      fused with the honest-stack statistics (one pass over the honest stack)  attack.py:847
   3. the aggregation rule         defense = GAR(honests + [byz]*f, f)          attack.py:821
   4. the study statistics         sampled / attack stacks, defense norm and max, six cosines,
@@ -28,7 +28,7 @@ _RULES = {"krum": gars.krum, "bulyan": gars.bulyan, "median": gars.median, "trme
 
 class AggregationStep:
   def __init__(self, nb_workers, nb_decl_byz, nb_real_byz, gar="krum", gar_args=None, momentum=0.99,
-               dampening=0.99, attack_factor=1.1, nb_past=25):
+               dampening=0.99, attack="empire", attack_factor=1.1, nb_past=25):
     if gar not in _RULES:
       raise ValueError(f"unknown aggregation rule {gar!r}")
     self.n = nb_workers
@@ -39,6 +39,9 @@ class AggregationStep:
     self.gar_args = dict(gar_args or {})
     self.mu = momentum
     self.damp = dampening
+    if attack not in ("empire", "little"):
+      raise ValueError(f"unknown attack {attack!r} (empire: factor, little: factor, use a negative one for negative:True)")
+    self.attack = attack
     self.factor = attack_factor
     self.buffers = None                      # storage["momentum"]: one per honest worker (attack.py:676)
     self.pasts = collections.deque(maxlen=nb_past)  # (sampled average, its squared norm tensor)
@@ -56,7 +59,7 @@ class AggregationStep:
     stats.multi_axpby(self.buffers, sampled[:h], self.mu, 1.0 - self.damp)
     honests = self.buffers
     # 2. honest-stack statistics + empire vector in one pass
-    h_avg, h_out3, byz = stats.stack_stats_async(honests, scale=self.factor)
+    h_avg, h_out3, byz = stats.stack_stats_async(honests, scale=self.factor, attack=self.attack)
     attacks = [byz] * self.f_real
     # 3. aggregation
     if self.rule in (gars.median, gars.average):

@@ -105,9 +105,15 @@ int bm_aksel_pass1(const float* const* rows, int n, int64_t d, float* median_out
  * reference's `grad_att = grad_avg.neg(); grad_att.mul_(factor); byz = grad_avg.add_(grad_att)`:
  * the Byzantine vector of the "empire" attack with factor = scale (attacks/identical.py:63-86,
  * 129-134) comes for free with the honest-stack statistics the study block needs anyway
- * (attack.py:847). */
+ * (attack.py:847).
+ * attack_kind selects what scaled_out holds:
+ *   BM_ATTACK_EMPIRE  avg + scale * (-avg)                         attacks/identical.py:129-134
+ *   BM_ATTACK_LITTLE  avg + scale * sqrt(var_unbiased over rows)   attacks/identical.py:136-141
+ *                     (pass a negative scale for the reference's `negative:True`) */
+enum bm_attack_kind { BM_ATTACK_EMPIRE = 0, BM_ATTACK_LITTLE = 1 };
 int bm_stack_stats(const float* const* rows, int k, int64_t d, float* avg_out,
-                   float* scaled_out, float scale, double* out3, void* ws, void* stream);
+                   float* scaled_out, float scale, int attack_kind, double* out3, void* ws,
+                   void* stream);
 
 /* The dot products of the study block (attack.py:851-868) in one pass:
  *   out[a*nc+b]   = <core[a], core[b]>   for the nc (<= 4) "core" vectors (symmetric, the

@@ -451,9 +451,8 @@ def test_influence_hooks_match_reference_semantics(bm):
 
 
 @pytest.mark.parametrize("n,f,d", [(25, 5, 300003), (7, 1, 262145), (28, 6, 270000), (4, 1, 1048577)])
-def test_large_columns_nan_inf_and_lds_dma_variant(bm, n, f, d):
-  """Long columns with NaN / inf sprinkled in, ragged last chunk and d % 4 tail.  Run once with the
-  default kernel; `BM_COL_DMA=1 pytest -k lds_dma` exercises the LDS-DMA variant on the same data."""
+def test_long_columns_with_nan_and_inf(bm, n, f, d):
+  """Long columns with NaN / inf sprinkled in and a d % 4 tail (several grid-stride trips per lane)."""
   gen = torch.Generator().manual_seed(n * 1000 + f)
   rows = [torch.randn(d, generator=gen) for _ in range(n)]
   rows[0][::1001] = math.nan
@@ -465,3 +464,43 @@ def test_large_columns_nan_inf_and_lds_dma_variant(bm, n, f, d):
   fin = torch.isfinite(want)
   assert bool(((got[fin] - want[fin]).abs() <= 1e-6 * 5).all())
   assert bool((got[~fin & ~torch.isnan(want)] == want[~fin & ~torch.isnan(want)]).all())
+
+
+def test_fused_attack_vectors(bm):
+  """Byzantine vectors produced in the honest-stack statistics pass (attacks/identical.py:63-86)."""
+  rows, h = O.make_stack("iid", 20, 0, 40003, seed=5)
+  dev = [r.to(DEV) for r in rows]
+  stck = torch.stack(rows)
+  avg = stck.mean(dim=0)
+  _, _, emp = bm.stats.stack_stats_async(dev, scale=1.1, attack="empire")
+  want = avg + 1.1 * avg.neg()
+  assert close(emp, want, 2e-6, float(avg.abs().max()))
+  _, _, lit = bm.stats.stack_stats_async(dev, scale=-1.5, attack="little")
+  want = avg + (-1.5) * stck.var(dim=0).sqrt_()
+  assert close(lit, want, 2e-6, float(want.abs().max()))
+
+
+def test_direct_difference_pairwise_mode():
+  """BM_PAIR_MODE=1 (the VALU direct-difference kernel) is read once per process: run it in a
+  subprocess and compare squared distances with float64, including ties of aliased rows."""
+  import os
+  import subprocess
+  import sys
+  code = (
+    "import torch, math\n"
+    "import byzantinemomentum_amd as bm\n"
+    "from oracle import gar_oracle as O\n"
+    "for n, f, d in ((13, 3, 4099), (51, 12, 20001)):\n"
+    "  rows, h = O.make_stack('hetero', n, f, d, seed=4)\n"
+    "  seen = {}\n"
+    "  dev = [seen.setdefault(id(g), g.to('cuda:0')) for g in rows]\n"
+    "  sq = bm.gars.pairwise_sqdist(dev).cpu()\n"
+    "  want = torch.from_numpy(O.pairwise_distances(rows, 'f64')) ** 2\n"
+    "  assert ((sq - want).abs() <= 1e-6 * want.max()).all()\n"
+    "  assert torch.equal(sq, sq.T) and sq[h, h + 1].item() == 0.0 and torch.equal(sq[h, :h], sq[n - 1, :h])\n"
+    "  assert bm.gars.krum_selection(dev, f) == O.krum_order(rows, f, 'f64')[0][:n - f - 2]\n"
+    "print('direct ok')\n")
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = dict(os.environ, BM_PAIR_MODE="1", PYTHONPATH=root)
+  out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root)
+  assert out.returncode == 0 and "direct ok" in out.stdout, out.stderr[-2000:]
