@@ -29,17 +29,29 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(RowTable rows,
   constexpr int THETA = N - 2 * F - 2;
   constexpr int BETA = THETA - 2 * F;
   static_assert(BETA >= 1, "bulyan needs n >= 4f+3");
-  __shared__ const float* ranked[MMAX];
-  if (threadIdx.x < MMAX) ranked[threadIdx.x] = rows.p[order[threadIdx.x]];
+  __shared__ const float* ranked_lds[MMAX];
+  if (threadIdx.x < MMAX) ranked_lds[threadIdx.x] = rows.p[order[threadIdx.x]];
   __syncthreads();
+  // the m_max ranked row pointers move to SGPRs (wave-uniform): loads then use the saddr form with
+  // one 32-bit byte offset per lane, like the column kernels
+  const float* ranked[MMAX];
+#pragma unroll
+  for (int t = 0; t < MMAX; ++t) {
+    const uint64_t p = reinterpret_cast<uint64_t>(ranked_lds[t]);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    ranked[t] = reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
+  }
   const float kNaN = __builtin_nanf("");
-  const int64_t stride = (int64_t)gridDim.x * kBulBlock;
-  for (int64_t v = (int64_t)blockIdx.x * kBulBlock + threadIdx.x; v < nvec; v += stride) {
+  const uint32_t nv = (uint32_t)nvec;  // nvec * VEC * 4 < 2^32: the host splits longer gradients
+  const uint32_t stride = gridDim.x * kBulBlock;
+  for (uint32_t v = blockIdx.x * kBulBlock + threadIdx.x; v < nv; v += stride) {
+    const uint32_t off = v * (uint32_t)(VEC * sizeof(float));
     float x[VEC][MMAX];
 #pragma unroll
     for (int t = 0; t < MMAX; ++t) {
       float tmp[VEC];
-      load_stream<VEC>(ranked[t] + v * VEC, tmp);
+      load_stream_off<VEC>(ranked[t], off, tmp);
 #pragma unroll
       for (int c = 0; c < VEC; ++c) x[c][t] = tmp[c];
     }
@@ -74,7 +86,7 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(RowTable rows,
       const float res = div_small_int(w, (float)BETA, 1.0f / (float)BETA);
       r[c] = has_nan ? kNaN : res;
     }
-    store_stream<VEC>(out + v * VEC, r);
+    store_stream_off<VEC>(out, off, r);
   }
 }
 
@@ -129,40 +141,45 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_generic_kernel(
 }
 
 template <int N, int F>
-static int launch_bulyan_fast(const float* const* rows_host, const int32_t* order, int64_t d,
-                              float* out, hipStream_t s) {
-  RowTable tab{};
-  for (int i = 0; i < N; ++i) tab.p[i] = rows_host[i];
-  int vec = common_vec_width(reinterpret_cast<const void* const*>(rows_host), N, out);
+static int launch_bulyan_fast(const float* const* rows_host, const int32_t* order, int64_t d_all,
+                              float* out_all, hipStream_t s) {
   constexpr int MMAX = N - F - 2;
   constexpr int kMaxVec = (MMAX <= 20) ? 4 : (MMAX <= 44 ? 2 : 1);
+  int vec = common_vec_width(reinterpret_cast<const void* const*>(rows_host), N, out_all);
   if (vec > kMaxVec) vec = kMaxVec;
   const int forced = tuning().force_vec;
   if (forced == 1 || (forced == 2 && vec >= 2)) vec = forced;
-  int64_t body = 0;
-  if (vec == 4 && kMaxVec >= 4 && d / 4 > 0) {
-    const int64_t nvec = d / 4;
-    hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 4 ? 4 : 1)>),
-                       dim3(stream_grid(nvec, kBulBlock, tuning().col_max_blocks)), dim3(kBulBlock), 0,
-                       s, tab, order, nvec, out);
-    BM_LAUNCH_CHECK();
-    body = nvec * 4;
-  } else if (vec == 2 && kMaxVec >= 2 && d / 2 > 0) {
-    const int64_t nvec = d / 2;
-    hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 2 ? 2 : 1)>),
-                       dim3(stream_grid(nvec, kBulBlock, tuning().col_max_blocks)), dim3(kBulBlock), 0,
-                       s, tab, order, nvec, out);
-    BM_LAUNCH_CHECK();
-    body = nvec * 2;
-  }
-  if (body < d) {
-    RowTable tail{};
-    for (int i = 0; i < N; ++i) tail.p[i] = rows_host[i] + body;
-    const int64_t rest = d - body;
-    hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, 1>),
-                       dim3(stream_grid(rest, kBulBlock, tuning().col_max_blocks)), dim3(kBulBlock), 0,
-                       s, tail, order, rest, out + body);
-    BM_LAUNCH_CHECK();
+  // pieces of at most 2^29 columns so that byte offsets fit 32 bits inside the kernel
+  for (int64_t lo = 0; lo < d_all; lo += kMaxColsPerLaunch) {
+    const int64_t d = (d_all - lo < kMaxColsPerLaunch) ? (d_all - lo) : kMaxColsPerLaunch;
+    RowTable tab{};
+    for (int i = 0; i < N; ++i) tab.p[i] = rows_host[i] + lo;
+    float* out = out_all + lo;
+    int64_t body = 0;
+    if (vec == 4 && kMaxVec >= 4 && d / 4 > 0) {
+      const int64_t nvec = d / 4;
+      hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 4 ? 4 : 1)>),
+                         dim3(stream_grid(nvec, kBulBlock, tuning().col_max_blocks)), dim3(kBulBlock), 0,
+                         s, tab, order, nvec, out);
+      BM_LAUNCH_CHECK();
+      body = nvec * 4;
+    } else if (vec == 2 && kMaxVec >= 2 && d / 2 > 0) {
+      const int64_t nvec = d / 2;
+      hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 2 ? 2 : 1)>),
+                         dim3(stream_grid(nvec, kBulBlock, tuning().col_max_blocks)), dim3(kBulBlock), 0,
+                         s, tab, order, nvec, out);
+      BM_LAUNCH_CHECK();
+      body = nvec * 2;
+    }
+    if (body < d) {
+      RowTable tail{};
+      for (int i = 0; i < N; ++i) tail.p[i] = tab.p[i] + body;
+      const int64_t rest = d - body;
+      hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, 1>),
+                         dim3(stream_grid(rest, kBulBlock, tuning().col_max_blocks)), dim3(kBulBlock), 0,
+                         s, tail, order, rest, out + body);
+      BM_LAUNCH_CHECK();
+    }
   }
   return 0;
 }
