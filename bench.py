@@ -269,7 +269,7 @@ def main():
       except Exception:  # noqa: BLE001
         traffic = None
     line = {
-      "metric": "aggregations_per_sec (robust gradient aggregation, n workers x d dims)",
+      "metric": "aggregations/sec (Byzantine-robust GAR over n workers x d dims; achieved HBM GB/s per GAR in roofline/per_gar)",
       "value": aggs_per_step * args.steps * world / elapsed,
       "unit": "agg/s",
       "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

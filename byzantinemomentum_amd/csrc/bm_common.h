@@ -13,24 +13,6 @@ namespace bm {
 // trmean.py:79) — the n x d copy is never made.
 struct RowTable {
   const float* p[BM_MAX_ROWS];
-  // Row pointer for a run-time row index.  The table lives in the kernarg segment; a divergent
-  // index would make the compiler spill the whole table to scratch, so the lookup is done per
-  // wave-uniform value (one s_load per distinct index in the wave, usually 1-2).
-  __device__ __forceinline__ const float* p_dyn(int r) const {
-    const float* res = nullptr;
-    bool done = false;
-    while (!done) {
-      const int ur = __builtin_amdgcn_readfirstlane(r);
-      if (r == ur) {
-        res = p[ur];
-        done = true;
-      }
-    }
-    return res;
-  }
-};
-struct MutRowTable {
-  float* p[BM_MAX_ROWS];
 };
 
 static inline int hip_code(hipError_t e) { return e == hipSuccess ? 0 : -(int)e; }

@@ -69,10 +69,6 @@ static int dispatch_n(std::integer_sequence<int, Ns...>, const float* const* row
   return rc;
 }
 
-#ifndef BM_COLWISE_OPS
-#define BM_COLWISE_OPS 0xF
-#endif
-
 }  // namespace bm
 
 extern "C" int bm_colwise(int op, const float* const* rows, int n, int64_t d, int f, float* out,
