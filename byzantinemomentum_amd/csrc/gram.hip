@@ -334,14 +334,30 @@ static GramGeom gram_geometry(int n) {
 template <int RB>
 static int launch_gram(const RowTable& tab, const GramGeom& g, int64_t d, bool aligned, double* partial,
                        int blocks, hipStream_t s) {
-  if ((g.nb + kGramWaves - 1) / kGramWaves > 8) return BM_EINVAL;  // kMaxDma pieces per wave and tile
-  const int nbuf = tuning().pair_nbuf == 3 ? 3 : 2;
-  const int waves = (tuning().pair_ablate == 8 && g.width / 16 >= 8) ? 8 : kGramWaves;  // experiment knob
+  // Ring depth and workgroup width.  Deep ring (BM_PAIR_NBUF = 4 or 5 with 8-wave workgroups): the
+  // LDS-DMA of tile t+NBUF-1 is issued while tile t is contracted, so several tiles (tens of KB per
+  // CU) stay in flight — everything in flight through the DMA engine needs LDS behind it.
+  int nbuf = tuning().pair_nbuf;
+  if (nbuf < 2 || nbuf > 5) nbuf = 2;
+  const bool wide = (nbuf >= 4 || tuning().pair_ablate == 8) && g.width / 16 >= 8;
+  if (nbuf >= 4 && !wide) nbuf = 3;
+  const int waves = wide ? 8 : kGramWaves;
+  if ((g.nb + waves - 1) / waves > 8) return BM_EINVAL;  // kMaxDma pieces per wave and tile
   const size_t lds = BM_MAX_ROWS * sizeof(float*) + waves * 256 * sizeof(double) +
                      (size_t)nbuf * (g.nb + 1) * kGramDmaPitch;
-  auto kern = !aligned ? gram_partial_kernel<RB, 2, false>
-                       : (waves == 8 ? gram_partial_kernel<RB, 2, true, 8>
-                                     : (nbuf == 2 ? gram_partial_kernel<RB, 2, true> : gram_partial_kernel<RB, 3, true>));
+  if (lds > 160 * 1024) return BM_EINVAL;
+  void (*kern)(RowTable, GramGeom, int64_t, double*);
+  if (!aligned) {
+    kern = gram_partial_kernel<RB, 2, false>;
+    nbuf = 2;
+  } else if (wide) {
+    kern = nbuf == 5 ? gram_partial_kernel<RB, 5, true, 8>
+                     : (nbuf == 4 ? gram_partial_kernel<RB, 4, true, 8>
+                                  : (nbuf == 3 ? gram_partial_kernel<RB, 3, true, 8>
+                                               : gram_partial_kernel<RB, 2, true, 8>));
+  } else {
+    kern = nbuf == 3 ? gram_partial_kernel<RB, 3, true> : gram_partial_kernel<RB, 2, true>;
+  }
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
