@@ -504,3 +504,23 @@ def test_direct_difference_pairwise_mode():
   env = dict(os.environ, BM_PAIR_MODE="1", PYTHONPATH=root)
   out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=root)
   assert out.returncode == 0 and "direct ok" in out.stdout, out.stderr[-2000:]
+
+
+@pytest.mark.parametrize("n,f", [(64, 15), (63, 15), (64, 1), (48, 11), (49, 11), (33, 7), (17, 3), (16, 3)])
+def test_largest_row_counts_distance_rules(bm, n, f):
+  """Upper end of the supported worker counts (BM_MAX_ROWS = 64) and the 16-row block boundaries of
+  the Gram kernel: Krum, Bulyan (generic LDS kernel with > 64 KB of dynamic LDS at n = 64) and Aksel."""
+  d = 6007
+  rows, h = O.make_stack("hetero", n, f, d, seed=n * 31 + f)
+  dev = to_dev(rows)
+  m = n - f - 2
+  assert bm.gars.krum_selection(dev, f) == O.krum_order(rows, f, "f64")[0][:m]
+  assert torch.equal(bm.krum(dev, f).cpu(), O.krum(rows, f))
+  sq = bm.gars.pairwise_sqdist(dev).cpu()
+  want = torch.from_numpy(O.pairwise_distances(rows, "f64")) ** 2
+  assert close(sq, want, 1e-6, float(want.max()) * 1e-3)
+  if n >= 4 * f + 3:
+    assert bm.gars.bulyan_ranking(dev, f) == O.bulyan_order(rows, f, None, "f64")[0]
+    scale = float(torch.stack(rows[:h]).abs().max())
+    assert close(bm.bulyan(dev, f), O.bulyan(rows, f), 2e-6, scale)
+  assert bm.gars.aksel_selection(dev, f) == O.aksel_order(rows, "f64")[0][:(n + 1) // 2]
