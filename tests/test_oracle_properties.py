@@ -1,0 +1,49 @@
+"""Property checks of the oracle's two formulations on random small inputs (CPU only): the window
+formulation the kernels implement must agree with the reference's topk formulation wherever the
+choice is not ambiguous, including stacks with duplicated (aliased) rows and infinities."""
+
+import math
+
+import pytest
+import torch
+
+from oracle import gar_oracle as O
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_closest_window_vs_topk_random(seed):
+  gen = torch.Generator().manual_seed(seed)
+  n = int(torch.randint(3, 20, (1,), generator=gen))
+  f = int(torch.randint(1, (n - 1) // 2 + 1, (1,), generator=gen))
+  d = 400
+  rows = [torch.randn(d, generator=gen) for _ in range(n - f)]
+  byz = rows[0] * -0.5
+  rows = rows + [byz] * f                       # duplicated values in every column
+  if seed % 3 == 0:
+    rows[1][::17] = math.inf
+  st = torch.stack(rows)
+  for centre in (st.median(dim=0).values, O.trmean(rows, f)):
+    ref = O._closest_like_reference(st, n - f, centre).double()
+    win, amb = O.closest_window(st, n - f, centre)
+    ok = ((win - ref).abs() <= 1e-6 * (1 + ref.abs())) | amb | ~torch.isfinite(ref) | ~torch.isfinite(centre)
+    assert bool(ok.all())
+    assert int(amb.sum()) <= d // 4
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_bulyan_f64_equals_f32_on_separated_stacks(seed):
+  n, f = 4 * (seed % 3 + 1) + 3 + seed % 2, seed % 3 + 1
+  rows, h = O.make_stack("hetero", n, f, 3000, seed=100 + seed)
+  assert O.bulyan_order(rows, f, None, "f32")[0] == O.bulyan_order(rows, f, None, "f64")[0]
+  a, b = O.bulyan(rows, f, None, "f32").double(), O.bulyan(rows, f, None, "f64")
+  assert bool(((a - b).abs() <= 5e-6 * float(torch.stack(rows[:h]).abs().max())).all())
+
+
+def test_krum_scores_are_invariant_to_aliasing_order():
+  """f aliased Byzantine rows: equal scores, stable order by index (krum.py:62)."""
+  rows, h = O.make_stack("hetero", 13, 3, 500, seed=9)
+  order, scores = O.krum_order(rows, 3)
+  byz_scores = {scores[i] for i in range(h, 13)}
+  assert len(byz_scores) == 1
+  pos = [order.index(i) for i in range(h, 13)]
+  assert pos == sorted(pos) and pos[-1] - pos[0] == 2
