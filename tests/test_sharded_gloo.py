@@ -47,7 +47,9 @@ def _worker(rank, world, port, queue):
     res["avg"] = agg.all_gather_output(avg, D)
     res["stats"] = (norm, dev, mx)
     res["sq"] = agg.global_sqdist(local)
-    queue.put((rank, {k: (v.clone() if torch.is_tensor(v) else v) for k, v in res.items()}))
+    # numpy arrays are pickled by value; torch tensors would be shared through file descriptors of
+    # this process, which may already have exited when the parent rebuilds them
+    queue.put((rank, {k: (v.detach().numpy().copy() if torch.is_tensor(v) else v) for k, v in res.items()}))
     dist.barrier()
   finally:
     dist.destroy_process_group()
@@ -63,6 +65,8 @@ def test_two_rank_sharded_aggregation_matches_single_process():
   for p in procs:
     p.start()
   results = dict(queue.get(timeout=240) for _ in range(world))
+  results = {r: {k: (torch.from_numpy(v) if hasattr(v, "dtype") else v) for k, v in res.items()}
+             for r, res in results.items()}
   for p in procs:
     p.join(timeout=60)
     assert p.exitcode == 0
