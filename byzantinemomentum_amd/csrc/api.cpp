@@ -10,10 +10,15 @@ static int env_int(const char* name, int dflt) {
   if (v == nullptr || *v == '\0') return dflt;
   return atoi(v);
 }
+static double env_double(const char* name, double dflt) {
+  const char* v = getenv(name);
+  if (v == nullptr || *v == '\0') return dflt;
+  return atof(v);
+}
 const Tuning& tuning() {
   static const Tuning t = {env_int("BM_FORCE_VEC", 0), env_int("BM_COL_MAX_BLOCKS", 256 * 64),
                            env_int("BM_PAIR_BLOCKS", 0), env_int("BM_PAIR_STRIPS", 0), env_int("BM_PAIR_ABLATE", 0), env_int("BM_PAIR_NBUF", 2),
-                           env_int("BM_PAIR_MODE", 0)};
+                           env_int("BM_PAIR_MODE", 0), env_int("BM_PAIR_CENTRE", 1), env_double("BM_PAIR_TAU", 2e-3)};
   return t;
 }
 }  // namespace bm

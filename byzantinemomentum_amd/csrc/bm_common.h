@@ -208,7 +208,9 @@ struct Tuning {
   int pair_strips;     // BM_PAIR_STRIPS: force a tile shape, strips*100+slots (e.g. 208), 0 = automatic
   int pair_ablate;     // BM_PAIR_ABLATE: 1 = no compute, 2 = no staging (experiments)
   int pair_nbuf;       // BM_PAIR_NBUF: LDS tile buffers of the Gram kernel, 2 (default, measured best) or 3
-  int pair_mode;       // BM_PAIR_MODE: 0 = MFMA Gram contraction (default), 1 = direct differences on the VALU
+  int pair_mode;       // BM_PAIR_MODE: 0 = centred bf16x3 Gram (default), 1 = direct differences, 2 = fp32 Gram
+  int pair_centre;     // BM_PAIR_CENTRE: 1 (default) subtract the per-coordinate row mean in mode 0; 0 = experiments
+  double pair_tau;     // BM_PAIR_TAU: accuracy gate of the Gram modes (see gram_to_sqdist_kernel); <= 0 disables
 };
 const Tuning& tuning();
 }  // namespace bm

@@ -293,30 +293,45 @@ __global__ __launch_bounds__(64 * kGramRedWaves) void gram_reduce_kernel(const d
   gram[e] = tot;
 }
 
-__global__ void gram_to_sqdist_kernel(const double* __restrict__ gram, int n, double* __restrict__ sq) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= n * n) return;
-  const int i = e / n, j = e - i * n;
-  if (i == j) {
-    // a row with a non-finite coordinate is at non-finite distance of everything, itself
-    // included in the reference (x - x = nan); keep 0 on the diagonal, it is never read
-    sq[e] = 0.0;
-    return;
+// sq[i][j] = G_ii + G_jj - 2 G_ij in fp64, one workgroup.  Also decides whether the Gram form was
+// accurate enough: its absolute error is ~eps_G * (G_ii + G_jj) (eps_G ~ 1e-8, measured), so a pair
+// whose squared distance is below tau * (G_ii + G_jj) — rows that nearly coincide relative to their
+// (centred) norms — has lost relative accuracy eps_G / tau and raises *flag; the caller then
+// recomputes the matrix with the direct-difference kernel (pairwise.hip), which has no
+// cancellation.  Bitwise-equal rows (G_ii == G_jj == G_ij) are exact (d2 = 0) and never flag.
+constexpr int kSqThreads = 1024;
+__global__ __launch_bounds__(kSqThreads) void gram_to_sqdist_kernel(const double* __restrict__ gram, int n,
+                                                                    double tau, double* __restrict__ sq,
+                                                                    int* __restrict__ flag) {
+  __shared__ int any;
+  if (threadIdx.x == 0) any = 0;
+  __syncthreads();
+  bool bad = false;
+  for (int e = threadIdx.x; e < n * n; e += kSqThreads) {
+    const int i = e / n, j = e - i * n;
+    if (i == j) {
+      // a row with a non-finite coordinate is at non-finite distance of everything, itself
+      // included in the reference (x - x = nan); keep 0 on the diagonal, it is never read
+      sq[e] = 0.0;
+      continue;
+    }
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const double gii = gram[tri_index(lo, lo, n)], gjj = gram[tri_index(hi, hi, n)];
+    const double gij = gram[tri_index(lo, hi, n)];
+    double v = (gii + gjj) - 2.0 * gij;
+    const bool same = (gii == gjj) && (gij == gii);
+    if (!same && v < tau * (gii + gjj)) bad = true;  // NaN compares false: non-finite rows never flag
+    if (v < 0.0) v = 0.0;  // rounding of nearly identical rows; NaN stays NaN
+    sq[e] = v;
   }
-  const int lo = i < j ? i : j, hi = i < j ? j : i;
-  const double gii = gram[tri_index(lo, lo, n)], gjj = gram[tri_index(hi, hi, n)];
-  const double gij = gram[tri_index(lo, hi, n)];
-  double v = (gii + gjj) - 2.0 * gij;
-  if (v < 0.0) v = 0.0;  // rounding of nearly identical rows; NaN stays NaN
-  sq[e] = v;
+  if (bad) any = 1;  // benign race: every writer stores 1
+  __syncthreads();
+  if (threadIdx.x == 0 && flag != nullptr) *flag = any;
 }
 
 constexpr int kGramMaxBlocks = 2048;
 
-int64_t gram_workspace_bytes(int n) {
-  const int64_t per_block = (int64_t)n * (n + 1) / 2;
-  return (kGramMaxBlocks + 1) * per_block * (int64_t)sizeof(double);
-}
+int64_t gram_partial_doubles(int n) { return (int64_t)kGramMaxBlocks * ((int64_t)n * (n + 1) / 2); }
 
 static GramGeom gram_geometry(int n) {
   GramGeom g;
@@ -368,7 +383,20 @@ static int launch_gram(const RowTable& tab, const GramGeom& g, int64_t d, bool a
   return 0;
 }
 
-int gram_sqdist(const float* const* rows, int n, int64_t d, double* sq_nxn, void* ws, hipStream_t s) {
+// Fixed-order sum of the per-workgroup partial Gram matrices, then squared distances + accuracy flag.
+int gram_finish(const double* partial, int blocks, int n, double* gram, double* sq_nxn, int* flag, double tau,
+                hipStream_t s) {
+  const int64_t per_block = (int64_t)n * (n + 1) / 2;
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3((int)((per_block + 63) / 64)), dim3(64 * kGramRedWaves), 0, s,
+                     partial, blocks, n, gram);
+  BM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gram_to_sqdist_kernel, dim3(1), dim3(kSqThreads), 0, s, gram, n, tau, sq_nxn, flag);
+  BM_LAUNCH_CHECK();
+  return 0;
+}
+
+int gram_sqdist(const float* const* rows, int n, int64_t d, double* sq_nxn, double* partial, double* gram,
+                int* flag, double tau, hipStream_t s) {
   RowTable tab{};
   for (int i = 0; i < n; ++i) tab.p[i] = rows[i];
   const bool aligned = common_vec_width(reinterpret_cast<const void* const*>(rows), n, nullptr) == 4;
@@ -377,9 +405,6 @@ int gram_sqdist(const float* const* rows, int n, int64_t d, double* sq_nxn, void
   int blocks = tuning().pair_blocks > 0 ? tuning().pair_blocks : 256 * 4;
   if (blocks > kGramMaxBlocks) blocks = kGramMaxBlocks;
   if (blocks > chunks) blocks = (int)(chunks > 0 ? chunks : 1);
-  double* partial = static_cast<double*>(ws);
-  const int64_t per_block = (int64_t)n * (n + 1) / 2;
-  double* gram = partial + (int64_t)blocks * per_block;
   const int rb = (n + 15) / 16;
   int rc;
   switch (rb) {
@@ -389,12 +414,7 @@ int gram_sqdist(const float* const* rows, int n, int64_t d, double* sq_nxn, void
     default: rc = launch_gram<4>(tab, g, d, aligned, partial, blocks, s); break;
   }
   if (rc != 0) return rc;
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3((int)((per_block + 63) / 64)), dim3(64 * kGramRedWaves), 0, s,
-                     partial, blocks, n, gram);
-  BM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gram_to_sqdist_kernel, dim3((n * n + 255) / 256), dim3(256), 0, s, gram, n, sq_nxn);
-  BM_LAUNCH_CHECK();
-  return 0;
+  return gram_finish(partial, blocks, n, gram, sq_nxn, flag, tau, s);
 }
 
 }  // namespace bm

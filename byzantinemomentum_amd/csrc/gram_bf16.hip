@@ -1,0 +1,339 @@
+// gram_bf16.hip — pairwise squared distances as a CENTRED Gram contraction on the bf16 matrix
+// cores with a three-way split of every fp32 value (default path of bm_pairwise_sqdist).
+//
+// Replaces the per-pair loop `gradients[x].sub(gradients[y]).norm().item()` of
+// aggregators/krum.py:41-48, bulyan.py:48-54, brute.py:43-45.
+//
+// Why this shape (measured history in DESIGN.md §4.2):
+//   * the direct form (pairwise.hip) is VALU-bound, 1.05 ms at n=51 x d=11.2 M;
+//   * the fp32-MFMA Gram (gram.hip) is matrix-pipe bound at n=51 (fp32 MFMA = the fp32 vector
+//     rate: 364 us floor > the 285 us HBM floor) and, staged through LDS-DMA double buffers, keeps
+//     only ~50 KB per CU in flight (4.6 TB/s at n=25);
+//   * here every fp32 value x is split EXACTLY into three bf16 numbers x = h + m + l
+//     (h = rne_bf16(x), m = rne_bf16(x - h), l = x - h - m, which has <= 8 significant bits) and
+//     x_i*x_j is taken as hh + mm + (hm + hl) + (mh + lh) on v_mfma_f32_16x16x32_bf16: 6 MFMAs at
+//     16x the fp32-MFMA rate.  The dropped terms (ml, lm, ll) are <= 2^-25 relative to |x_i x_j|
+//     each with random signs.  The matrix pipe is then ~45 % busy at n=51 and the kernel is
+//     bound by the HBM stream.
+//
+// Data path (gfx950), one WAVE = one independent stream processor (no workgroup barrier in the
+// main loop):
+//   * HBM -> VGPR: global_load_dwordx4, lane (rho = l>>4, x = l&15) reads coordinates 4x..4x+3 of
+//     row 4k+rho for k = 0..K-1 (K = ceil(n/4)): 256 contiguous bytes per row and instruction.  The
+//     bytes in flight live in the VGPR file (512 KB per CU) exactly as in the column kernels —
+//     LDS-DMA needs LDS behind every byte in flight and LDS is what ran out;
+//   * centring: distances are translation invariant, so the per-coordinate mean over the n rows
+//     (sum over k in registers + two cross-lane adds) is subtracted before the split.  G then holds
+//     inner products of DEVIATIONS: the cancellation in G_ii + G_jj - 2 G_ij is bounded by
+//     (|x_i-c|^2 + |x_j-c|^2) / |x_i-x_j|^2 instead of (|x_i|^2+|x_j|^2)/|x_i-x_j|^2, which is what
+//     made the uncentred Gram lose small distances between rows with a large common component
+//     (worker momentum late in training).  What centring cannot fix (far outliers next to a tight
+//     cluster) is detected by gram_to_sqdist_kernel and recomputed by the direct kernel;
+//   * split in registers (5.5 VALU ops per value, every lane busy), three bf16 planes written to a
+//     WAVE-PRIVATE LDS region with ds_write_b64 ([plane][row][64 coords], 128-byte rows, 16-byte
+//     slots XOR-swizzled by (row>>1)&7: writes and fragment reads are bank-conflict free);
+//   * LDS -> MFMA operands: one ds_read_b128 per (plane, 16-row block, 32-coordinate step):
+//     lane (i = l&15, g = l>>4) gets 8 consecutive bf16 of row 16R+i = the A operand of block R
+//     and, for the column block, the B operand;
+//   * per step and block pair three independent accumulators S0 = hh+mm, S1 = hm+hl, S2 = mh+lh
+//     start from zero and are flushed as outer += S0 + (S1 + S2): exchanging the roles of the
+//     two rows exchanges S1 and S2, so G_ij is bitwise symmetric in (i, j), and bitwise-equal rows
+//     produce bitwise-equal G entries: d2 = 0 exactly between aliased Byzantine rows and bitwise
+//     equal distances from them to any third row (the exact score ties of the reference survive,
+//     krum.py:62 stable sort);
+//   * fp32 chains cover 32 coordinates, per-wave fp32 sums ~100 chunks, everything wider is fp64
+//     (workgroup, grid, GPUs) in a fixed order: deterministic, no atomics.
+#include "bm_common.h"
+
+namespace bm {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// row pointers travel through LDS as generic pointers; say "global" again so that the loads are
+// global_load (vmcnt only) and not flat_load (vmcnt + lgkmcnt, which would tie them to the LDS waits)
+typedef const float __attribute__((address_space(1)))* GlobalF;
+typedef f32x4 __attribute__((address_space(1))) GlobalF4;
+
+constexpr int kB3Waves = 4;      // waves per workgroup (they only meet in the final reduction)
+constexpr int kB3Chunk = 64;     // coordinates per wave and chunk: 256 B per row
+constexpr int kB3RowBytes = 128; // one row of one bf16 plane in LDS
+
+__host__ __device__ constexpr int b3_pairs(int rb) { return rb * (rb + 1) / 2; }
+__host__ __device__ inline int b3_tri_index(int i, int j, int n) { return i * n - (i * (i - 1)) / 2 + (j - i); }
+
+// two fp32 -> packed bf16 pair (round to nearest even): v_cvt_pk_bf16_f32
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+  const f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
+__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
+
+// x = h + m + l exactly (h, m, l bf16): the subtractions are exact, the last residual has at most
+// 8 significant bits.
+__device__ __forceinline__ void split3(const f32x4 x, u32x2& h, u32x2& m, u32x2& l) {
+  h.x = pack_bf16(x.x, x.y);
+  h.y = pack_bf16(x.z, x.w);
+  const float r0 = x.x - bf16_lo(h.x), r1 = x.y - bf16_hi(h.x);
+  const float r2 = x.z - bf16_lo(h.y), r3 = x.w - bf16_hi(h.y);
+  m.x = pack_bf16(r0, r1);
+  m.y = pack_bf16(r2, r3);
+  const float s0 = r0 - bf16_lo(m.x), s1 = r1 - bf16_hi(m.x);
+  const float s2 = r2 - bf16_lo(m.y), s3 = r3 - bf16_hi(m.y);
+  l.x = pack_bf16(s0, s1);
+  l.y = pack_bf16(s2, s3);
+}
+
+__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
+                                                 0, 0, 0);
+}
+
+// K = ceil(n/4) load instructions per chunk; RB = ceil(K/4) 16-row blocks.
+template <int K>
+struct B3Shape {
+  static constexpr int RB = (K + 3) / 4;
+  static constexpr int NP = b3_pairs(RB);
+  static constexpr int N4 = 4 * K;                      // LDS rows per plane
+  static constexpr int PS = N4 * kB3RowBytes;           // plane stride
+  static constexpr int WS = 3 * PS;                     // wave region
+  static constexpr int NSETS = (K <= 8) ? 2 : 1;        // register sets of loads in flight
+  static constexpr int MINW = (K <= 8) ? 3 : 2;         // workgroups per CU aimed at
+  static constexpr int kPtrBytes = BM_MAX_ROWS * 8;
+  static constexpr int kRedBytes = kB3Waves * 256 * 8;
+  static constexpr int kLds = kPtrBytes + (kB3Waves * WS > kRedBytes ? kB3Waves * WS : kRedBytes);
+};
+
+template <int K, bool ALIGNED>
+__global__ __launch_bounds__(64 * kB3Waves, B3Shape<K>::MINW) void gram3_partial_kernel(
+    RowTable rows, int n, int64_t d, float inv_n, int centre, double* __restrict__ partial) {
+  using S = B3Shape<K>;
+  constexpr int RB = S::RB, NP = S::NP, NSETS = S::NSETS;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const float** row_ptr = reinterpret_cast<const float**>(smem);
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6, lane = tid & 63;
+  char* wbase = smem + S::kPtrBytes + wave * S::WS;
+
+  // Row pointers: one per-lane load from the kernarg segment (the table is the first kernel
+  // argument, passed by value) instead of a serial fill by one thread.
+  if (tid < BM_MAX_ROWS) {
+    typedef const float* __attribute__((address_space(4))) const* KargTable;
+    KargTable karg = (KargTable)__builtin_amdgcn_kernarg_segment_ptr();
+    row_ptr[tid] = (const float*)karg[tid < n ? tid : 0];
+  }
+  __syncthreads();
+
+  // ---- load side: lane (rho, x) owns coordinates 4x..4x+3 of rows 4k+rho ----
+  const int rho = lane >> 4, x = lane & 15;
+  const bool last_valid = (4 * (K - 1) + rho) < n;  // only the last instruction can hold a padded row
+  // LDS write address of instruction k: row 4k+rho, 16-byte slot (x>>1) ^ ((row>>1)&7), half x&1.
+  // (row>>1)&7 = ((2k)&7) | (rho>>1): the k part is a compile-time XOR on bits 4..6.
+  const int wr_lane = rho * kB3RowBytes + ((((x >> 1) ^ (rho >> 1)) & 7) << 4) + ((x & 1) << 3);
+
+  // ---- MFMA side: lane (i, g) reads row 16R+i, slot (4s+g) ^ ((row>>1)&7) ----
+  const int li = lane & 15, lg = lane >> 4;
+  const int rd0 = li * kB3RowBytes + (((lg ^ (li >> 1)) & 7) << 4);  // step 0; step 1 flips bit 6
+  // last block: rows >= N4 do not exist in LDS, read row 0 instead (their products are discarded)
+  const bool last_ok = (16 * (RB - 1) + li) < S::N4;
+  const int rd_last0 = last_ok ? rd0 + (RB - 1) * 16 * kB3RowBytes : (lg << 4);
+
+  f32x4 outer[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) outer[p] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+
+  const int64_t nchunks = (d + kB3Chunk - 1) / kB3Chunk;
+  const int64_t gw = (int64_t)blockIdx.x * kB3Waves + wave;
+  const int64_t nw = (int64_t)gridDim.x * kB3Waves;
+
+  f32x4 xs[NSETS][K];
+
+  auto issue = [&](int64_t c, f32x4 (&v)[K]) {
+    const int64_t coord = c * kB3Chunk + 4 * x;
+    if (ALIGNED && (c + 1) * kB3Chunk <= d) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        int r = 4 * k + rho;
+        if (k == K - 1) r = r < n ? r : n - 1;
+        v[k] = __builtin_nontemporal_load(reinterpret_cast<const GlobalF4*>((GlobalF)row_ptr[r] + coord));
+      }
+    } else {
+      // ragged last chunk / rows that are not 16-byte aligned: guarded scalar loads, zero fill
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        int r = 4 * k + rho;
+        if (k == K - 1) r = r < n ? r : n - 1;
+        GlobalF src = (GlobalF)row_ptr[r] + coord;
+        const int64_t left = d - coord;
+        f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (left > 0) t.x = src[0];
+        if (left > 1) t.y = src[1];
+        if (left > 2) t.z = src[2];
+        if (left > 3) t.w = src[3];
+        v[k] = t;
+      }
+    }
+  };
+
+  auto contract = [&](f32x4 (&v)[K]) {
+    // -- per-coordinate centre: mean over the n rows (any finite vector would do) --
+    f32x4 c = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (centre) {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        if (k == K - 1) {
+          const f32x4 z = {0.0f, 0.0f, 0.0f, 0.0f};
+          c += last_valid ? v[k] : z;
+        } else {
+          c += v[k];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float s = c[e];
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        s *= inv_n;
+        // a non-finite coordinate in ONE row must not poison the other rows' distances
+        c[e] = (__builtin_fabsf(s) < __builtin_inff()) ? s : 0.0f;
+      }
+    }
+    // -- split and store the three planes --
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      u32x2 h, m, l;
+      split3(v[k] - c, h, m, l);
+      char* dst = wbase + (wr_lane ^ (((2 * k) & 7) << 4)) + k * 4 * kB3RowBytes;
+      *reinterpret_cast<u32x2*>(dst) = h;
+      *reinterpret_cast<u32x2*>(dst + S::PS) = m;
+      *reinterpret_cast<u32x2*>(dst + 2 * S::PS) = l;
+    }
+  };
+
+  auto multiply = [&]() {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      u32x4 fh[RB], fm[RB], fl[RB];
+#pragma unroll
+      for (int R = 0; R < RB; ++R) {
+        const int off = ((R == RB - 1) ? rd_last0 : rd0 + R * 16 * kB3RowBytes) ^ (s << 6);
+        fh[R] = *reinterpret_cast<const u32x4*>(wbase + off);
+        fm[R] = *reinterpret_cast<const u32x4*>(wbase + off + S::PS);
+        fl[R] = *reinterpret_cast<const u32x4*>(wbase + off + 2 * S::PS);
+      }
+      const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+      int p = 0;
+#pragma unroll
+      for (int I = 0; I < RB; ++I)
+#pragma unroll
+        for (int J = I; J < RB; ++J) {
+          f32x4 s0 = mfma_bf16(fh[I], fh[J], zero);
+          f32x4 s1 = mfma_bf16(fh[I], fm[J], zero);
+          f32x4 s2 = mfma_bf16(fm[I], fh[J], zero);
+          s0 = mfma_bf16(fm[I], fm[J], s0);
+          s1 = mfma_bf16(fh[I], fl[J], s1);
+          s2 = mfma_bf16(fl[I], fh[J], s2);
+          outer[p] += s0 + (s1 + s2);
+          ++p;
+        }
+    }
+  };
+
+  // ---- main loop: loads of the next chunk(s) stay in flight under the MFMAs of this one ----
+  int64_t c = gw;
+#pragma unroll
+  for (int b = 0; b < NSETS; ++b)
+    if (c + b * nw < nchunks) issue(c + b * nw, xs[b]);
+  while (c < nchunks) {
+#pragma unroll
+    for (int b = 0; b < NSETS; ++b) {
+      if (c < nchunks) {  // wave-uniform
+        contract(xs[b]);
+        const int64_t nxt = c + NSETS * nw;
+        if (nxt < nchunks) issue(nxt, xs[b]);
+        multiply();
+      }
+      c += nw;
+    }
+  }
+
+  // ---- workgroup reduction, one 16x16 block at a time, fixed order; compact upper triangle ----
+  // C/D layout of the 16x16 MFMA: lane l, register v -> row 4*(l>>4)+v, column l&15.
+  double* red = reinterpret_cast<double*>(smem + S::kPtrBytes);  // [waves][256], aliases the planes
+  const int per_block = n * (n + 1) / 2;
+  __syncthreads();
+  int p = 0;
+#pragma unroll
+  for (int I = 0; I < RB; ++I)
+#pragma unroll
+    for (int J = I; J < RB; ++J) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) red[wave * 256 + (4 * lg + v) * 16 + li] = (double)outer[p][v];
+      __syncthreads();
+      if (tid < 256) {
+        const int rr = tid >> 4, cc = tid & 15;
+        double s = red[tid];
+#pragma unroll
+        for (int w = 1; w < kB3Waves; ++w) s += red[w * 256 + tid];
+        const int gi = 16 * I + rr, gj = 16 * J + cc;
+        if (gi <= gj && gj < n) partial[(int64_t)blockIdx.x * per_block + b3_tri_index(gi, gj, n)] = s;
+      }
+      __syncthreads();
+      ++p;
+    }
+}
+
+template <int K>
+static int launch_gram3(const RowTable& tab, int n, int64_t d, bool aligned, int centre, double* partial,
+                        int blocks, hipStream_t s) {
+  using S = B3Shape<K>;
+  auto kern = aligned ? gram3_partial_kernel<K, true> : gram3_partial_kernel<K, false>;
+  if (S::kLds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, S::kLds);
+    if (e != hipSuccess) return hip_code(e);
+  }
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * kB3Waves), S::kLds, s, tab, n, d, 1.0f / (float)n, centre,
+                     partial);
+  BM_LAUNCH_CHECK();
+  return 0;
+}
+
+constexpr int kB3MaxBlocks = 1024;
+
+int64_t gram3_partial_doubles(int n) { return (int64_t)kB3MaxBlocks * ((int64_t)n * (n + 1) / 2); }
+
+// Partial Gram matrices of the centred rows; returns the number of workgroups (= partial blocks)
+// through *blocks_out.  `partial` holds gram3_partial_doubles(n) doubles.
+int gram3_partials(const float* const* rows, int n, int64_t d, double* partial, int* blocks_out,
+                   hipStream_t s) {
+  RowTable tab{};
+  for (int i = 0; i < n; ++i) tab.p[i] = rows[i];
+  const bool aligned = common_vec_width(reinterpret_cast<const void* const*>(rows), n, nullptr) == 4;
+  const int K = (n + 3) / 4;
+  const int per_cu = (K <= 8) ? 3 : 2;
+  const int64_t chunks = (d + kB3Chunk - 1) / kB3Chunk;
+  int blocks = tuning().pair_blocks > 0 ? tuning().pair_blocks : 256 * per_cu;
+  if (blocks > kB3MaxBlocks) blocks = kB3MaxBlocks;
+  const int64_t need = (chunks + kB3Waves - 1) / kB3Waves;
+  if (blocks > need) blocks = (int)(need > 0 ? need : 1);
+  const int centre = tuning().pair_centre;
+  int rc;
+  switch (K) {
+#define BM_B3_CASE(KK) \
+  case KK: rc = launch_gram3<KK>(tab, n, d, aligned, centre, partial, blocks, s); break;
+    BM_B3_CASE(1) BM_B3_CASE(2) BM_B3_CASE(3) BM_B3_CASE(4) BM_B3_CASE(5) BM_B3_CASE(6) BM_B3_CASE(7)
+    BM_B3_CASE(8) BM_B3_CASE(9) BM_B3_CASE(10) BM_B3_CASE(11) BM_B3_CASE(12) BM_B3_CASE(13) BM_B3_CASE(14)
+    BM_B3_CASE(15) BM_B3_CASE(16)
+#undef BM_B3_CASE
+    default: rc = BM_EINVAL;
+  }
+  *blocks_out = blocks;
+  return rc;
+}
+
+}  // namespace bm

@@ -142,7 +142,9 @@ __device__ __forceinline__ int row_offset_bytes(const PairGeom& g, int I, int a)
 // use a plain load + ds_write loop (same layout, not overlapped).
 template <bool ALIGNED, int ABLATE = 0>
 __global__ __launch_bounds__(kPairMaxThreads) void pairwise_partial_kernel(
-    RowTable rows, PairGeom g, int64_t d, double* __restrict__ partial) {
+    RowTable rows, PairGeom g, int64_t d, double* __restrict__ partial, const int* __restrict__ gate) {
+  // gate: accuracy flag of the Gram path (gram_to_sqdist_kernel); 0 = this launch has nothing to do
+  if (gate != nullptr && *gate == 0) return;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const float** row_ptr = reinterpret_cast<const float**>(smem);  // 512 B pointer table
   char* tiles = smem + BM_MAX_ROWS * sizeof(float*);
@@ -322,7 +324,9 @@ __global__ __launch_bounds__(kPairMaxThreads) void pairwise_partial_kernel(
 // scatters the value to sq[i][j] and sq[j][i].
 constexpr int kRedWaves = 8;
 __global__ __launch_bounds__(64 * kRedWaves) void pairwise_reduce_kernel(
-    const double* __restrict__ partial, int nblocks, PairGeom g, double* __restrict__ sq) {
+    const double* __restrict__ partial, int nblocks, PairGeom g, double* __restrict__ sq,
+    const int* __restrict__ gate) {
+  if (gate != nullptr && *gate == 0) return;
   __shared__ double wsum[kRedWaves][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int per_block = g.tiles * 16;
@@ -428,19 +432,24 @@ __global__ __launch_bounds__(kRankThreads) void krum_rank_kernel(const double* _
 }  // namespace bm
 
 namespace bm {
-int gram_sqdist(const float* const* rows, int n, int64_t d, double* sq_nxn, void* ws, hipStream_t s);
-int64_t gram_workspace_bytes(int n);
-}  // namespace bm
+int gram_sqdist(const float* const* rows, int n, int64_t d, double* sq_nxn, double* partial, double* gram,
+                int* flag, double tau, hipStream_t s);
+int gram_finish(const double* partial, int blocks, int n, double* gram, double* sq_nxn, int* flag, double tau,
+                hipStream_t s);
+int64_t gram_partial_doubles(int n);
+int gram3_partials(const float* const* rows, int n, int64_t d, double* partial, int* blocks_out, hipStream_t s);
+int64_t gram3_partial_doubles(int n);
 
-extern "C" int bm_pairwise_sqdist(const float* const* rows, int n, int64_t d, double* sq_nxn,
-                                  void* ws, void* stream) {
-  using namespace bm;
-  if (rows == nullptr || sq_nxn == nullptr || ws == nullptr || n < 1 || n > BM_MAX_ROWS || d < 0)
-    return BM_EINVAL;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  // Default: Gram contraction on the fp32 matrix cores (gram.hip).  BM_PAIR_MODE=1 selects the
-  // direct-difference VALU kernel below (kept as the measured alternative).
-  if (tuning().pair_mode == 0) return gram_sqdist(rows, n, d, sq_nxn, ws, s);
+// Workspace layout of bm_pairwise_sqdist: [flag: 64 B][Gram partials][Gram n(n+1)/2][direct partials]
+static int64_t pair_gram_doubles(int n) {
+  const int64_t a = gram_partial_doubles(n), b = gram3_partial_doubles(n);
+  return (a > b ? a : b) + (int64_t)n * (n + 1) / 2;
+}
+
+// Direct-difference kernel + its reduction.  gate == nullptr: unconditional; otherwise both launches
+// return immediately unless *gate != 0 (device-side decision, no host synchronisation).
+static int pairwise_direct(const float* const* rows, int n, int64_t d, double* sq_nxn, double* partial,
+                           const int* gate, hipStream_t s) {
   const PairGeom g = pair_geometry(n);
   RowTable tab{};
   for (int i = 0; i < n; ++i) tab.p[i] = rows[i];
@@ -451,7 +460,6 @@ extern "C" int bm_pairwise_sqdist(const float* const* rows, int n, int64_t d, do
   lds_bytes += BM_MAX_ROWS * sizeof(float*);  // row pointer table in front
   const bool aligned =
       common_vec_width(reinterpret_cast<const void* const*>(rows), n, nullptr) == 4;
-  double* partial = static_cast<double*>(ws);
   const int ablate = tuning().pair_ablate;  // experiments only (BM_PAIR_ABLATE)
   auto kern = !aligned ? pairwise_partial_kernel<false>
                        : (ablate == 1 ? pairwise_partial_kernel<true, 1>
@@ -462,13 +470,46 @@ extern "C" int bm_pairwise_sqdist(const float* const* rows, int n, int64_t d, do
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return hip_code(e);
   }
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(g.threads), lds_bytes, s, tab, g, d, partial);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(g.threads), lds_bytes, s, tab, g, d, partial, gate);
   BM_LAUNCH_CHECK();
   const int per_block = g.tiles * 16;
   hipLaunchKernelGGL(pairwise_reduce_kernel, dim3((per_block + 63) / 64), dim3(64 * kRedWaves), 0, s,
-                     partial, blocks, g, sq_nxn);
+                     partial, blocks, g, sq_nxn, gate);
   BM_LAUNCH_CHECK();
   return 0;
+}
+}  // namespace bm
+
+extern "C" int bm_pairwise_sqdist(const float* const* rows, int n, int64_t d, double* sq_nxn,
+                                  void* ws, void* stream) {
+  using namespace bm;
+  if (rows == nullptr || sq_nxn == nullptr || ws == nullptr || n < 1 || n > BM_MAX_ROWS || d < 0)
+    return BM_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int* flag = static_cast<int*>(ws);
+  double* gram_partial = reinterpret_cast<double*>(static_cast<char*>(ws) + 64);
+  double* direct_partial = gram_partial + pair_gram_doubles(n);
+  // BM_PAIR_MODE: 0 (default) centred Gram on the bf16 matrix cores, three-way split (gram_bf16.hip);
+  //               1 direct differences on the VALU (this file), no cancellation at all;
+  //               2 uncentred Gram on the fp32 matrix cores (gram.hip), kept as the measured alternative.
+  // Modes 0 and 2 end with the accuracy check of gram_to_sqdist_kernel; if it flags a pair the direct
+  // kernel recomputes the whole matrix (gated on the device, no host round trip).
+  const int mode = tuning().pair_mode;
+  if (mode == 1) return pairwise_direct(rows, n, d, sq_nxn, direct_partial, nullptr, s);
+  const double tau = tuning().pair_tau;
+  int rc;
+  if (mode == 2) {
+    double* gram = gram_partial + gram_partial_doubles(n);
+    rc = gram_sqdist(rows, n, d, sq_nxn, gram_partial, gram, flag, tau, s);
+  } else {
+    int blocks = 0;
+    rc = gram3_partials(rows, n, d, gram_partial, &blocks, s);
+    if (rc != 0) return rc;
+    double* gram = gram_partial + gram3_partial_doubles(n);
+    rc = gram_finish(gram_partial, blocks, n, gram, sq_nxn, flag, tau, s);
+  }
+  if (rc != 0 || tau <= 0.0) return rc;
+  return pairwise_direct(rows, n, d, sq_nxn, direct_partial, flag, s);
 }
 
 extern "C" int bm_krum_rank(const double* sq_nxn, int n, int f, int m, int mode,
@@ -486,12 +527,11 @@ extern "C" int bm_krum_rank(const double* sq_nxn, int n, int f, int m, int mode,
 namespace bm {
 int64_t pairwise_workspace_bytes(int n, int64_t d) {
   const PairGeom g = pair_geometry(n);
-  // upper bound on the grid (BM_PAIR_BLOCKS may raise it, keep a floor of 8192 workgroups)
+  // upper bound on the grid (BM_PAIR_BLOCKS may raise it, keep a floor of 4096 workgroups)
   int blocks = tuning().pair_blocks > 0 ? tuning().pair_blocks : 256 * 4;
   if (blocks < 4096) blocks = 4096;
   (void)d;
   const int64_t direct = (int64_t)blocks * g.tiles * 16 * (int64_t)sizeof(double);
-  const int64_t gram = gram_workspace_bytes(n);
-  return direct > gram ? direct : gram;
+  return 64 + pair_gram_doubles(n) * (int64_t)sizeof(double) + direct;
 }
 }  // namespace bm

@@ -95,8 +95,10 @@ def _influence_average(honests, attacks, **kwargs):
 # Registration of the rules the reference has no `native` call site for
 
 def _reference_check(module, fallback):
-  """Use the reference's own `check` of the rule (looked up lazily: the module may be imported
-  after us) and fall back to an equivalent local one if it is unavailable."""
+  """Use the reference's own `check` of the rule, looked up lazily (`native` is imported from inside
+  the first rule module that probes for it, before aggregators/trmean.py, aksel.py... have run).  Only
+  when that module does not exist at all (this package used with another registry) the generic
+  validator below is used."""
   def check(**kwargs):
     mod = sys.modules.get(f"aggregators.{module}")
     fn = getattr(mod, "check", None)
@@ -104,26 +106,26 @@ def _reference_check(module, fallback):
   return check
 
 
-def _check_list(gradients, **kwargs):
-  if not isinstance(gradients, list) or len(gradients) < 1:
-    return f"Expected a list of at least one gradient to aggregate, got {gradients!r}"
+def _generic_check(min_rows_per_f=0, modes=None):
+  """Validator for registries other than the reference's: None when the arguments can be served,
+  otherwise a message (the contract of aggregators/__init__.py:23-27)."""
+  def check(gradients=None, f=None, mode=None, **kwargs):
+    if not isinstance(gradients, list) or not gradients:
+      return "gradients must be a non-empty list of tensors"
+    if min_rows_per_f:
+      if not isinstance(f, int) or f < 1:
+        return f"f must be a positive integer (got {f!r})"
+      if len(gradients) < min_rows_per_f * f + 1:
+        return f"{len(gradients)} gradients cannot tolerate f = {f}: at least {min_rows_per_f * f + 1} are needed"
+    if modes is not None and mode is not None and mode not in modes:
+      return f"mode must be one of {modes} (got {mode!r})"
+    return None
+  return check
 
 
-def _check_f_half(gradients, f, **kwargs):
-  msg = _check_list(gradients)
-  if msg is not None:
-    return msg
-  if not isinstance(f, int) or f < 1 or len(gradients) < 2 * f + 1:
-    return (f"Invalid number of Byzantine gradients to tolerate, got f = {f!r}, "
-            f"expected 1 ≤ f ≤ {(len(gradients) - 1) // 2}")
-
-
-def _check_aksel(gradients, f, mode="mid", **kwargs):
-  msg = _check_f_half(gradients, f)
-  if msg is not None:
-    return msg
-  if mode not in ("mid", "n-f"):
-    return f"Invalid operation mode {mode!r}"
+_check_list = _generic_check()
+_check_f_half = _generic_check(min_rows_per_f=2)
+_check_aksel = _generic_check(min_rows_per_f=2, modes=("mid", "n-f"))
 
 
 _registered = False

@@ -368,16 +368,32 @@ def make_stack(kind, n, f, d, seed, device="cpu", dtype=torch.float32):
           f Byzantine rows = -0.1 mean(honest)  ("empire", factor 1.1: (1 - 1.1) * mean)
   little  honest as hetero; Byzantine = mean - 1.5 std (coordinate-wise, unbiased std)
   nan     honest as hetero; Byzantine = all-NaN (attacks/nan.py)
+  tight   mu = 10 randn; honest g_i = mu + sigma_i randn, sigma = linspace(0.01, 0.1, h): rows whose
+          distances are 1e-3..1e-2 of their norms (what a Gram formulation G_ii+G_jj-2G_ij cancels
+          on); Byzantine = -0.1 mean(honest), i.e. far outliers next to the tight cluster
+  momentum  the honest rows are worker momentum buffers after 50 steps of
+          buf <- 0.99 buf + 0.01 g_t (attack.py:800-804) with g_t = mu + sigma_i randn (hetero's
+          distribution, a fresh draw per step); Byzantine = -0.1 mean(honest)
   """
   gen = torch.Generator(device="cpu").manual_seed(seed)
   if kind == "iid":
     return [torch.randn(d, generator=gen, dtype=dtype).to(device) for _ in range(n)], n
   h = n - f
-  mu = 0.1 * torch.randn(d, generator=gen, dtype=dtype)
-  sigmas = torch.linspace(0.5, 1.5, h)
-  honests = [(mu + sigmas[i] * torch.randn(d, generator=gen, dtype=dtype)) for i in range(h)]
+  if kind == "tight":
+    mu = 10.0 * torch.randn(d, generator=gen, dtype=dtype)
+    sigmas = torch.linspace(0.01, 0.1, h)
+  else:
+    mu = 0.1 * torch.randn(d, generator=gen, dtype=dtype)
+    sigmas = torch.linspace(0.5, 1.5, h)
+  if kind == "momentum":
+    honests = [torch.zeros(d, dtype=dtype) for _ in range(h)]
+    for _ in range(50):
+      for i in range(h):
+        honests[i].mul_(0.99).add_(mu + sigmas[i] * torch.randn(d, generator=gen, dtype=dtype), alpha=0.01)
+  else:
+    honests = [(mu + sigmas[i] * torch.randn(d, generator=gen, dtype=dtype)) for i in range(h)]
   stack = torch.stack(honests)
-  if kind == "hetero":
+  if kind in ("hetero", "tight", "momentum"):
     byz = stack.mean(dim=0).mul_(-0.1)
   elif kind == "little":
     byz = stack.mean(dim=0) - 1.5 * stack.std(dim=0)

@@ -1,0 +1,89 @@
+"""Distance-rule parity on ill-conditioned stacks, run as a script so that a test can execute it once
+per BM_PAIR_MODE (the library reads its environment once per process).  Needs a GPU.
+
+Checks, for the generators of oracle.make_stack ("hetero", "tight", "momentum") at d = 100 003:
+  * every squared distance within 1e-5 RELATIVE TO ITSELF of the float64 value (not relative to
+    the largest entry: a Gram formulation that cancels fails exactly on the small ones);
+  * exact zeros / bitwise-equal rows for the aliased Byzantine gradients;
+  * Krum selection, Bulyan ranking, Aksel selection and Brute selection equal to the float64
+    oracle whenever the decisive score gap is > 1e-5 relative (it always is for these generators);
+  * the Multi-Krum average bit-identical to the reference-faithful f32 oracle.
+Prints "pair-mode ok" on success.
+"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import byzantinemomentum_amd as bm  # noqa: E402
+from oracle import gar_oracle as O  # noqa: E402
+
+
+def to_dev(rows):
+  seen = {}
+  return [seen.setdefault(id(g), g.to("cuda:0")) for g in rows]
+
+
+def decisive(scores, k, tol=1e-5):
+  srt = sorted(scores)
+  return k >= len(srt) or srt[k] - srt[k - 1] > tol * abs(srt[k])
+
+
+def check_stack(kind, n, f, d, seed):
+  rows, h = O.make_stack(kind, n, f, d, seed=seed)
+  dev = to_dev(rows)
+  m = n - f - 2
+  sq = bm.gars.pairwise_sqdist(dev).cpu()
+  want = torch.from_numpy(O.pairwise_distances(rows, "f64")) ** 2
+  off = ~torch.eye(n, dtype=torch.bool)
+  rel = ((sq - want).abs()[off & (want > 0)] / want[off & (want > 0)]).max().item()
+  assert rel <= 1e-5, (kind, n, "max relative error of a squared distance", rel)
+  assert torch.equal(sq, sq.T) and bool((sq.diagonal() == 0).all())
+  for a in range(h + 1, n):
+    assert sq[h, a].item() == 0.0 and torch.equal(sq[h, :h], sq[a, :h]), (kind, "aliased rows")
+  o64, s64 = O.krum_order(rows, f, "f64")
+  if decisive(s64, m):
+    got = bm.gars.krum_selection(dev, f)
+    assert sorted(got) == sorted(o64[:m]), (kind, n, "krum selection set")
+    if all(decisive(s64, k) for k in range(1, m)):
+      assert got == o64[:m], (kind, n, "krum selection order")
+      o32, _ = O.krum_order(rows, f, "f32")
+      if o32[:m] == o64[:m]:
+        assert torch.equal(bm.krum(dev, f).cpu(), O.krum(rows, f)), (kind, n, "krum average bits")
+  if n >= 4 * f + 3:
+    ob, sb = O.bulyan_order(rows, f, None, "f64")
+    if all(decisive(sb, k) for k in range(1, n)):
+      assert bm.gars.bulyan_ranking(dev, f) == ob, (kind, n, "bulyan ranking")
+    scale = float(torch.stack(rows[:h]).abs().max())
+    err = (bm.bulyan(dev, f).cpu().double() - O.bulyan(rows, f, None, "f64")).abs().max().item()
+    assert err <= 2e-6 * scale, (kind, n, "bulyan output", err)
+  oa, sa = O.aksel_order(rows, "f64")
+  c = (n + 1) // 2
+  if decisive(sa, c):
+    assert sorted(bm.gars.aksel_selection(dev, f)) == sorted(oa[:c]), (kind, n, "aksel selection")
+  if n <= 13:
+    assert bm.gars.brute_selection(dev, f) == O.brute_selection(rows, f, "f64"), (kind, n, "brute selection")
+  return rel
+
+
+def main():
+  d = 100003
+  worst = 0.0
+  for kind in ("hetero", "tight", "momentum"):
+    for n, f in ((25, 5), (51, 12), (11, 2)):
+      worst = max(worst, check_stack(kind, n, f, d, seed=99))
+  # a near-duplicate pair (relative difference 1e-6): the accuracy gate must hand it to the direct kernel
+  rows, h = O.make_stack("hetero", 13, 3, 50021, seed=5)
+  rows[2] = rows[1] * (1.0 + 1e-6) + 1e-7
+  dev = to_dev(rows)
+  sq = bm.gars.pairwise_sqdist(dev).cpu()
+  want = torch.from_numpy(O.pairwise_distances(rows, "f64")) ** 2
+  rel = abs(sq[1, 2].item() - want[1, 2].item()) / want[1, 2].item()
+  assert rel <= 1e-5, ("near-duplicate rows", rel)
+  print(f"pair-mode ok (worst relative error of a squared distance {worst:.2e})")
+
+
+if __name__ == "__main__":
+  main()

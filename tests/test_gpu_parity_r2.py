@@ -1,0 +1,351 @@
+"""Round-2 GPU parity: the BASELINE.json configurations at FULL size against fp64 computed with torch
+on the same GPU, ill-conditioned stacks in every BM_PAIR_MODE, the closest-to-centre rules without
+exempt columns, and the plugin objects exactly as the reference's call sites use them.
+Needs an MI355X: `pytest -m gpu`.
+"""
+
+import math
+import os
+import subprocess
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gar_oracle as O
+from tests.golden_io import CASES, Golden, same_bits
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+D_RESNET18 = 11173962
+D_WRN = 36546980
+
+
+@pytest.fixture(scope="module")
+def bm():
+  import byzantinemomentum_amd
+  byzantinemomentum_amd._lib.load()
+  return byzantinemomentum_amd
+
+
+def to_dev(gradients):
+  seen = {}
+  return [seen.setdefault(id(g), g.to(DEV)) for g in gradients]
+
+
+def gpu_stack(kind, n, f, d, seed):
+  """oracle.make_stack's "hetero"/"tight" distributions generated on the GPU (full-size cases)."""
+  gen = torch.Generator(device=DEV).manual_seed(seed)
+  h = n - f
+  if kind == "tight":
+    mu = 10.0 * torch.randn(d, device=DEV, generator=gen)
+    sig = torch.linspace(0.01, 0.1, h).tolist()
+  else:
+    mu = 0.1 * torch.randn(d, device=DEV, generator=gen)
+    sig = torch.linspace(0.5, 1.5, h).tolist()
+  honest = [mu + s * torch.randn(d, device=DEV, generator=gen) for s in sig]
+  acc = torch.zeros(d, dtype=torch.float32, device=DEV)
+  for g in honest:
+    acc += g
+  byz = acc.div_(h).mul_(-0.1)
+  return honest + [byz] * f, h
+
+
+def sqdist_f64_on_gpu(rows):
+  """n x n float64 squared distances, direct differences in fp64 on the GPU (no Gram, no cancellation)."""
+  n = len(rows)
+  out = np.zeros((n, n))
+  for i in range(n - 1):
+    xi = rows[i].double()
+    for j in range(i + 1, n):
+      if rows[j] is rows[i]:
+        continue
+      diff = rows[j].double().sub_(xi)
+      out[i, j] = out[j, i] = torch.dot(diff, diff).item()
+  return out
+
+
+def decisive(scores, k, tol=1e-5):
+  srt = sorted(scores)
+  return k >= len(srt) or srt[k] - srt[k - 1] > tol * abs(srt[k])
+
+
+# ---------------------------------------------------------------------------- #
+# BASELINE config 3 at full size: n = 51, f = 12, d = 11 173 962
+
+@pytest.mark.parametrize("kind", ["hetero", "tight"])
+def test_full_size_c3_krum_against_fp64(bm, kind):
+  n, f, d = 51, 12, D_RESNET18
+  m = n - f - 2
+  rows, h = gpu_stack(kind, n, f, d, seed=2024)
+  want_sq = sqdist_f64_on_gpu(rows)                       # all 1 275 distances, fp64, same GPU
+  sq = bm.gars.pairwise_sqdist(rows).cpu().numpy()
+  off = ~np.eye(n, dtype=bool) & (want_sq > 0)
+  rel = np.abs(sq - want_sq)[off] / want_sq[off]
+  assert rel.max() <= 1e-5, f"{kind}: worst relative error of a squared distance {rel.max():.2e}"
+  for a in range(h + 1, n):
+    assert sq[h, a] == 0.0 and np.array_equal(sq[h, :h], sq[a, :h])
+  # rank with the oracle's own logic (krum.py:50-62) on the fp64 distances
+  scores = O.krum_scores(np.sqrt(want_sq), f)
+  order = O._stable_order(scores)
+  assert all(decisive(scores, k) for k in range(1, m + 1)), "generator is meant to be well separated"
+  got = bm.gars.krum_selection(rows, f)
+  assert got == order[:m]
+  # the average: torch's own sequential fp32 sum on the same GPU, true division on the host
+  acc = torch.zeros(d, dtype=torch.float32, device=DEV)
+  for i in order[:m]:
+    acc = acc + rows[i]
+  assert same_bits(bm.krum(rows, f), acc.cpu().div_(m))
+  acc1 = (torch.zeros(d, dtype=torch.float32, device=DEV) + rows[order[0]]).cpu().div_(1)
+  assert same_bits(bm.krum(rows, f, 1), acc1)
+
+
+# ---------------------------------------------------------------------------- #
+# BASELINE config 4 at full size on one GPU: Bulyan n = 25, f = 5
+
+def test_full_size_c4_bulyan_against_fp64(bm):
+  n, f, d = 25, 5, D_RESNET18
+  m = n - f - 2
+  theta, beta = n - 2 * f - 2, n - 4 * f - 2
+  rows, h = gpu_stack("hetero", n, f, d, seed=4)
+  want_sq = sqdist_f64_on_gpu(rows)
+  # bulyan.py:56-62: score = sum of the m smallest distances of the row
+  dist = np.sqrt(want_sq)
+  scores = [O._sum_smallest([dist[i, j] for j in range(n) if j != i], m) for i in range(n)]
+  order = O._stable_order(scores)
+  got = bm.gars.bulyan_ranking(rows, f)
+  # neighbours in the ranking are either exactly tied (aliased Byzantine rows: index order) or well apart
+  assert all(scores[a] == scores[b] or scores[b] - scores[a] > 1e-5 * scores[b] for a, b in zip(order, order[1:]))
+  assert got == order
+  # pass 2 in fp64 on the GPU from the ranking we obtained (bulyan.py:64-84, static scores)
+  sel = []
+  for i in range(theta):
+    cnt = min(m, m - i)
+    acc = torch.zeros(d, dtype=torch.float64, device=DEV)
+    for r in got[i:i + cnt]:
+      acc += rows[r]
+    sel.append((acc / cnt).float())
+  sel = torch.stack(sel)
+  med = sel.median(dim=0).values
+  idx = (sel - med).abs().topk(beta, dim=0, largest=False, sorted=False).indices
+  want = sel.gather(0, idx).double().mean(dim=0)
+  out = bm.bulyan(rows, f)
+  scale = float(torch.stack([r.abs().max() for r in rows[:h]]).max())
+  assert float((out.double() - want).abs().max()) <= 4e-6 * scale
+
+
+# ---------------------------------------------------------------------------- #
+# Ill-conditioned stacks in every distance mode (the library reads BM_PAIR_MODE once per process)
+
+@pytest.mark.parametrize("mode", ["0", "1", "2"])
+def test_tight_and_momentum_stacks_in_every_pair_mode(mode):
+  env = dict(os.environ, BM_PAIR_MODE=mode, PYTHONPATH=ROOT)
+  out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "pair_mode_check.py")], capture_output=True,
+                       text=True, env=env, cwd=ROOT, timeout=900)
+  assert out.returncode == 0 and "pair-mode ok" in out.stdout, (out.stdout[-1000:], out.stderr[-3000:])
+  print(out.stdout.strip())
+
+
+def test_accuracy_gate_hands_over_to_the_direct_kernel():
+  """BM_PAIR_TAU=1e30 flags every pair: the gated direct kernel must then produce exactly what
+  BM_PAIR_MODE=1 produces (same kernel, same reduction order)."""
+  code = (
+    "import torch, sys\n"
+    "import byzantinemomentum_amd as bm\n"
+    "from oracle import gar_oracle as O\n"
+    "rows, h = O.make_stack('hetero', 25, 5, 70001, seed=8)\n"
+    "seen = {}\n"
+    "dev = [seen.setdefault(id(g), g.to('cuda:0')) for g in rows]\n"
+    "torch.save(bm.gars.pairwise_sqdist(dev).cpu(), sys.argv[1])\n")
+  import tempfile
+  with tempfile.TemporaryDirectory() as tmp:
+    paths = []
+    for name, extra in (("gated", {"BM_PAIR_TAU": "1e30"}), ("direct", {"BM_PAIR_MODE": "1"})):
+      path = os.path.join(tmp, name + ".pt")
+      env = dict(os.environ, PYTHONPATH=ROOT, **extra)
+      out = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, env=env, cwd=ROOT)
+      assert out.returncode == 0, out.stderr[-2000:]
+      paths.append(path)
+    assert torch.equal(torch.load(paths[0]), torch.load(paths[1]))
+
+
+# ---------------------------------------------------------------------------- #
+# phocas / meamed: no exempt columns — an exact deviation tie must give one of the two legal windows
+
+def _window_candidates(st, keep, centre):
+  """(mean of the reference-legal window, ambiguous mask, list of alternative means) per column."""
+  g = st.to(torch.float64)
+  c = centre.to(torch.float64)
+  n, d = g.shape
+  srt = g.sort(dim=0).values
+  win, amb = O.closest_window(st, keep, centre)
+  # alternatives: every contiguous window of `keep` sorted values (the topk result is always one of them
+  # when deviations tie only at the window edges)
+  csum = torch.cat([torch.zeros(1, d, dtype=torch.float64), srt.cumsum(dim=0)])
+  alts = [(csum[s + keep] - csum[s]) / keep for s in range(n - keep + 1)]
+  return win, amb, alts
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_closest_rules_without_exemptions(bm, name):
+  g = Golden(name)
+  if not g.has("trmean"):
+    pytest.skip("no trimmed-mean fixture")
+  dev = to_dev(g.gradients)
+  st = torch.stack(g.gradients)
+  finite = torch.isfinite(st)
+  scale = float(st[finite].abs().max())
+  for rule, centre in (("phocas", O.trmean(g.gradients, g.f)), ("meamed", O.median(g.gradients))):
+    got = bm.gars.__dict__[rule](dev, g.f).cpu().double()
+    want = g.tensor(rule).double()
+    keep = g.n - g.f
+    win, amb, alts = _window_candidates(torch.nan_to_num(st, nan=math.inf), keep, centre)
+    nan_centre = torch.isnan(centre)
+    ok = ((got - want).abs() <= 2e-6 * scale) | (torch.isnan(got) & torch.isnan(want))
+    # ambiguous columns: ours must be one of the legal windows
+    legal = torch.zeros_like(ok)
+    for alt in alts:
+      legal |= (got - alt).abs() <= 2e-6 * scale
+    ok |= amb & legal
+    # NaN centre: documented deviation — we return NaN, the reference an arbitrary subset mean
+    ok |= nan_centre & torch.isnan(got)
+    assert bool(ok.all()), (rule, int((~ok).sum()))
+    frac_amb = float(amb.float().mean())
+    print(f"{name} {rule}: {int(amb.sum())} tie columns ({frac_amb:.2%}), {int(nan_centre.sum())} NaN-centre columns "
+          f"of {st.shape[1]}")
+    if not name.startswith("nan"):
+      assert int(nan_centre.sum()) == 0
+
+
+def test_closest_rules_full_size(bm):
+  """phocas / meamed at n = 25, d = 11 173 962 against a float64 window formulation on the GPU."""
+  n, f, d = 25, 5, D_RESNET18
+  rows, h = gpu_stack("hetero", n, f, d, seed=11)
+  keep = n - f
+  st = torch.stack(rows)
+  srt = st.sort(dim=0).values
+  del st
+  for rule in ("meamed", "phocas"):
+    got = bm.gars.__dict__[rule](rows, f)
+    centre = srt[(n - 1) // 2] if rule == "meamed" else srt[f:n - f].mean(dim=0)
+    dev = (srt - centre).abs()
+    # window start = number of leading values farther than their mirror (trmean.py:45-50 keeps the nearest)
+    lo = torch.zeros(d, dtype=torch.long, device=DEV)
+    hi = torch.full((d,), n - 1, dtype=torch.long, device=DEV)
+    cols = torch.arange(d, device=DEV)
+    for _ in range(n - keep):
+      drop_lo = dev[lo, cols] > dev[hi, cols]
+      lo = torch.where(drop_lo, lo + 1, lo)
+      hi = torch.where(drop_lo, hi, hi - 1)
+    total = torch.zeros(d, dtype=torch.float64, device=DEV)
+    for k in range(keep):
+      total += srt[lo + k, cols]
+    want = total / keep
+    # near ties at the window edge: our centre may differ from torch's in the last bit (phocas), which
+    # legitimately flips the choice between two values that are equally far within rounding
+    eps = 1e-6 * float(srt.abs().max())
+    tie = ((dev[(lo - 1).clamp(min=0), cols] - dev[hi, cols]).abs() <= eps) & (lo > 0) | \
+          ((dev[(hi + 1).clamp(max=n - 1), cols] - dev[lo, cols]).abs() <= eps) & (hi < n - 1)
+    bad = ((got.double() - want).abs() > 2e-6 * float(srt.abs().max())) & ~tie
+    assert int(bad.sum()) == 0, (rule, int(bad.sum()))
+    assert int(tie.sum()) <= d // 1000, (rule, "tie columns", int(tie.sum()))
+
+
+# ---------------------------------------------------------------------------- #
+# The plugin objects, driven the way the reference's aggregators package drives them
+# (aggregators/__init__.py:42-86, krum.py:82-96,159-166, median.py:41-49,80-87), on the GPU.
+
+def _fake_aggregators_package():
+  """A stand-in for the reference's `aggregators` package (absent on the GPU box): the registry
+  contract only — `gars`, `register(name, unchecked, check, upper_bound=None, influence=None)` producing
+  callables with the attributes check/checked/unchecked/upper_bound/influence — and the four
+  native call sites with the reference's positional conventions."""
+  pkg = types.ModuleType("aggregators")
+  pkg.gars = {}
+
+  def register(name, unchecked, check, upper_bound=None, influence=None):
+    if name in pkg.gars:
+      return
+    def checked(**kwargs):
+      message = check(**kwargs)
+      if message is not None:
+        raise RuntimeError(f"rule {name!r} rejected its parameters: {message}")
+      return unchecked(**kwargs)
+    for key, val in (("check", check), ("checked", checked), ("unchecked", unchecked), ("upper_bound", upper_bound),
+                     ("influence", influence)):
+      setattr(checked, key, val)
+    pkg.gars[name] = checked
+  pkg.register = register
+  sys.modules["aggregators"] = pkg
+  sys.modules.pop("native", None)
+  import native  # registers native-trmean/-phocas/-meamed/-aksel/-average/-cge through pkg.register
+
+  def accept(gradients, f=None, **kwargs):
+    return None if isinstance(gradients, list) and len(gradients) >= 1 else "need a non-empty list"
+  # the four call sites of the reference, positional arguments as written there
+  register("native-krum", lambda gradients, f, m=None, **kw: native.krum.aggregate(
+    gradients, f, len(gradients) - f - 2 if m is None else m), accept)
+  register("native-bulyan", lambda gradients, f, m=None, **kw: native.bulyan.aggregate(
+    gradients, f, len(gradients) - f - 2 if m is None else m), accept)
+  register("native-median", lambda gradients, **kw: native.median.aggregate(gradients), accept)
+  register("native-brute", lambda gradients, f, **kw: native.brute.aggregate(gradients, f), accept)
+  return pkg, native
+
+
+def test_plugin_objects_on_gpu(bm):
+  saved = {k: sys.modules.get(k) for k in ("aggregators", "native")}
+  try:
+    pkg, native = _fake_aggregators_package()
+    gars = pkg.gars
+    for name in ("native-trmean", "native-phocas", "native-meamed", "native-aksel", "native-average", "native-cge",
+                 "native-krum", "native-bulyan", "native-median", "native-brute"):
+      assert name in gars, name
+    g = Golden("hetero_n11_f2")
+    dev = to_dev(g.gradients)
+    model = object()  # rules must tolerate unknown keyword arguments (aggregators/__init__.py:15-21)
+    assert same_bits(gars["native-median"](gradients=dev, f=g.f, model=model), g.tensor("median"))
+    out = gars["native-trmean"](gradients=dev, f=g.f, model=model)
+    assert float((out.cpu() - g.tensor("trmean")).abs().max()) <= 1e-6 * float(g.tensor("trmean").abs().max())
+    assert all(out.data_ptr() != t.data_ptr() for t in dev)       # never an alias of an input
+    assert same_bits(gars["native-krum"](gradients=dev, f=g.f, model=model), g.tensor("krum"))
+    assert same_bits(gars["native-krum"](gradients=dev, f=g.f, m=1), g.tensor("krum_m1"))
+    assert same_bits(native.krum.aggregate(dev, g.f, g.n - g.f - 2), g.tensor("krum"))  # positional, as krum.py:96
+    assert same_bits(gars["native-brute"](gradients=dev, f=g.f), g.tensor("brute"))
+    assert same_bits(gars["native-aksel"](gradients=dev, f=g.f), g.tensor("aksel_mid"))
+    assert same_bits(gars["native-aksel"](gradients=dev, f=g.f, mode="n-f"), g.tensor("aksel_n-f"))
+    assert same_bits(gars["native-average"](gradients=dev, f=g.f), g.tensor("average"))
+    assert same_bits(gars["native-cge"](gradients=dev, f=g.f), g.tensor("cge"))
+    g25 = Golden("hetero_n25_f5")
+    dev25 = to_dev(g25.gradients)
+    scale = float(torch.stack(g25.honests).abs().max())
+    out = gars["native-bulyan"](gradients=dev25, f=g25.f, model=model)
+    assert float((out.cpu() - g25.tensor("bulyan")).abs().max()) <= 2e-6 * scale
+    # influence: late-bound on the reference-registered native-krum/-brute after their first call,
+    # registered directly for the rules `native` registers itself
+    order = g.array("krum_order").tolist()
+    m = g.n - g.f - 2
+    want = sum(1 for i in order[:m] if i >= g.h) / m
+    assert gars["native-krum"].influence is not None
+    assert gars["native-krum"].influence(dev[:g.h], dev[g.h:], f=g.f) == want
+    sel = g.array("brute_selection").tolist()
+    assert gars["native-brute"].influence(dev[:g.h], dev[g.h:], f=g.f) == sum(1 for i in sel if i >= g.h) / len(sel)
+    ao = g.array("aksel_order").tolist()
+    c = (g.n + 1) // 2
+    assert gars["native-aksel"].influence(dev[:g.h], dev[g.h:], f=g.f) == sum(1 for i in ao[:c] if i >= g.h) / c
+    assert gars["native-average"].influence(dev[:g.h], dev[g.h:], f=g.f) == (g.n - g.h) / g.n
+    # checks are the callables handed to register(); a bad f must be refused by `checked`
+    with pytest.raises(Exception):
+      gars["native-trmean"].checked(gradients=dev, f=0)
+    # errors: CPU tensors are refused loudly, there is no fallback
+    with pytest.raises(bm.gars.GarInputError):
+      gars["native-median"](gradients=[t.cpu() for t in dev], f=g.f)
+  finally:
+    for k, v in saved.items():
+      if v is None:
+        sys.modules.pop(k, None)
+      else:
+        sys.modules[k] = v
