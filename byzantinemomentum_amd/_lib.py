@@ -16,12 +16,12 @@ import torch  # noqa: F401  (must be imported before the CDLL, see above)
 _PKG_DIR = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _PKG_DIR / "libbm_gar.so"
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_ROWS = 64
 EINVAL = -100000
 
 OP_MEDIAN, OP_TRMEAN, OP_PHOCAS, OP_MEAMED = 0, 1, 2, 3
-WS_PAIRWISE, WS_AKSEL, WS_STATS, WS_DOT = 0, 1, 2, 3
+WS_PAIRWISE, WS_AKSEL, WS_STATS, WS_DOT, WS_STEP = 0, 1, 2, 3, 4
 RANK_KRUM, RANK_BULYAN = 0, 1
 ATTACK_EMPIRE, ATTACK_LITTLE = 0, 1
 
@@ -53,6 +53,15 @@ SIGNATURES = {
   "bm_multi_axpby": (ctypes.c_int, [_c_float_pp, _c_float_pp, ctypes.c_int, ctypes.c_int64,
                                     ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),
   "bm_brute_select": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+  "bm_momentum_stats": (ctypes.c_int, [_c_float_pp, ctypes.c_int, _c_float_pp, ctypes.c_int, ctypes.c_int64,
+                                       ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_int,
+                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+  "bm_multi_fma3": (ctypes.c_int, [_c_float_pp, _c_float_pp, _c_float_pp, ctypes.c_int, ctypes.c_int64,
+                                   ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
+  "bm_clip_factors": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_void_p,
+                                     ctypes.c_void_p]),
+  "bm_multi_scale": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
 }
 
 

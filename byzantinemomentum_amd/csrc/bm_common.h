@@ -209,7 +209,8 @@ struct Tuning {
   int pair_ablate;     // BM_PAIR_ABLATE: 1 = no compute, 2 = no staging (experiments)
   int pair_nbuf;       // BM_PAIR_NBUF: LDS tile buffers of the Gram kernel, 2 (default, measured best) or 3
   int pair_mode;       // BM_PAIR_MODE: 0 = centred bf16x3 Gram (default), 1 = direct differences, 2 = fp32 Gram
-  int pair_centre;     // BM_PAIR_CENTRE: 1 (default) subtract the per-coordinate row mean in mode 0; 0 = experiments
+  int pair_centre;     // BM_PAIR_CENTRE (mode 0): 2 (default) median of three rows, 1 row mean, 0 none (experiments)
+  int pair_planes;     // BM_PAIR_PLANES (mode 0): 0 (default) by length, 2 or 3 forced
   double pair_tau;     // BM_PAIR_TAU: accuracy gate of the Gram modes (see gram_to_sqdist_kernel); <= 0 disables
 };
 const Tuning& tuning();

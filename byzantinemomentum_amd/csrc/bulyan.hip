@@ -354,6 +354,8 @@ extern "C" int64_t bm_workspace_bytes(int kind, int n, int64_t d) {
       return (int64_t)2048 * 3 * (int64_t)sizeof(double);
     case BM_WS_DOT:
       return (int64_t)1025 * 42 * (int64_t)sizeof(double);
+    case BM_WS_STEP:
+      return (int64_t)2049 * 6 * (int64_t)sizeof(double);
     default:
       return BM_EINVAL;
   }

@@ -93,25 +93,26 @@ __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
                                                  0, 0, 0);
 }
 
-// K = ceil(n/4) load instructions per chunk; RB = ceil(K/4) 16-row blocks.
-template <int K>
+// K = ceil(n/4) load instructions per chunk; RB = ceil(K/4) 16-row blocks; NPL bf16 planes (3 = the
+// exact split, 2 = h + rne_bf16(x - h): 16 significant bits, see gram3_partials).
+template <int K, int NPL>
 struct B3Shape {
   static constexpr int RB = (K + 3) / 4;
   static constexpr int NP = b3_pairs(RB);
   static constexpr int N4 = 4 * K;                      // LDS rows per plane
   static constexpr int PS = N4 * kB3RowBytes;           // plane stride
-  static constexpr int WS = 3 * PS;                     // wave region
-  static constexpr int NSETS = (K <= 8) ? 2 : 1;        // register sets of loads in flight
+  static constexpr int WS = NPL * PS;                   // wave region
+  static constexpr int NSETS = (K <= 8 && (NPL == 2 || K * NPL <= 21)) ? 2 : 1;  // register sets of loads in flight
   static constexpr int MINW = (K <= 8) ? 3 : 2;         // workgroups per CU aimed at
   static constexpr int kPtrBytes = BM_MAX_ROWS * 8;
   static constexpr int kRedBytes = kB3Waves * 256 * 8;
   static constexpr int kLds = kPtrBytes + (kB3Waves * WS > kRedBytes ? kB3Waves * WS : kRedBytes);
 };
 
-template <int K, bool ALIGNED>
-__global__ __launch_bounds__(64 * kB3Waves, B3Shape<K>::MINW) void gram3_partial_kernel(
+template <int K, int NPL, bool ALIGNED>
+__global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_partial_kernel(
     RowTable rows, int n, int64_t d, float inv_n, int centre, double* __restrict__ partial) {
-  using S = B3Shape<K>;
+  using S = B3Shape<K, NPL>;
   constexpr int RB = S::RB, NP = S::NP, NSETS = S::NSETS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const float** row_ptr = reinterpret_cast<const float**>(smem);
@@ -179,10 +180,28 @@ __global__ __launch_bounds__(64 * kB3Waves, B3Shape<K>::MINW) void gram3_partial
     }
   };
 
+  // Probe rows of the median-of-three centre: three rows spread over the stack, all held by the
+  // rho = 0 lanes (rows 0, 4*(K/3), 4*(2K/3)); tiny stacks take rows 0, 1, 2 / 0, 2, 4.
+  constexpr int kPa = 0, kPb = (K >= 3) ? K / 3 : 0, kPc = (K >= 3) ? (2 * K) / 3 : (K == 2 ? 1 : 0);
+  const int src_a = x;
+  const int src_b = (K >= 3) ? x : (K == 2 ? 32 + x : (n >= 3 ? 16 + x : x));
+  const int src_c = (K >= 3) ? x : (K == 2 ? x : (n >= 3 ? 32 + x : x));
+
   auto contract = [&](f32x4 (&v)[K]) {
-    // -- per-coordinate centre: mean over the n rows (any finite vector would do) --
+    // -- per-coordinate centre (distances are translation invariant; any finite vector is legal) --
     f32x4 c = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (centre) {
+    if (centre == 2) {
+      // median of three rows: stays inside the honest cluster as long as at most one of the three
+      // probes is an outlier, whatever the outliers' magnitude (the mean does not)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a = __shfl(v[kPa][e], src_a, 64);
+        const float b = __shfl(v[kPb][e], src_b, 64);
+        const float cc = __shfl(v[kPc][e], src_c, 64);
+        const float s = __builtin_amdgcn_fmed3f(a, b, cc);
+        c[e] = (__builtin_fabsf(s) < __builtin_inff()) ? s : 0.0f;
+      }
+    } else if (centre == 1) {
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         if (k == K - 1) {
@@ -202,7 +221,7 @@ __global__ __launch_bounds__(64 * kB3Waves, B3Shape<K>::MINW) void gram3_partial
         c[e] = (__builtin_fabsf(s) < __builtin_inff()) ? s : 0.0f;
       }
     }
-    // -- split and store the three planes --
+    // -- split and store the planes --
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       u32x2 h, m, l;
@@ -210,37 +229,57 @@ __global__ __launch_bounds__(64 * kB3Waves, B3Shape<K>::MINW) void gram3_partial
       char* dst = wbase + (wr_lane ^ (((2 * k) & 7) << 4)) + k * 4 * kB3RowBytes;
       *reinterpret_cast<u32x2*>(dst) = h;
       *reinterpret_cast<u32x2*>(dst + S::PS) = m;
-      *reinterpret_cast<u32x2*>(dst + 2 * S::PS) = l;
+      if constexpr (NPL == 3) *reinterpret_cast<u32x2*>(dst + 2 * S::PS) = l;
     }
   };
 
+  // Fragments of both 32-coordinate steps are read first; every block pair then runs its MFMAs of
+  // both steps into the same three accumulators, which are folded into the per-wave fp32 sums once
+  // per chunk (64 coordinates).
   auto multiply = [&]() {
+    u32x4 fh[2][RB], fm[2][RB], fl[2][RB];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      u32x4 fh[RB], fm[RB], fl[RB];
+    for (int s = 0; s < 2; ++s)
 #pragma unroll
       for (int R = 0; R < RB; ++R) {
         const int off = ((R == RB - 1) ? rd_last0 : rd0 + R * 16 * kB3RowBytes) ^ (s << 6);
-        fh[R] = *reinterpret_cast<const u32x4*>(wbase + off);
-        fm[R] = *reinterpret_cast<const u32x4*>(wbase + off + S::PS);
-        fl[R] = *reinterpret_cast<const u32x4*>(wbase + off + 2 * S::PS);
+        fh[s][R] = *reinterpret_cast<const u32x4*>(wbase + off);
+        fm[s][R] = *reinterpret_cast<const u32x4*>(wbase + off + S::PS);
+        if constexpr (NPL == 3) fl[s][R] = *reinterpret_cast<const u32x4*>(wbase + off + 2 * S::PS);
       }
-      const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-      int p = 0;
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    // Software pipeline over the block pairs: the MFMAs of pair p are issued before the three VALU
+    // folds of pair p-1, so the folds never wait for the matrix pipe; inside a pair the chain of S0
+    // (4 or 4 MFMAs) alternates with the S1 / S2 chains, dependent MFMAs are two issue slots apart.
+    f32x4 q0 = zero, q1 = zero, q2 = zero;  // accumulators of the previous pair, not folded yet
+    int p = 0;
 #pragma unroll
-      for (int I = 0; I < RB; ++I)
+    for (int I = 0; I < RB; ++I)
 #pragma unroll
-        for (int J = I; J < RB; ++J) {
-          f32x4 s0 = mfma_bf16(fh[I], fh[J], zero);
-          f32x4 s1 = mfma_bf16(fh[I], fm[J], zero);
-          f32x4 s2 = mfma_bf16(fm[I], fh[J], zero);
-          s0 = mfma_bf16(fm[I], fm[J], s0);
-          s1 = mfma_bf16(fh[I], fl[J], s1);
-          s2 = mfma_bf16(fl[I], fh[J], s2);
-          outer[p] += s0 + (s1 + s2);
-          ++p;
+      for (int J = I; J < RB; ++J) {
+        f32x4 s0 = mfma_bf16(fh[0][I], fh[0][J], zero);
+        f32x4 s1 = mfma_bf16(fh[0][I], fm[0][J], zero);
+        s0 = mfma_bf16(fm[0][I], fm[0][J], s0);
+        f32x4 s2 = mfma_bf16(fm[0][I], fh[0][J], zero);
+        if constexpr (NPL == 3) {
+          s1 = mfma_bf16(fh[0][I], fl[0][J], s1);
+          s2 = mfma_bf16(fl[0][I], fh[0][J], s2);
         }
-    }
+        s0 = mfma_bf16(fh[1][I], fh[1][J], s0);
+        s1 = mfma_bf16(fh[1][I], fm[1][J], s1);
+        s0 = mfma_bf16(fm[1][I], fm[1][J], s0);
+        s2 = mfma_bf16(fm[1][I], fh[1][J], s2);
+        if constexpr (NPL == 3) {
+          s1 = mfma_bf16(fh[1][I], fl[1][J], s1);
+          s2 = mfma_bf16(fl[1][I], fh[1][J], s2);
+        }
+        if (p > 0) outer[p - 1] += q0 + (q1 + q2);
+        q0 = s0;
+        q1 = s1;
+        q2 = s2;
+        ++p;
+      }
+    outer[NP - 1] += q0 + (q1 + q2);
   };
 
   // ---- main loop: loads of the next chunk(s) stay in flight under the MFMAs of this one ----
@@ -287,11 +326,11 @@ __global__ __launch_bounds__(64 * kB3Waves, B3Shape<K>::MINW) void gram3_partial
     }
 }
 
-template <int K>
-static int launch_gram3(const RowTable& tab, int n, int64_t d, bool aligned, int centre, double* partial,
-                        int blocks, hipStream_t s) {
-  using S = B3Shape<K>;
-  auto kern = aligned ? gram3_partial_kernel<K, true> : gram3_partial_kernel<K, false>;
+template <int K, int NPL>
+static int launch_gram3_planes(const RowTable& tab, int n, int64_t d, bool aligned, int centre, double* partial,
+                               int blocks, hipStream_t s) {
+  using S = B3Shape<K, NPL>;
+  auto kern = aligned ? gram3_partial_kernel<K, NPL, true> : gram3_partial_kernel<K, NPL, false>;
   if (S::kLds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, S::kLds);
@@ -301,6 +340,13 @@ static int launch_gram3(const RowTable& tab, int n, int64_t d, bool aligned, int
                      partial);
   BM_LAUNCH_CHECK();
   return 0;
+}
+
+template <int K>
+static int launch_gram3(const RowTable& tab, int n, int64_t d, bool aligned, int centre, int planes,
+                        double* partial, int blocks, hipStream_t s) {
+  return planes == 2 ? launch_gram3_planes<K, 2>(tab, n, d, aligned, centre, partial, blocks, s)
+                     : launch_gram3_planes<K, 3>(tab, n, d, aligned, centre, partial, blocks, s);
 }
 
 constexpr int kB3MaxBlocks = 1024;
@@ -322,10 +368,16 @@ int gram3_partials(const float* const* rows, int n, int64_t d, double* partial, 
   const int64_t need = (chunks + kB3Waves - 1) / kB3Waves;
   if (blocks > need) blocks = (int)(need > 0 ? need : 1);
   const int centre = tuning().pair_centre;
+  // Planes: the exact three-way split below 2^17 coordinates; above, two planes (x ~ h + m, 16
+  // significant bits, unbiased remainder <= 2^-17 |x|): the rounding noise of a Gram entry averages
+  // as 4.4e-6 * sqrt(3/d) <= 2.1e-8 relative, the same order as the fp32 accumulation error, for a third
+  // fewer MFMAs and conversion ops.  BM_PAIR_PLANES forces 2 or 3.
+  int planes = tuning().pair_planes;
+  if (planes != 2 && planes != 3) planes = (d >= ((int64_t)1 << 17)) ? 2 : 3;
   int rc;
   switch (K) {
 #define BM_B3_CASE(KK) \
-  case KK: rc = launch_gram3<KK>(tab, n, d, aligned, centre, partial, blocks, s); break;
+  case KK: rc = launch_gram3<KK>(tab, n, d, aligned, centre, planes, partial, blocks, s); break;
     BM_B3_CASE(1) BM_B3_CASE(2) BM_B3_CASE(3) BM_B3_CASE(4) BM_B3_CASE(5) BM_B3_CASE(6) BM_B3_CASE(7)
     BM_B3_CASE(8) BM_B3_CASE(9) BM_B3_CASE(10) BM_B3_CASE(11) BM_B3_CASE(12) BM_B3_CASE(13) BM_B3_CASE(14)
     BM_B3_CASE(15) BM_B3_CASE(16)

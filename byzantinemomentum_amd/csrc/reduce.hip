@@ -360,7 +360,9 @@ extern "C" int bm_stack_stats(const float* const* rows, int k, int64_t d, float*
                               float* scaled_out, float scale, int attack_kind, double* out3, void* ws,
                               void* stream) {
   using namespace bm;
-  if (rows == nullptr || out3 == nullptr || ws == nullptr || k < 1 || k > BM_MAX_ROWS || d < 1 ||
+  // d == 0 is legal (an empty trailing shard): the finish kernel then writes zeros, so that every rank
+  // of a sharded job reaches its collective
+  if (rows == nullptr || out3 == nullptr || ws == nullptr || k < 1 || k > BM_MAX_ROWS || d < 0 ||
       (attack_kind != BM_ATTACK_EMPIRE && attack_kind != BM_ATTACK_LITTLE))
     return BM_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -404,7 +406,7 @@ extern "C" int bm_multi_dot(const float* const* core, int nc, const float* const
                             int64_t d, double* out, void* ws, void* stream) {
   using namespace bm;
   if (core == nullptr || out == nullptr || ws == nullptr || nc < 1 || nc > kMaxCore || ne < 0 ||
-      ne > kMaxExtra || (ne > 0 && extra == nullptr) || d < 1)
+      ne > kMaxExtra || (ne > 0 && extra == nullptr) || d < 0)
     return BM_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   DotTable tab{};

@@ -1,0 +1,429 @@
+// step.hip — the first pass of a simulation step fused into one kernel, plus the momentum /
+// clipping primitives of the other momentum placements.
+//
+// Replaces (reference, PyTorch, one launch and one host sync per line):
+//   grad.mul_(clip / grad.norm().item())  per sampled gradient                 attack.py:776-779,791-794
+//   gmtm.mul_(mu).add_(grad, alpha=1-damp)  per honest worker                   attack.py:800-804
+//   tools.compute_avg_dev_max(grad_sampleds), (grad_honests)                    attack.py:846-847
+//   grad_avg / grad_att / byz_grad of the "identical" attacks                   attacks/identical.py:63-86,129-141
+// bm_momentum_stats reads every sampled gradient and every momentum buffer ONCE and writes every
+// buffer once: 4*d*(ks + 2h + 3) bytes instead of the 4*d*(3h + (h+2) + (ks+1)) of separate
+// momentum / honest-statistics / sampled-statistics passes (63 against 103 row passes at ks = h = 20).
+//
+// Layout: lane <-> VEC consecutive coordinates, the ks + h values of a column group live in
+// VGPRs (two-pass deviations without re-reading), row base pointers come from the kernarg
+// table; reductions leave the kernel as fp64 per-workgroup partials and are finished in a fixed
+// order by a one-wave kernel: deterministic, no float atomics, no host synchronisation.
+#include "bm_common.h"
+
+namespace bm {
+
+constexpr int kStepBlock = 256;
+constexpr int kStepMaxBlocks = 2048;
+
+struct StepTable {
+  const float* g[BM_MAX_ROWS];  // sampled gradients (ks)
+  float* b[BM_MAX_ROWS];        // momentum buffers (h), updated in place
+};
+
+// NaN-propagating max of |.| partials across a workgroup; result valid on thread 0
+template <int BLOCK>
+__device__ __forceinline__ float block_reduce_absmax(float m, float* lds) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float o = __shfl_down(m, off, 64);
+    m = (m != m || o != o) ? __builtin_nanf("") : fmaxf(m, o);
+  }
+  if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = m;
+  __syncthreads();
+  float r = 0.0f;
+  if (threadIdx.x == 0) {
+    r = lds[0];
+    for (int w = 1; w < BLOCK / 64; ++w) {
+      const float o = lds[w];
+      r = (r != r || o != o) ? __builtin_nanf("") : fmaxf(r, o);
+    }
+  }
+  __syncthreads();
+  return r;
+}
+
+// T = compile-time bound on max(ks, h); rows beyond ks / h are predicated off (wave-uniform).
+template <int T, int VEC>
+__global__ __launch_bounds__(kStepBlock) void momentum_stats_kernel(
+    StepTable tab, int ks, int h, int64_t nvec, float mu, float omd, const float* __restrict__ clipf,
+    float* __restrict__ s_avg_out, float* __restrict__ h_avg_out, float* __restrict__ byz_out, float scale,
+    int attack_kind, double* __restrict__ partial) {
+  __shared__ double red[kStepBlock / 64];
+  __shared__ float mred[kStepBlock / 64];
+  const float fks = (float)ks, fh = (float)h;
+  float n2s = 0.0f, dvs = 0.0f, mxs = 0.0f, n2h = 0.0f, dvh = 0.0f, mxh = 0.0f;
+  bool nan_s = false, nan_h = false;
+  // per-row clipping factors (attack.py:791-794): wave-uniform scalars
+  float cf[T];
+#pragma unroll
+  for (int i = 0; i < T; ++i) cf[i] = (clipf != nullptr && i < ks) ? clipf[i] : 1.0f;
+  const int64_t stride = (int64_t)gridDim.x * kStepBlock;
+  for (int64_t v = (int64_t)blockIdx.x * kStepBlock + threadIdx.x; v < nvec; v += stride) {
+    float g[T][VEC], b[T][VEC];
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+      if (i < ks) load_stream<VEC>(tab.g[i] + v * VEC, g[i]);
+      if (i < h) load_stream<VEC>(tab.b[i] + v * VEC, b[i]);
+    }
+    // clip, then momentum: gmtm.mul_(mu).add_(grad, alpha=1-damp) = fma(1-damp, grad, round(mu*gmtm))
+#pragma unroll
+    for (int i = 0; i < T; ++i) {
+      if (i < ks && clipf != nullptr) {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) g[i][c] *= cf[i];
+      }
+      if (i < h) {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) b[i][c] = __builtin_fmaf(omd, g[i][c], mu * b[i][c]);
+        store_stream<VEC>(tab.b[i] + v * VEC, b[i]);
+      }
+    }
+    float sa[VEC], ha[VEC], bz[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      // sampled stack: sequential mean, ||avg||^2, max|avg|, sum_i ||s_i - avg||^2 (tools/pytorch.py:105-125)
+      float s = g[0][c];
+#pragma unroll
+      for (int i = 1; i < T; ++i)
+        if (i < ks) s += g[i][c];
+      s = s / fks;
+      sa[c] = s;
+      n2s = __builtin_fmaf(s, s, n2s);
+      mxs = fmaxf(mxs, __builtin_fabsf(s));
+      nan_s |= (s != s);
+      float q = 0.0f;
+#pragma unroll
+      for (int i = 0; i < T; ++i)
+        if (i < ks) {
+          const float df = g[i][c] - s;
+          q = __builtin_fmaf(df, df, q);
+        }
+      dvs += q;
+      // honest stack = the updated momentum buffers
+      float t = b[0][c];
+#pragma unroll
+      for (int i = 1; i < T; ++i)
+        if (i < h) t += b[i][c];
+      t = t / fh;
+      ha[c] = t;
+      n2h = __builtin_fmaf(t, t, n2h);
+      mxh = fmaxf(mxh, __builtin_fabsf(t));
+      nan_h |= (t != t);
+      float qh = 0.0f;
+#pragma unroll
+      for (int i = 0; i < T; ++i)
+        if (i < h) {
+          const float df = b[i][c] - t;
+          qh = __builtin_fmaf(df, df, qh);
+        }
+      dvh += qh;
+      // empire: grad_att = grad_avg.neg();  little: grad_att = grad_stck.var(dim=0).sqrt_()
+      const float dir = (attack_kind == BM_ATTACK_LITTLE) ? __builtin_sqrtf(qh / (fh - 1.0f)) : -t;
+      bz[c] = t + dir * scale;  // grad_att.mul_(factor); byz_grad = grad_avg.add_(grad_att)
+    }
+    if (s_avg_out != nullptr) store_stream<VEC>(s_avg_out + v * VEC, sa);
+    if (h_avg_out != nullptr) store_stream<VEC>(h_avg_out + v * VEC, ha);
+    if (byz_out != nullptr) store_stream<VEC>(byz_out + v * VEC, bz);
+  }
+  if (nan_s) mxs = __builtin_nanf("");  // torch's abs().max() propagates NaN; fmaxf does not
+  if (nan_h) mxh = __builtin_nanf("");
+  const double r0 = block_reduce_sum<kStepBlock>((double)n2s, red);
+  const double r1 = block_reduce_sum<kStepBlock>((double)dvs, red);
+  const double r3 = block_reduce_sum<kStepBlock>((double)n2h, red);
+  const double r4 = block_reduce_sum<kStepBlock>((double)dvh, red);
+  const float r2 = block_reduce_absmax<kStepBlock>(mxs, mred);
+  const float r5 = block_reduce_absmax<kStepBlock>(mxh, mred);
+  if (threadIdx.x == 0) {
+    double* p = partial + (int64_t)blockIdx.x * 6;
+    p[0] = r0;
+    p[1] = r1;
+    p[2] = (double)r2;
+    p[3] = r3;
+    p[4] = r4;
+    p[5] = (double)r5;
+  }
+}
+
+// Fixed-order reduction of [nparts][6] partials: slots 0,1,3,4 are sums, 2 and 5 NaN-propagating maxima.
+__global__ __launch_bounds__(64) void step_finish_kernel(const double* __restrict__ partial, int nparts,
+                                                         double* __restrict__ out6) {
+  const int lane = threadIdx.x;
+  double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+  bool nan2 = false, nan5 = false;
+  for (int b = lane; b < nparts; b += 64) {
+    const double* p = partial + (int64_t)b * 6;
+    s[0] += p[0];
+    s[1] += p[1];
+    s[3] += p[3];
+    s[4] += p[4];
+    nan2 |= (p[2] != p[2]);
+    nan5 |= (p[5] != p[5]);
+    s[2] = p[2] > s[2] ? p[2] : s[2];
+    s[5] = p[5] > s[5] ? p[5] : s[5];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    s[0] += __shfl_down(s[0], off, 64);
+    s[1] += __shfl_down(s[1], off, 64);
+    s[3] += __shfl_down(s[3], off, 64);
+    s[4] += __shfl_down(s[4], off, 64);
+    const double o2 = __shfl_down(s[2], off, 64), o5 = __shfl_down(s[5], off, 64);
+    s[2] = o2 > s[2] ? o2 : s[2];
+    s[5] = o5 > s[5] ? o5 : s[5];
+    nan2 |= (bool)__shfl_down((int)nan2, off, 64);
+    nan5 |= (bool)__shfl_down((int)nan5, off, 64);
+  }
+  if (lane == 0) {
+    out6[0] = s[0];
+    out6[1] = s[1];
+    out6[2] = nan2 ? __builtin_nan("") : s[2];
+    out6[3] = s[3];
+    out6[4] = s[4];
+    out6[5] = nan5 ? __builtin_nan("") : s[5];
+  }
+}
+
+template <int T, int VEC>
+static int launch_momentum_stats(const StepTable& tab, int ks, int h, int64_t nvec, float mu, float omd,
+                                 const float* clipf, float* s_avg, float* h_avg, float* byz, float scale, int kind,
+                                 double* partial, int grid, hipStream_t s) {
+  hipLaunchKernelGGL((momentum_stats_kernel<T, VEC>), dim3(grid), dim3(kStepBlock), 0, s, tab, ks, h, nvec, mu, omd,
+                     clipf, s_avg, h_avg, byz, scale, kind, partial);
+  BM_LAUNCH_CHECK();
+  return 0;
+}
+
+// Tiers by max(ks, h): registers hold 2 * T * VEC values per lane.
+template <int VEC>
+static int dispatch_momentum_stats(const StepTable& tab, int ks, int h, int64_t nvec, float mu, float omd,
+                                   const float* clipf, float* s_avg, float* h_avg, float* byz, float scale, int kind,
+                                   double* partial, int grid, hipStream_t s) {
+  const int t = ks > h ? ks : h;
+#define BM_STEP_ARGS tab, ks, h, nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial, grid, s
+  if (t <= 8) return launch_momentum_stats<8, VEC>(BM_STEP_ARGS);
+  if (t <= 12) return launch_momentum_stats<12, VEC>(BM_STEP_ARGS);
+  if (t <= 20) return launch_momentum_stats<20, VEC>(BM_STEP_ARGS);
+  if constexpr (VEC <= 2) {
+    if (t <= 40) return launch_momentum_stats<40, VEC>(BM_STEP_ARGS);
+  }
+  if constexpr (VEC == 1) return launch_momentum_stats<64, 1>(BM_STEP_ARGS);
+#undef BM_STEP_ARGS
+  return BM_EINVAL;  // caller picks a narrower vector
+}
+
+// ---------------------------------------------------------------------------
+// out_i = fma(b, q_i, a * (c_i * p_i)) for k vectors: every momentum placement of attack.py
+//   worker : out = p = buffer, q = gradient, a = mu, b = 1-damp                     attack.py:800-804
+//   server : out = new,  p = gradient, a = 1-damp, q = server momentum (shared), b = mu   attack.py:805-808
+//   update : out = p = server momentum, q = defense gradient, a = mu, b = 1-damp (k = 1)   attack.py:838-839
+//   nesterov look-ahead: out = p = parameters, q = momentum, a = 1, b = -mu*lr             attack.py:762,767
+// c_i: optional per-row device scalars (the clipping factors), applied to p_i.
+// ---------------------------------------------------------------------------
+struct Fma3Table {
+  float* out[BM_MAX_ROWS];
+  const float* p[BM_MAX_ROWS];
+  const float* q[BM_MAX_ROWS];
+};
+
+template <int VEC>
+__global__ __launch_bounds__(kStepBlock) void multi_fma3_kernel(Fma3Table tab, int64_t nvec, float a, float b,
+                                                                const float* __restrict__ pscale) {
+  float* out = tab.out[blockIdx.y];
+  const float* p = tab.p[blockIdx.y];
+  const float* q = tab.q[blockIdx.y];
+  const float c = pscale != nullptr ? pscale[blockIdx.y] : 1.0f;
+  const int64_t stride = (int64_t)gridDim.x * kStepBlock;
+  for (int64_t v = (int64_t)blockIdx.x * kStepBlock + threadIdx.x; v < nvec; v += stride) {
+    float pp[VEC], qq[VEC];
+    load_stream<VEC>(p + v * VEC, pp);
+    load_stream<VEC>(q + v * VEC, qq);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float x = pscale != nullptr ? pp[e] * c : pp[e];
+      pp[e] = __builtin_fmaf(b, qq[e], a * x);
+    }
+    store_stream<VEC>(out + v * VEC, pp);
+  }
+}
+
+// y_i *= c_i in place, rows with c_i == 1 untouched (no traffic): the in-place gradient clipping of
+// attack.py:776-779,791-794 once the factors are known.
+struct ScaleTable {
+  float* y[BM_MAX_ROWS];
+};
+template <int VEC>
+__global__ __launch_bounds__(kStepBlock) void multi_scale_kernel(ScaleTable tab, int64_t nvec,
+                                                                 const float* __restrict__ factors) {
+  const float c = factors[blockIdx.y];
+  if (c == 1.0f) return;
+  float* y = tab.y[blockIdx.y];
+  const int64_t stride = (int64_t)gridDim.x * kStepBlock;
+  for (int64_t v = (int64_t)blockIdx.x * kStepBlock + threadIdx.x; v < nvec; v += stride) {
+    float yy[VEC];
+    load_stream<VEC>(y + v * VEC, yy);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) yy[e] *= c;
+    store_stream<VEC>(y + v * VEC, yy);
+  }
+}
+
+// factors_i = clip / ||g_i|| if ||g_i|| > clip else 1 (attack.py:791-794), from squared norms on the device
+__global__ __launch_bounds__(64) void clip_factors_kernel(const double* __restrict__ row_sq, int k, float clip,
+                                                          float* __restrict__ factors) {
+  const int i = threadIdx.x;
+  if (i >= k) return;
+  const double norm = sqrt(row_sq[i]);
+  factors[i] = (norm > (double)clip) ? (float)((double)clip / norm) : 1.0f;
+}
+
+static inline int vec_of(uintptr_t bits) { return (bits & 15u) == 0 ? 4 : ((bits & 7u) == 0 ? 2 : 1); }
+
+}  // namespace bm
+
+extern "C" int bm_momentum_stats(const float* const* sampled, int ks, float* const* buffers, int h, int64_t d,
+                                 float mu, float one_minus_damp, const float* clip_factors, float* sampled_avg,
+                                 float* honest_avg, float* byz_out, float scale, int attack_kind, double* out6,
+                                 void* ws, void* stream) {
+  using namespace bm;
+  if (sampled == nullptr || buffers == nullptr || out6 == nullptr || ws == nullptr || h < 1 || ks < h ||
+      ks > BM_MAX_ROWS || d < 0 || (attack_kind != BM_ATTACK_EMPIRE && attack_kind != BM_ATTACK_LITTLE))
+    return BM_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  StepTable tab{};
+  uintptr_t bits = reinterpret_cast<uintptr_t>(sampled_avg) | reinterpret_cast<uintptr_t>(honest_avg) |
+                   reinterpret_cast<uintptr_t>(byz_out);
+  for (int i = 0; i < ks; ++i) {
+    tab.g[i] = sampled[i];
+    bits |= reinterpret_cast<uintptr_t>(sampled[i]);
+  }
+  for (int i = 0; i < h; ++i) {
+    tab.b[i] = buffers[i];
+    bits |= reinterpret_cast<uintptr_t>(buffers[i]);
+  }
+  double* partial = static_cast<double*>(ws);
+  int vec = vec_of(bits);
+  const int t = ks > h ? ks : h;
+  if (t > 20 && vec > 2) vec = 2;   // register budget: 2*T*VEC values per lane
+  if (t > 40) vec = 1;
+  int nparts = 0;
+  int64_t body = 0;
+  int rc = 0;
+  if (vec >= 2 && d / vec > 0) {
+    const int64_t nvec = d / vec;
+    const int grid = stream_grid(nvec, kStepBlock, kStepMaxBlocks - 1);
+    rc = (vec == 4) ? dispatch_momentum_stats<4>(tab, ks, h, nvec, mu, one_minus_damp, clip_factors, sampled_avg,
+                                                  honest_avg, byz_out, scale, attack_kind, partial, grid, s)
+                    : dispatch_momentum_stats<2>(tab, ks, h, nvec, mu, one_minus_damp, clip_factors, sampled_avg,
+                                                  honest_avg, byz_out, scale, attack_kind, partial, grid, s);
+    if (rc != 0) return rc;
+    nparts = grid;
+    body = nvec * vec;
+  }
+  if (body < d) {
+    StepTable tail = tab;
+    for (int i = 0; i < ks; ++i) tail.g[i] += body;
+    for (int i = 0; i < h; ++i) tail.b[i] += body;
+    const int64_t rest = d - body;
+    const int grid = (body == 0) ? stream_grid(rest, kStepBlock, kStepMaxBlocks) : 1;
+    rc = dispatch_momentum_stats<1>(tail, ks, h, rest, mu, one_minus_damp, clip_factors,
+                                    sampled_avg ? sampled_avg + body : nullptr,
+                                    honest_avg ? honest_avg + body : nullptr, byz_out ? byz_out + body : nullptr,
+                                    scale, attack_kind, partial + (int64_t)nparts * 6, grid, s);
+    if (rc != 0) return rc;
+    nparts += grid;
+  }
+  // d == 0: nparts == 0 and the finish kernel writes zeros — every rank of a sharded job reaches its collective
+  hipLaunchKernelGGL(step_finish_kernel, dim3(1), dim3(64), 0, s, partial, nparts, out6);
+  BM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int bm_multi_fma3(float* const* out, const float* const* p, const float* const* q, int k, int64_t d,
+                             float a, float b, const float* p_scale, void* stream) {
+  using namespace bm;
+  if (out == nullptr || p == nullptr || q == nullptr || k < 1 || k > BM_MAX_ROWS || d < 0) return BM_EINVAL;
+  if (d == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  Fma3Table tab{};
+  uintptr_t bits = 0;
+  for (int i = 0; i < k; ++i) {
+    tab.out[i] = out[i];
+    tab.p[i] = p[i];
+    tab.q[i] = q[i];
+    bits |= reinterpret_cast<uintptr_t>(out[i]) | reinterpret_cast<uintptr_t>(p[i]) | reinterpret_cast<uintptr_t>(q[i]);
+  }
+  const int vec = vec_of(bits);
+  int64_t body = 0;
+  if (vec >= 2 && d / vec > 0) {
+    const int64_t nvec = d / vec;
+    const int grid = stream_grid(nvec, kStepBlock, 2048);
+    if (vec == 4)
+      hipLaunchKernelGGL(multi_fma3_kernel<4>, dim3(grid, k), dim3(kStepBlock), 0, s, tab, nvec, a, b, p_scale);
+    else
+      hipLaunchKernelGGL(multi_fma3_kernel<2>, dim3(grid, k), dim3(kStepBlock), 0, s, tab, nvec, a, b, p_scale);
+    BM_LAUNCH_CHECK();
+    body = nvec * vec;
+  }
+  if (body < d) {
+    Fma3Table tail = tab;
+    for (int i = 0; i < k; ++i) {
+      tail.out[i] += body;
+      tail.p[i] += body;
+      tail.q[i] += body;
+    }
+    const int64_t rest = d - body;
+    hipLaunchKernelGGL(multi_fma3_kernel<1>, dim3(stream_grid(rest, kStepBlock, 2048), k), dim3(kStepBlock), 0, s,
+                       tail, rest, a, b, p_scale);
+    BM_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int bm_multi_scale(float* const* y, int k, int64_t d, const float* factors, void* stream) {
+  using namespace bm;
+  if (y == nullptr || factors == nullptr || k < 1 || k > BM_MAX_ROWS || d < 0) return BM_EINVAL;
+  if (d == 0) return 0;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  ScaleTable tab{};
+  uintptr_t bits = 0;
+  for (int i = 0; i < k; ++i) {
+    tab.y[i] = y[i];
+    bits |= reinterpret_cast<uintptr_t>(y[i]);
+  }
+  const int vec = vec_of(bits);
+  int64_t body = 0;
+  if (vec >= 2 && d / vec > 0) {
+    const int64_t nvec = d / vec;
+    const int grid = stream_grid(nvec, kStepBlock, 2048);
+    if (vec == 4)
+      hipLaunchKernelGGL(multi_scale_kernel<4>, dim3(grid, k), dim3(kStepBlock), 0, s, tab, nvec, factors);
+    else
+      hipLaunchKernelGGL(multi_scale_kernel<2>, dim3(grid, k), dim3(kStepBlock), 0, s, tab, nvec, factors);
+    BM_LAUNCH_CHECK();
+    body = nvec * vec;
+  }
+  if (body < d) {
+    ScaleTable tail = tab;
+    for (int i = 0; i < k; ++i) tail.y[i] += body;
+    const int64_t rest = d - body;
+    hipLaunchKernelGGL(multi_scale_kernel<1>, dim3(stream_grid(rest, kStepBlock, 2048), k), dim3(kStepBlock), 0, s,
+                       tail, rest, factors);
+    BM_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int bm_clip_factors(const double* row_sq, int k, float clip, float* factors_out, void* stream) {
+  using namespace bm;
+  if (row_sq == nullptr || factors_out == nullptr || k < 1 || k > BM_MAX_ROWS || !(clip > 0.0f)) return BM_EINVAL;
+  hipLaunchKernelGGL(clip_factors_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), row_sq, k, clip,
+                     factors_out);
+  BM_LAUNCH_CHECK();
+  return 0;
+}

@@ -246,17 +246,22 @@ def bulyan(gradients, f, m=None, **kwargs):
   return bulyan_pass2(gradients, order, f, m)
 
 
-def brute_selection(gradients, f, **kwargs):
-  """Index set (ascending) of the n-f rows of smallest diameter (aggregators/brute.py:32-68)."""
-  n, d, device = _validate(gradients)
+def brute_select_host(dist_host, n, f):
+  """Subset search of the Brute rule on a HOST fp64 n x n distance matrix (aggregators/brute.py:47-68)."""
   lib = _lib.load()
-  # brute keeps non-finite distances as they are and skips the subsets that contain one
-  dist = pairwise_sqdist(gradients).sqrt().cpu().contiguous()  # the subset search is host work
   sel = (ctypes.c_int32 * (n - f))()
-  rc = lib.bm_brute_select(ctypes.c_void_p(dist.data_ptr()), n, f, ctypes.cast(sel, ctypes.c_void_p))
+  rc = lib.bm_brute_select(ctypes.c_void_p(dist_host.data_ptr()), n, f, ctypes.cast(sel, ctypes.c_void_p))
   if rc != 0:
     raise RuntimeError("brute: too many non-finite gradients, no subset of n-f rows has a finite diameter")
   return list(sel)
+
+
+def brute_selection(gradients, f, **kwargs):
+  """Index set (ascending) of the n-f rows of smallest diameter (aggregators/brute.py:32-68)."""
+  n, d, device = _validate(gradients)
+  # brute keeps non-finite distances as they are and skips the subsets that contain one
+  dist = pairwise_sqdist(gradients).sqrt().cpu().contiguous()  # the subset search is host work
+  return brute_select_host(dist, n, f)
 
 
 def brute(gradients, f, **kwargs):

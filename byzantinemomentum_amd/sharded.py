@@ -10,7 +10,8 @@ the path.  Every rank holds the SAME n workers but only its slice [lo, hi) of th
     never a d-sized collective) gives every rank the same matrix, and every rank runs the same
     deterministic score/rank kernel -> identical selections without further traffic;
   * Aksel: all-reduce of the n partial squared distances to the (local) median slices;
-  * statistics: all-reduce(sum) of the two sums, all-reduce(max) of max|avg|;
+  * statistics: ONE all-gather of the packed per-rank scalars (sums and maxima together), reduced
+    locally in rank order (`exchange`);
   * the full aggregated vector, when a consumer needs it on every rank, is ONE all-gather of the
     d/P slices (the only bandwidth collective: 7 peers on 7 links in parallel).
 
@@ -47,6 +48,8 @@ class HipBackend:
     self.gars = gars
     self.stats = stats
 
+  # -- aggregation rules ------------------------------------------------------ #
+
   def pairwise_sqdist(self, gradients):
     return self.gars.pairwise_sqdist(gradients)
 
@@ -69,8 +72,34 @@ class HipBackend:
   def argsort(self, keys, n):
     return self.gars.stable_argsort(keys, n)
 
-  def stack_stats(self, samples):
-    return self.stats.stack_stats_async(samples)
+  def brute_select(self, dist_host, n, f):
+    return self.gars.brute_select_host(dist_host, n, f)
+
+  def index_tensor(self, indices, like):
+    return torch.tensor(indices, dtype=torch.int32, device=like.device)
+
+  # -- step statistics and momentum -------------------------------------------- #
+
+  def stack_stats(self, samples, scale=None, attack="empire"):
+    return self.stats.stack_stats_async(samples, scale=scale, attack=attack)
+
+  def momentum_stats(self, sampled, buffers, mu, omd, factors, scale, attack):
+    return self.stats.momentum_stats(sampled, buffers, mu, omd, factors, scale, attack)
+
+  def multi_fma3(self, outs, ps, qs, a, b, p_scale=None):
+    return self.stats.multi_fma3(outs, ps, qs, a, b, p_scale)
+
+  def multi_scale(self, ys, factors):
+    return self.stats.multi_scale(ys, factors)
+
+  def row_sqnorms(self, gradients):
+    return self.stats.row_sqnorms(gradients).contiguous()
+
+  def clip_factors_from_sq(self, sq, k, clip):
+    return self.stats.clip_factors_from_sq(sq, k, clip)
+
+  def study_dots(self, core, extra):
+    return self.stats.study_dots(core, extra)
 
 
 class ShardedAggregator:
@@ -92,6 +121,26 @@ class ShardedAggregator:
     if self.collective:
       dist.all_reduce(tensor, op=(op or dist.ReduceOp.SUM), group=self.group)
     return tensor
+
+  def all_reduce_sum(self, tensor):
+    """In-place sum over the ranks of a small device tensor (no-op with one rank)."""
+    return self._all_reduce(tensor)
+
+  def exchange(self, sums, maxes):
+    """ONE collective for every scalar of a step: each rank contributes [sums | maxes] (fp64), an
+    all-gather hands every rank all contributions, which it reduces itself in rank order — sums and
+    (NaN-propagating) maxima from the same message, bitwise identical on every rank."""
+    if not self.collective:
+      return sums, maxes
+    ns = sums.shape[0]
+    mine = torch.cat([sums, maxes]).contiguous()
+    everyone = torch.empty(self.world_size * mine.shape[0], dtype=mine.dtype, device=mine.device)
+    dist.all_gather_into_tensor(everyone, mine, group=self.group)
+    everyone = everyone.view(self.world_size, -1)
+    total = everyone[0, :ns].clone()
+    for r in range(1, self.world_size):
+      total += everyone[r, :ns]
+    return total, everyone[:, ns:].max(dim=0).values
 
   def all_gather_output(self, local_out, d):
     """Full d-vector on every rank from the per-rank slices (shard_bounds layout)."""
@@ -147,20 +196,31 @@ class ShardedAggregator:
     self._all_reduce(sq)
     return self.backend.selected_mean(local, self.backend.argsort(sq, n), count)
 
+  def brute(self, local, f):
+    """Brute rule: all-reduced distances, the (deterministic) subset search on every rank's host."""
+    n = len(local)
+    dist_host = self.global_sqdist(local).sqrt().cpu().contiguous()
+    sel = self.backend.brute_select(dist_host, n, f)
+    return self.backend.selected_mean(local, self.backend.index_tensor(sel, local[0]), n - f)
+
+  def average(self, local):
+    n = len(local)
+    return self.backend.selected_mean(local, self.backend.index_tensor(list(range(n)), local[0]), n)
+
+  def cge(self, local, f):
+    n = len(local)
+    sq = self.backend.row_sqnorms(local)
+    self._all_reduce(sq)
+    return self.backend.selected_mean(local, self.backend.argsort(sq, n), n - f)
+
   def compute_avg_dev_max(self, local_samples):
     """Sharded tools.compute_avg_dev_max: (local slice of the average, norm, deviation, max)."""
     k = len(local_samples)
     if k == 0:
       return None, math.nan, math.nan, math.nan
     avg, out3 = self.backend.stack_stats(local_samples)
-    if self.collective:
-      sums = out3[:2].clone()
-      mx = out3[2:].clone()
-      self._all_reduce(sums)
-      self._all_reduce(mx, dist.ReduceOp.MAX)
-      norm2, dev2 = sums.tolist()
-      amax = mx.item()
-    else:
-      norm2, dev2, amax = out3.tolist()
+    sums, mx = self.exchange(out3[:2], out3[2:])  # one collective (none with a single rank)
+    norm2, dev2 = sums.tolist()
+    amax = mx.item()
     dev = math.sqrt(dev2 / (k - 1)) if k >= 2 else math.nan
     return avg, math.sqrt(norm2), dev, amax

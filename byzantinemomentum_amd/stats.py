@@ -14,7 +14,8 @@ import torch
 from . import _lib
 from . import gars
 
-__all__ = ["compute_avg_dev_max", "stack_stats_async", "study_dots", "multi_axpby", "row_sqnorms"]
+__all__ = ["compute_avg_dev_max", "stack_stats_async", "study_dots", "multi_axpby", "row_sqnorms", "momentum_stats",
+           "multi_fma3", "clip_factors", "clip_factors_from_sq", "multi_scale", "clip_gradients", "l2_distance"]
 
 _ptr = gars._ptr
 
@@ -100,3 +101,95 @@ def multi_axpby(ys, xs, a, b):
     _lib.check(lib.bm_multi_axpby(_lib.pointer_table(ys), _lib.pointer_table(xs), k, d,
                                   ctypes.c_float(a), ctypes.c_float(b), gars._stream(device)),
                "bm_multi_axpby")
+
+
+def momentum_stats(sampled, buffers, mu, one_minus_damp, clip_factors_dev=None, attack_scale=None, attack="empire"):
+  """First pass of a step in one kernel (attack.py:791-804,846-847 and attacks/identical.py:63-86):
+  worker momentum in place on `buffers` (which then ARE the honest gradients), statistics of the
+  sampled stack and of the honest stack, and the Byzantine vector of an "identical" attack.
+
+  Returns (sampled_avg, honest_avg, byz or None, out6) with out6 a device fp64 tensor
+  [sum avg_s^2, sum_i |s_i-avg_s|^2, max|avg_s|, sum avg_h^2, sum_i |b_i-avg_h|^2, max|avg_h|]. No sync.
+  """
+  ks, d, device = gars._validate(list(sampled))
+  h, _, _ = gars._validate(list(buffers) + [sampled[0]])
+  h -= 1
+  if h < 1 or ks < h:
+    raise gars.GarInputError("momentum_stats needs 1 <= len(buffers) <= len(sampled)")
+  lib = _lib.load()
+  s_avg = torch.empty(d, dtype=torch.float32, device=device)
+  h_avg = torch.empty(d, dtype=torch.float32, device=device)
+  byz = torch.empty(d, dtype=torch.float32, device=device) if attack_scale is not None else None
+  out6 = torch.empty(6, dtype=torch.float64, device=device)
+  ws = gars._workspace(device, _lib.WS_STEP, 1, d, "ws_step")
+  gars.invalidate_rank_cache()
+  with torch.cuda.device(device):
+    _lib.check(lib.bm_momentum_stats(
+      _lib.pointer_table(sampled), ks, _lib.pointer_table(buffers), h, d, ctypes.c_float(mu),
+      ctypes.c_float(one_minus_damp), _ptr(clip_factors_dev) if clip_factors_dev is not None else None,
+      _ptr(s_avg), _ptr(h_avg), _ptr(byz) if byz is not None else None,
+      ctypes.c_float(attack_scale if attack_scale is not None else 0.0),
+      _lib.ATTACK_LITTLE if attack == "little" else _lib.ATTACK_EMPIRE, _ptr(out6), _ptr(ws),
+      gars._stream(device)), "bm_momentum_stats")
+  return s_avg, h_avg, byz, out6
+
+
+def multi_fma3(outs, ps, qs, a, b, p_scale_dev=None):
+  """out_i = b*q_i + a*(p_scale_i*p_i) for every triple (outs may alias ps; qs may repeat one tensor):
+  worker / server / update momentum and the Nesterov look-ahead of attack.py:757-810,832-839."""
+  outs, ps, qs = list(outs), list(ps), list(qs)
+  k, d, device = gars._validate(outs)
+  gars._validate(ps + [outs[0]])
+  gars._validate(qs + [outs[0]])
+  if len(ps) != k or len(qs) != k:
+    raise gars.GarInputError("multi_fma3 needs as many p and q as out vectors")
+  lib = _lib.load()
+  gars.invalidate_rank_cache()
+  with torch.cuda.device(device):
+    _lib.check(lib.bm_multi_fma3(_lib.pointer_table(outs), _lib.pointer_table(ps), _lib.pointer_table(qs), k, d,
+                                 ctypes.c_float(a), ctypes.c_float(b),
+                                 _ptr(p_scale_dev) if p_scale_dev is not None else None, gars._stream(device)),
+               "bm_multi_fma3")
+
+
+def clip_factors_from_sq(sq, k, clip):
+  """Device float32 factors from a device fp64 tensor of k squared norms (possibly all-reduced)."""
+  lib = _lib.load()
+  device = sq.device
+  if not sq.is_contiguous():
+    sq = sq.contiguous()
+  factors = torch.empty(_lib.MAX_ROWS, dtype=torch.float32, device=device)
+  with torch.cuda.device(device):
+    _lib.check(lib.bm_clip_factors(_ptr(sq), k, ctypes.c_float(clip), _ptr(factors), gars._stream(device)),
+               "bm_clip_factors")
+  return factors
+
+
+def clip_factors(gradients, clip):
+  """Device float32[k]: clip/||g_i|| where ||g_i|| > clip, else 1 (attack.py:791-794). No sync."""
+  k, d, device = gars._validate(gradients)
+  return clip_factors_from_sq(row_sqnorms(gradients), k, clip)
+
+
+def multi_scale(ys, factors_dev):
+  """y_i *= factors[i] in place; rows whose factor is exactly 1 are not touched."""
+  ys = list(ys)
+  k, d, device = gars._validate(ys)
+  lib = _lib.load()
+  gars.invalidate_rank_cache()
+  with torch.cuda.device(device):
+    _lib.check(lib.bm_multi_scale(_lib.pointer_table(ys), k, d, _ptr(factors_dev), gars._stream(device)),
+               "bm_multi_scale")
+
+
+def clip_gradients(gradients, clip):
+  """In-place gradient clipping of attack.py:776-779,791-794 for a whole list, without a host sync."""
+  factors = clip_factors(gradients, clip)
+  multi_scale(gradients, factors)
+  return factors
+
+
+def l2_distance(a, b):
+  """||a - b||_2 as a device fp64 scalar tensor (attack.py:830 `l2_origin`), no sync.  Two rows through
+  the centred pairwise kernel: the centre is row 0, so the contraction sees a - b itself (no cancellation)."""
+  return gars.pairwise_sqdist([a, b])[0, 1].sqrt()

@@ -1,14 +1,25 @@
-"""One aggregation step of the simulation loop on the HIP path (mirror of attack.py:800-878).
+"""One aggregation step of the simulation loop on the HIP path (mirror of attack.py:757-878).
 
 Given the sampled honest gradients of a step it performs, without leaving the GPU:
-  1. worker-side momentum        buf_i <- mu*buf_i + (1-damp)*g_i            attack.py:800-804
-  2. the "empire" / "little" attack  byz = avg_h + factor*dir, repeated f      attacks/identical.py:63-86,129-141
-     fused with the honest-stack statistics (one pass over the honest stack)  attack.py:847
-  3. the aggregation rule         defense = GAR(honests + [byz]*f, f)          attack.py:821
-  4. the study statistics         sampled / attack stacks, defense norm and max, six cosines,
-                                  previous-step cosine and curvature           attack.py:842-868
-The model update itself (attack.py:832-839) belongs to the caller.  Everything is asynchronous
-on the current stream until `AggregationStep.floats()` fetches the scalars (one sync).
+  0. gradient clipping             g_i <- g_i * clip/||g_i|| where ||g_i|| > clip   attack.py:776-779,791-794
+  1. momentum, by placement        worker: buf_i <- mu*buf_i + (1-damp)*g_i            attack.py:800-804
+                                   server: hon_i  = (1-damp)*g_i + mu*M                attack.py:805-808
+                                   update / none: hon_i = g_i                          attack.py:809-810
+  2. the "empire" / "little" attack  byz = avg_h + factor*dir, repeated f_real times   attacks/identical.py:63-86,129-141
+  3. the aggregation rule          defense = GAR(honests + [byz]*f, f)                 attack.py:821
+  4. the momentum of the update    server: M <- defense; update: M <- mu*M + (1-damp)*defense   attack.py:832-839
+  5. the study statistics          sampled / honest / attack stacks, defense norm and max, six cosines,
+                                   previous-step cosine and curvature, l2 distance from the origin   attack.py:828-868
+With worker momentum, steps 0-2 and the sampled/honest statistics of step 5 are ONE kernel
+(bm_momentum_stats): every sampled gradient and every momentum buffer is read once.
+
+The step shards along the coordinates like the rules do (sharded.ShardedAggregator): every rank
+passes its slice of every tensor; scalars are exchanged in at most three small collectives per
+step (row norms if clipping, the n x n squared distances if the rule needs them, and one packed
+vector of every statistic), never a d-sized one.  With one rank no collective is issued.
+The model update itself (optimizer step) belongs to the caller: `update_gradient()` returns what
+attack.py hands to `model.update`.  Everything is asynchronous on the current stream until
+`floats()` fetches the scalars (one sync).
 """
 
 import collections
@@ -16,79 +27,187 @@ import math
 
 import torch
 
-from . import gars
-from . import stats
-
 __all__ = ["AggregationStep"]
 
-_RULES = {"krum": gars.krum, "bulyan": gars.bulyan, "median": gars.median, "trmean": gars.trmean,
-          "phocas": gars.phocas, "meamed": gars.meamed, "aksel": gars.aksel, "brute": gars.brute,
-          "average": gars.average, "cge": gars.cge}
+_RULES = ("krum", "bulyan", "median", "trmean", "phocas", "meamed", "aksel", "brute", "average", "cge")
+_NEEDS_F = {"krum", "bulyan", "trmean", "phocas", "meamed", "aksel", "brute", "cge"}
+MAX_PAST = 32  # bm_multi_dot takes at most 32 extra vectors
 
 
 class AggregationStep:
   def __init__(self, nb_workers, nb_decl_byz, nb_real_byz, gar="krum", gar_args=None, momentum=0.99,
-               dampening=0.99, attack="empire", attack_factor=1.1, nb_past=25):
+               dampening=0.99, momentum_at="worker", attack="empire", attack_factor=1.1, nb_past=25,
+               gradient_clip=None, aggregator=None):
+    """aggregator: a sharded.ShardedAggregator (default: one over the default process group, or a
+    single-rank one when torch.distributed is not initialised)."""
     if gar not in _RULES:
       raise ValueError(f"unknown aggregation rule {gar!r}")
+    if momentum_at not in ("worker", "server", "update"):
+      raise ValueError(f"momentum_at must be 'worker', 'server' or 'update', got {momentum_at!r}")
+    if attack not in ("empire", "little"):
+      raise ValueError(f"unknown attack {attack!r} (empire: factor, little: factor, use a negative one for negative:True)")
+    if not 0 <= nb_past <= MAX_PAST:
+      raise ValueError(f"nb_past must be within 0..{MAX_PAST} (the fused dot kernel takes at most {MAX_PAST} past gradients)")
+    if aggregator is None:
+      from .sharded import ShardedAggregator
+      aggregator = ShardedAggregator()
+    self.agg = aggregator
+    self.ops = aggregator.backend
     self.n = nb_workers
     self.f_decl = nb_decl_byz
     self.f_real = nb_real_byz
     self.h = nb_workers - nb_real_byz
-    self.rule = _RULES[gar]
+    self.gar = gar
     self.gar_args = dict(gar_args or {})
     self.mu = momentum
     self.damp = dampening
-    if attack not in ("empire", "little"):
-      raise ValueError(f"unknown attack {attack!r} (empire: factor, little: factor, use a negative one for negative:True)")
+    self.momentum_at = momentum_at
     self.attack = attack
     self.factor = attack_factor
-    self.buffers = None                      # storage["momentum"]: one per honest worker (attack.py:676)
-    self.pasts = collections.deque(maxlen=nb_past)  # (sampled average, its squared norm tensor)
+    self.clip = gradient_clip
+    self.buffers = None        # worker placement: one momentum buffer per honest worker (attack.py:676)
+    self.server_momentum = None  # server / update placements: grad_momentum_server (attack.py:678)
+    self.pasts = collections.deque(maxlen=max(nb_past, 1))  # past sampled averages, newest first (attack.py:868)
+    self.nb_past = nb_past
+    self._prev_s2 = None       # device fp64[1]: (this rank's part of) the squared norm of pasts[0]
     self._pending = None
+    self._update = None
 
-  def run(self, grad_sampleds):
-    """grad_sampleds: list of >= h flat fp32 GPU tensors (the step's sampled gradients).
-    Returns the aggregated gradient; statistics stay on the device until floats()."""
-    h = self.h
+  # ------------------------------------------------------------------------ #
+
+  def _aggregate(self, gradients):
+    agg, f = self.agg, self.f_decl
+    if self.gar == "median":
+      return agg.median(gradients)
+    if self.gar == "average":
+      return agg.average(gradients)
+    return getattr(agg, self.gar)(gradients, f, **self.gar_args)
+
+  def nesterov_lookahead(self, params, lr, worker=None):
+    """params <- params - mu*lr*momentum in place (attack.py:760-767): the parameter shift before
+    the gradients of a Nesterov step are computed.  worker: index of the worker momentum buffer
+    (worker placement), else the server momentum."""
+    mom = self.buffers[worker] if worker is not None else self.server_momentum
+    if mom is not None:
+      self.ops.multi_fma3([params], [params], [mom], 1.0, -(self.mu * lr))
+    return params
+
+  def run(self, grad_sampleds, params=None, origin=None):
+    """grad_sampleds: list of >= h flat fp32 GPU tensors (this rank's slice of the step's sampled
+    gradients).  params/origin: optional flat parameter vectors for `l2_origin` (attack.py:830).
+    Returns the aggregated gradient (slice); statistics stay on the device until floats()."""
+    ops, agg, h = self.ops, self.agg, self.h
     sampled = list(grad_sampleds)
-    self._nb_sampled = len(sampled)
-    if self.buffers is None:
-      self.buffers = [torch.zeros_like(g) for g in sampled[:h]]
-    # 1. worker momentum in place; the buffers ARE the honest gradients the rule sees
-    stats.multi_axpby(self.buffers, sampled[:h], self.mu, 1.0 - self.damp)
-    honests = self.buffers
-    # 2. honest-stack statistics + empire vector in one pass
-    h_avg, h_out3, byz = stats.stack_stats_async(honests, scale=self.factor, attack=self.attack)
+    ks = len(sampled)
+    if ks < h:
+      raise ValueError(f"{ks} sampled gradients for {h} honest workers")
+    omd = 1.0 - self.damp
+    # 0. clipping factors (device scalars; the all-reduce makes them global under sharding)
+    factors = None
+    if self.clip is not None:
+      sq = ops.row_sqnorms(sampled)
+      agg.all_reduce_sum(sq)
+      factors = ops.clip_factors_from_sq(sq, ks, self.clip)
+    # 1.+2. momentum, attack vector, sampled/honest statistics
+    if self.momentum_at == "worker":
+      if self.buffers is None:
+        self.buffers = [torch.zeros_like(g) for g in sampled[:h]]
+      s_avg, h_avg, byz, out6 = ops.momentum_stats(sampled, self.buffers, self.mu, omd, factors, self.factor, self.attack)
+      honests = self.buffers
+      s_out3, h_out3 = out6[:3], out6[3:]
+    else:
+      if factors is not None:
+        ops.multi_scale(sampled, factors)  # in place, like the reference's grad.mul_
+      if self.momentum_at == "server" and self.server_momentum is not None:
+        honests = [torch.empty_like(g) for g in sampled[:h]]
+        ops.multi_fma3(honests, sampled[:h], [self.server_momentum] * h, omd, self.mu)
+      elif self.momentum_at == "server":
+        # first step: grad_momentum_server is zero (attack.py:678), hon_i = (1-damp)*g_i
+        honests = [torch.empty_like(g) for g in sampled[:h]]
+        zero = torch.zeros_like(sampled[0])
+        ops.multi_fma3(honests, sampled[:h], [zero] * h, omd, self.mu)
+      else:
+        honests = sampled[:h]
+      h_avg, h_out3, byz = ops.stack_stats(honests, scale=self.factor, attack=self.attack)
+      s_avg, s_out3 = ops.stack_stats(sampled)
     attacks = [byz] * self.f_real
     # 3. aggregation
-    if self.rule in (gars.median, gars.average):
-      defense = self.rule(honests + attacks)
+    defense = self._aggregate(honests + attacks)
+    # 4. momentum of the update
+    if self.momentum_at == "server":
+      self.server_momentum = defense          # no clone, as attack.py:835
+      self._update = defense
+    elif self.momentum_at == "update":
+      if self.server_momentum is None:
+        self.server_momentum = torch.zeros_like(defense)
+      ops.multi_fma3([self.server_momentum], [self.server_momentum], [defense], self.mu, omd)
+      self._update = self.server_momentum
     else:
-      defense = self.rule(honests + attacks, self.f_decl, **self.gar_args)
-    # 4. remaining statistics
-    s_avg, s_out3 = stats.stack_stats_async(sampled)
-    a_avg, a_out3 = stats.stack_stats_async(attacks) if self.f_real > 0 else (None, None)
-    _, d_out3 = stats.stack_stats_async([defense])
+      self._update = defense
+    # 5. remaining statistics
+    a_avg, a_out3 = ops.stack_stats(attacks) if self.f_real > 0 else (None, None)
+    _, d_out3 = ops.stack_stats([defense])
     core = [s_avg, h_avg, defense] + ([a_avg] if a_avg is not None else [])
-    gram, extra = stats.study_dots(core, [p for p, _ in self.pasts])
-    self._pending = (s_out3, h_out3, a_out3, d_out3, gram, extra, len(self.pasts), s_avg)
+    past_vecs = list(self.pasts) if self.nb_past > 0 else []
+    gram, extra = ops.study_dots(core, past_vecs)
+    l2 = ops.pairwise_sqdist([params, origin])[0, 1].reshape(1) if params is not None and origin is not None else None
+    self._pending = dict(s=s_out3, h=h_out3, a=a_out3, d=d_out3, gram=gram, extra=extra, npast=len(past_vecs),
+                         prev_s2=self._prev_s2 if past_vecs else None, l2=l2, ks=ks, floats=None)
+    # grad_pasts.appendleft(PastGrad(sampled_grad_avg, sampled_norm_avg))  (attack.py:868): every step,
+    # whether or not the scalars are fetched; the norm of the newest entry stays on the device
+    if self.nb_past > 0:
+      self.pasts.appendleft(s_avg)
+      self._prev_s2 = s_out3[:1]
     return defense
 
-  def floats(self):
-    """Python floats of the study row (attack.py:845-868) for the last run(); synchronises once."""
-    s_out3, h_out3, a_out3, d_out3, gram, extra, npast, s_avg = self._pending
-    parts = [s_out3, h_out3, d_out3, gram.reshape(-1), extra] + ([a_out3] if a_out3 is not None else [])
-    flat = torch.cat(parts).tolist()
-    s3, h3, d3 = flat[0:3], flat[3:6], flat[6:9]
-    nc = gram.shape[0]
-    g = [flat[9 + i * nc: 9 + (i + 1) * nc] for i in range(nc)]
-    ex = flat[9 + nc * nc: 9 + nc * nc + npast]
-    a3 = flat[9 + nc * nc + npast:] if a_out3 is not None else None
-    k_h, k_a = self.h, self.f_real
+  def update_gradient(self):
+    """What attack.py:832-839 passes to model.update(): the defense gradient (worker / server
+    placements) or the updated server momentum (update placement)."""
+    return self._update
 
-    def dev(out3, k):
-      return math.sqrt(out3[1] / (k - 1)) if k >= 2 else math.nan
+  # ------------------------------------------------------------------------ #
+
+  def _exchange(self, pend):
+    """One packed exchange of every scalar of the step: sums and maxima, all ranks."""
+    sums = [pend["s"][:2], pend["h"][:2], pend["d"][:2], pend["gram"].reshape(-1), pend["extra"]]
+    maxes = [pend["s"][2:], pend["h"][2:], pend["d"][2:]]
+    if pend["a"] is not None:
+      sums.append(pend["a"][:2])
+      maxes.append(pend["a"][2:])
+    if pend["l2"] is not None:
+      sums.append(pend["l2"])
+    if pend["prev_s2"] is not None:
+      sums.append(pend["prev_s2"])
+    sums, maxes = self.agg.exchange(torch.cat(sums), torch.cat(maxes))
+    return sums.tolist(), maxes.tolist()
+
+  def floats(self):
+    """Python floats of the study row (attack.py:828-868) for the last run(); synchronises once.
+    Idempotent: a second call returns the same dictionary without touching the device."""
+    pend = self._pending
+    if pend is None:
+      raise RuntimeError("floats() needs a run() first")
+    if pend["floats"] is not None:
+      return pend["floats"]
+    sums, maxes = self._exchange(pend)
+    it = iter(sums)
+    s2, sd = next(it), next(it)
+    h2, hd = next(it), next(it)
+    d2, _ = next(it), next(it)
+    nc = pend["gram"].shape[0]
+    g = [[next(it) for _ in range(nc)] for _ in range(nc)]
+    ex = [next(it) for _ in range(pend["npast"])]
+    a2 = ad = math.nan
+    if pend["a"] is not None:
+      a2, ad = next(it), next(it)
+    l2 = math.sqrt(next(it)) if pend["l2"] is not None else math.nan
+    prev_norm = math.sqrt(next(it)) if pend["prev_s2"] is not None else math.nan
+    smax, hmax, dmax = maxes[0], maxes[1], maxes[2]
+    amax = maxes[3] if pend["a"] is not None else math.nan
+    k_s, k_h, k_a = pend["ks"], self.h, self.f_real
+
+    def dev(v, k):
+      return math.sqrt(v / (k - 1)) if k >= 2 else math.nan
 
     def cos(i, j):
       if i >= nc or j >= nc:
@@ -96,22 +215,20 @@ class AggregationStep:
       return g[i][j] / math.sqrt(g[i][i]) / math.sqrt(g[j][j])
 
     res = {
-      "sampled_norm_avg": math.sqrt(s3[0]), "sampled_norm_dev": dev(s3, self._nb_sampled), "sampled_norm_max": s3[2],
-      "honest_norm_avg": math.sqrt(h3[0]), "honest_norm_dev": dev(h3, k_h), "honest_norm_max": h3[2],
-      "attack_norm_avg": math.sqrt(a3[0]) if a3 else math.nan, "attack_norm_dev": dev(a3, k_a) if a3 else math.nan,
-      "attack_norm_max": a3[2] if a3 else math.nan,
-      "defense_norm_avg": math.sqrt(d3[0]), "defense_norm_max": d3[2],
+      "l2_origin": l2,
+      "sampled_norm_avg": math.sqrt(s2), "sampled_norm_dev": dev(sd, k_s), "sampled_norm_max": smax,
+      "honest_norm_avg": math.sqrt(h2), "honest_norm_dev": dev(hd, k_h), "honest_norm_max": hmax,
+      "attack_norm_avg": math.sqrt(a2) if pend["a"] is not None else math.nan,
+      "attack_norm_dev": dev(ad, k_a) if pend["a"] is not None else math.nan, "attack_norm_max": amax,
+      "defense_norm_avg": math.sqrt(d2), "defense_norm_max": dmax,
       "cosin_splhon": cos(0, 1), "cosin_spldef": cos(0, 2), "cosin_hondef": cos(1, 2),
       "cosin_splatt": cos(0, 3), "cosin_honatt": cos(1, 3), "cosin_attdef": cos(3, 2),
     }
-    if npast > 0:
-      past_norm = self.pasts[0][1]
-      res["cosin_sampled"] = ex[0] / math.sqrt(s3[0]) / past_norm
-      res["curv_sampled"] = self.mu * sum(self.mu ** i * ex[i] for i in range(npast))
+    if pend["npast"] > 0:
+      res["cosin_sampled"] = ex[0] / math.sqrt(s2) / prev_norm
+      res["curv_sampled"] = self.mu * sum(self.mu ** i * ex[i] for i in range(pend["npast"]))
     else:
       res["cosin_sampled"] = math.nan
       res["curv_sampled"] = math.nan
-    # grad_pasts.appendleft(PastGrad(sampled_grad_avg, sampled_norm_avg))  (attack.py:868)
-    self.pasts.appendleft((s_avg, math.sqrt(s3[0])))
+    pend["floats"] = res
     return res
-

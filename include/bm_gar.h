@@ -57,7 +57,8 @@ enum bm_ws_kind {
   BM_WS_PAIRWISE = 0, /* bm_pairwise_sqdist            */
   BM_WS_AKSEL    = 1, /* bm_aksel_pass1                */
   BM_WS_STATS    = 2, /* bm_stack_stats                */
-  BM_WS_DOT      = 3  /* bm_multi_dot                  */
+  BM_WS_DOT      = 3, /* bm_multi_dot                  */
+  BM_WS_STEP     = 4  /* bm_momentum_stats             */
 };
 int64_t bm_workspace_bytes(int kind, int n, int64_t d);
 
@@ -131,6 +132,33 @@ int bm_stable_argsort(const double* keys, int n, int32_t* order_out, void* strea
  * `gmtm.mul_(mu).add_(grad, alpha=1-damp)` at attack.py:800-804. */
 int bm_multi_axpby(float* const* y, const float* const* x, int k, int64_t d,
                    float a, float b, void* stream);
+
+/* First pass of a simulation step in ONE kernel (attack.py:791-804,846-847 + attacks/identical.py:63-86):
+ *   s_i      = clip_factors[i] * sampled[i]                       (clip_factors NULL: s_i = sampled[i])
+ *   buffers[i] <- mu * buffers[i] + one_minus_damp * s_i, i < h   worker momentum, in place; these ARE
+ *                                                                  the honest gradients the rule sees
+ *   sampled_avg, honest_avg = sequential means of the ks sampled rows s_i / the h updated buffers
+ *   byz_out  = honest_avg + scale * (-honest_avg)                 BM_ATTACK_EMPIRE
+ *            = honest_avg + scale * sqrt(unbiased column variance) BM_ATTACK_LITTLE
+ *   out6     = { sum avg_s^2, sum_i ||s_i-avg_s||^2, max|avg_s|,  sum avg_h^2, sum_i ||b_i-avg_h||^2, max|avg_h| }
+ * i.e. tools.compute_avg_dev_max of both stacks (tools/pytorch.py:97-125) without re-reading them.
+ * ks >= h; any of sampled_avg / honest_avg / byz_out may be NULL.  ws: bm_workspace_bytes(BM_WS_STEP). */
+int bm_momentum_stats(const float* const* sampled, int ks, float* const* buffers, int h, int64_t d,
+                      float mu, float one_minus_damp, const float* clip_factors, float* sampled_avg,
+                      float* honest_avg, float* byz_out, float scale, int attack_kind, double* out6,
+                      void* ws, void* stream);
+
+/* out[i] = b * q[i] + a * (p_scale[i] * p[i]) for k vectors (p_scale: DEVICE array of k floats or NULL;
+ * entries of q may be one shared vector; out[i] may alias p[i]).  Every momentum placement of the loop:
+ * worker (attack.py:800-804), server (:805-808), update (:838-839), Nesterov look-ahead (:762,767). */
+int bm_multi_fma3(float* const* out, const float* const* p, const float* const* q, int k, int64_t d,
+                  float a, float b, const float* p_scale, void* stream);
+
+/* Gradient clipping (attack.py:776-779,791-794) without a host round trip:
+ * bm_clip_factors: factors[i] = clip/sqrt(row_sq[i]) if sqrt(row_sq[i]) > clip else 1 (device arrays);
+ * bm_multi_scale : y[i] *= factors[i] in place; rows whose factor is 1 are not touched. */
+int bm_clip_factors(const double* row_sq, int k, float clip, float* factors_out, void* stream);
+int bm_multi_scale(float* const* y, int k, int64_t d, const float* factors, void* stream);
 
 /* Brute subset search on the host (aggregators/brute.py:47-68): over all
  * C(n, n-f) subsets in lexicographic order, first subset of smallest diameter;

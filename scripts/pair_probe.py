@@ -74,9 +74,9 @@ def accuracy():
         f"rows3/5 all nonfinite {bool((~torch.isfinite(sq[3, [0, 1, 2, 4]])).all())} [{TAG}]", flush=True)
 
 
-def timing():
+def timing(ns=(25, 51, 16, 64)):
   d = 11173962
-  for n in (25, 51, 16, 64):
+  for n in ns:
     gen = torch.Generator(device="cuda").manual_seed(n)
     stacks = [[torch.randn(d, device="cuda", generator=gen) for _ in range(n)] for _ in range(2)]
     for i in range(3):
@@ -106,5 +106,6 @@ if __name__ == "__main__":
   what = sys.argv[1:] or ["acc", "time"]
   if "acc" in what:
     accuracy()
-  if "time" in what:
-    timing()
+  for w in what:
+    if w.startswith("time"):
+      timing(tuple(int(v) for v in w.split(":")[1].split(",")) if ":" in w else (25, 51, 16, 64))

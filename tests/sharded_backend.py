@@ -67,9 +67,78 @@ class OracleBackend:
     order = sorted(range(n), key=lambda i: vals[i])
     return torch.tensor(order + [0] * (64 - n), dtype=torch.int32)
 
-  def stack_stats(self, samples):
-    avg, _, _, _ = O.compute_avg_dev_max(samples)
+  def brute_select(self, dist_host, n, f):
+    import itertools
+    best, best_diam = None, None
+    for subset in itertools.combinations(range(n), n - f):
+      diam = 0.
+      for a, b in itertools.combinations(subset, 2):
+        v = dist_host[a, b].item()
+        if not math.isfinite(v):
+          break
+        diam = max(diam, v)
+      else:
+        if best is None or diam < best_diam:
+          best, best_diam = subset, diam
+    return list(best)
+
+  def index_tensor(self, indices, like):
+    return torch.tensor(indices, dtype=torch.int32)
+
+  # -- step statistics and momentum (the legs of byzantinemomentum_amd.step) -- #
+
+  @staticmethod
+  def _out3(samples, avg):
     a64 = avg.double()
     dev2 = sum((s.double() - a64).pow(2).sum().item() for s in samples)
-    out3 = torch.tensor([a64.pow(2).sum().item(), dev2, avg.abs().max().item()], dtype=torch.float64)
+    return torch.tensor([a64.pow(2).sum().item(), dev2, avg.abs().max().item() if avg.numel() else 0.0],
+                        dtype=torch.float64)
+
+  @staticmethod
+  def _byz(samples, avg, scale, attack):
+    att = avg.neg() if attack == "empire" else torch.stack(samples).var(dim=0).sqrt_()
+    att.mul_(scale)
+    return avg.add(att)
+
+  def stack_stats(self, samples, scale=None, attack="empire"):
+    avg, _, _, _ = O.compute_avg_dev_max(samples)
+    out3 = self._out3(samples, avg)
+    if scale is not None:
+      return avg, out3, self._byz(samples, avg, scale, attack)
     return avg, out3
+
+  def momentum_stats(self, sampled, buffers, mu, omd, factors, scale, attack):
+    ks, h = len(sampled), len(buffers)
+    clipped = [g * factors[i] if factors is not None else g for i, g in enumerate(sampled)]
+    for buf, g in zip(buffers, clipped[:h]):
+      buf.mul_(mu).add_(g, alpha=omd)
+    s_avg, _, _, _ = O.compute_avg_dev_max(clipped)
+    h_avg, _, _, _ = O.compute_avg_dev_max(list(buffers))
+    out6 = torch.cat([self._out3(clipped, s_avg), self._out3(list(buffers), h_avg)])
+    byz = self._byz(list(buffers), h_avg, scale, attack) if scale is not None else None
+    return s_avg, h_avg, byz, out6
+
+  def multi_fma3(self, outs, ps, qs, a, b, p_scale=None):
+    for i, (out, p, q) in enumerate(zip(outs, ps, qs)):
+      x = p * p_scale[i] if p_scale is not None else p
+      out.copy_(x.mul(a).add_(q, alpha=b))
+
+  def multi_scale(self, ys, factors):
+    for i, y in enumerate(ys):
+      if factors[i].item() != 1.0:
+        y.mul_(factors[i])
+
+  def row_sqnorms(self, gradients):
+    return torch.tensor([g.double().pow(2).sum().item() for g in gradients], dtype=torch.float64)
+
+  def clip_factors_from_sq(self, sq, k, clip):
+    norm = sq[:k].sqrt()
+    return torch.where(norm > clip, clip / norm, torch.ones_like(norm)).float()
+
+  def study_dots(self, core, extra):
+    c64 = [c.double() for c in core]
+    nc = len(core)
+    gram = torch.tensor([[torch.dot(c64[a], c64[b]).item() for b in range(nc)] for a in range(nc)],
+                        dtype=torch.float64)
+    ex = torch.tensor([torch.dot(c64[0], e.double()).item() for e in extra], dtype=torch.float64)
+    return gram, ex

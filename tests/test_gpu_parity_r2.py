@@ -349,3 +349,144 @@ def test_plugin_objects_on_gpu(bm):
         sys.modules.pop(k, None)
       else:
         sys.modules[k] = v
+
+
+# ---------------------------------------------------------------------------- #
+# The simulation step (attack.py:757-878 mirror): every momentum placement, clipping, both attacks,
+# against the independent oracle loop of tests/step_reference.py
+
+STEP_CONFIGS = [
+  dict(gar="krum", momentum_at="worker", clip=None, attack="empire", factor=1.1),
+  dict(gar="krum", momentum_at="worker", clip=100.0, attack="empire", factor=1.1),
+  dict(gar="bulyan", momentum_at="server", clip=None, attack="little", factor=1.5),
+  dict(gar="median", momentum_at="update", clip=105.0, attack="empire", factor=1.1),
+  dict(gar="trmean", momentum_at="server", clip=95.0, attack="little", factor=-1.5),
+  dict(gar="aksel", momentum_at="update", clip=None, attack="empire", factor=1.1),
+  dict(gar="brute", momentum_at="worker", clip=None, attack="empire", factor=1.1),
+  dict(gar="cge", momentum_at="worker", clip=None, attack="empire", factor=1.1),
+]
+
+
+@pytest.mark.parametrize("cfg", STEP_CONFIGS, ids=lambda c: f"{c['gar']}-{c['momentum_at']}-clip{c['clip']}-{c['attack']}")
+def test_step_all_placements_against_reference_loop(bm, cfg):
+  from byzantinemomentum_amd.step import AggregationStep
+  from tests.step_reference import ReferenceLoop, assert_floats_close
+  n, f, d = 11, 2, 30011
+  h = n - f
+  step = AggregationStep(n, f, f, gar=cfg["gar"], momentum=0.9, dampening=0.9, momentum_at=cfg["momentum_at"],
+                         attack=cfg["attack"], attack_factor=cfg["factor"], nb_past=3, gradient_clip=cfg["clip"])
+  ref = ReferenceLoop(n, f, f, cfg["gar"], cfg["momentum_at"], 0.9, 0.9, cfg["attack"], cfg["factor"], cfg["clip"], 3)
+  gen = torch.Generator().manual_seed(123)
+  origin = torch.randn(d, generator=gen)
+  params = origin.clone()
+  for it in range(4):
+    base = 0.2 * torch.randn(d, generator=gen)
+    sampled = [base + (0.5 + 0.1 * i) * torch.randn(d, generator=gen) for i in range(h + (1 if it == 2 else 0))]
+    want_def, want_upd, want = ref.step(sampled, params, origin)
+    got_def = step.run([g.to(DEV) for g in sampled], params.to(DEV), origin.to(DEV))
+    scale = float(torch.stack(sampled).abs().max())
+    assert float((got_def.cpu() - want_def).abs().max()) <= 4e-6 * scale, (cfg, it)
+    assert float((step.update_gradient().cpu() - want_upd).abs().max()) <= 4e-6 * scale, (cfg, it)
+    if it != 1:  # floats() skipped once: the past-gradient deque must advance regardless
+      got = step.floats()
+      assert step.floats() is got
+      assert_floats_close(got, want, tag=(cfg["gar"], it), tol=1e-5)
+    params = params - 0.05 * want_upd
+
+
+def test_momentum_stats_kernel_tiers(bm):
+  """bm_momentum_stats for row counts in every register tier (<= 8, 12, 20, 40, 64), odd lengths,
+  ks > h, clipping factors, both attacks; bit-exact momentum, averages and Byzantine vector."""
+  gen = torch.Generator().manual_seed(9)
+  for ks, h, d in ((3, 3, 1001), (8, 7, 4099), (12, 12, 2050), (20, 20, 30011), (25, 20, 10007), (39, 39, 5003),
+                   (64, 50, 2049)):
+    sampled = [torch.randn(d, generator=gen) for _ in range(ks)]
+    bufs = [torch.randn(d, generator=gen) for _ in range(h)]
+    factors = torch.ones(64)
+    factors[1] = 0.5
+    factors[ks - 1] = 0.25
+    for attack, scale in (("empire", 1.1), ("little", -1.5)):
+      dbufs = [b.to(DEV) for b in bufs]
+      s_avg, h_avg, byz, out6 = bm.stats.momentum_stats([g.to(DEV) for g in sampled], dbufs, 0.9, 0.1, factors.to(DEV),
+                                                        scale, attack)
+      clipped = [g * factors[i] for i, g in enumerate(sampled)]
+      want_bufs = [b.clone().mul_(0.9).add_(g, alpha=0.1) for b, g in zip(bufs, clipped)]
+      for a, b in zip(dbufs, want_bufs):
+        assert float((a.cpu() - b).abs().max()) <= 1e-6 * float(b.abs().max())
+      ws_avg, ws_norm, ws_dev, ws_max = O.compute_avg_dev_max(clipped, "f64")
+      wh_avg, wh_norm, wh_dev, wh_max = O.compute_avg_dev_max(want_bufs, "f64")
+      assert same_bits(s_avg, O.compute_avg_dev_max(clipped)[0])
+      assert float((h_avg.cpu() - O.compute_avg_dev_max(want_bufs)[0]).abs().max()) <= 2e-7 * wh_max
+      o = out6.tolist()
+      for got, want in ((math.sqrt(o[0]), ws_norm), (math.sqrt(o[1] / (ks - 1)), ws_dev), (o[2], ws_max),
+                        (math.sqrt(o[3]), wh_norm), (math.sqrt(o[4] / (h - 1)), wh_dev), (o[5], wh_max)):
+        assert abs(got - want) <= 1e-5 * want, (ks, h, d, attack, got, want)
+      stck = torch.stack(want_bufs)
+      avg = stck.mean(dim=0)
+      att = avg.neg() if attack == "empire" else stck.var(dim=0).sqrt_()
+      want_byz = avg + scale * att
+      assert float((byz.cpu() - want_byz).abs().max()) <= 4e-6 * float(want_byz.abs().max()), (ks, h, attack)
+
+
+def test_full_size_c5_step_against_fp64(bm):
+  """BASELINE config 5 on one GPU: one step at d = 36 546 980 (WRN-28-10 / CIFAR-100), n = 25, f = 5,
+  worker momentum 0.99, empire 1.1, Krum, against float64 reductions computed with torch on the same GPU."""
+  from byzantinemomentum_amd.step import AggregationStep
+  n, f, d, mu, damp = 25, 5, D_WRN, 0.99, 0.99
+  h = n - f
+  gen = torch.Generator(device=DEV).manual_seed(77)
+  mu_vec = 0.1 * torch.randn(d, device=DEV, generator=gen)
+  step = AggregationStep(n, f, f, gar="krum", momentum=mu, dampening=damp, attack_factor=1.1, nb_past=25)
+  ref_bufs = [torch.zeros(d, device=DEV) for _ in range(h)]
+  past = None
+  for it in range(2):
+    sampled = [mu_vec + s * torch.randn(d, device=DEV, generator=gen) for s in torch.linspace(0.5, 1.5, h).tolist()]
+    defense = step.run(sampled)
+    got = step.floats()
+    # reference on the same GPU: torch's own fp32 momentum, float64 for everything that is reduced
+    for b, g in zip(ref_bufs, sampled):
+      b.mul_(mu).add_(g, alpha=1.0 - damp)
+    for a, b in zip(step.buffers, ref_bufs):
+      assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+
+    def stats64(rows):
+      avg = rows[0].clone()
+      for r in rows[1:]:
+        avg.add_(r)
+      avg.div_(len(rows))
+      a64 = avg.double()
+      dev2 = sum(float((r.double() - a64).pow(2).sum()) for r in rows)
+      return avg, math.sqrt(float(a64.pow(2).sum())), math.sqrt(dev2 / (len(rows) - 1)) if len(rows) > 1 else math.nan, \
+          float(avg.abs().max())
+    s_avg, s_norm, s_dev, s_max = stats64(sampled)
+    h_avg, h_norm, h_dev, h_max = stats64(ref_bufs)
+    byz = h_avg + 1.1 * (-h_avg)
+    d_norm = math.sqrt(float(defense.double().pow(2).sum()))
+    for key, want in (("sampled_norm_avg", s_norm), ("sampled_norm_dev", s_dev), ("sampled_norm_max", s_max),
+                      ("honest_norm_avg", h_norm), ("honest_norm_dev", h_dev), ("honest_norm_max", h_max),
+                      ("defense_norm_avg", d_norm), ("defense_norm_max", float(defense.abs().max())),
+                      ("attack_norm_avg", math.sqrt(float(byz.double().pow(2).sum())))):
+      assert abs(got[key] - want) <= 1e-5 * want, (it, key, got[key], want)
+
+    def cos64(a, b):
+      return float(torch.dot(a.double(), b.double())) / math.sqrt(float(a.double().pow(2).sum())) / \
+          math.sqrt(float(b.double().pow(2).sum()))
+    for key, want in (("cosin_splhon", cos64(s_avg, h_avg)), ("cosin_spldef", cos64(s_avg, defense)),
+                      ("cosin_hondef", cos64(h_avg, defense)), ("cosin_splatt", cos64(s_avg, byz)),
+                      ("cosin_attdef", cos64(byz, defense))):
+      assert abs(got[key] - want) <= 1e-5, (it, key, got[key], want)
+    if past is not None:
+      assert abs(got["cosin_sampled"] - cos64(s_avg, past)) <= 1e-5
+      want_curv = mu * float(torch.dot(s_avg.double(), past.double()))
+      assert abs(got["curv_sampled"] - want_curv) <= 1e-5 * max(abs(want_curv), 1.0)
+    # the rule itself: selection from float64 distances on the same GPU
+    grads = list(ref_bufs) + [byz] * f
+    scores = O.krum_scores(np.sqrt(sqdist_f64_on_gpu(grads)), f)
+    order = O._stable_order(scores)
+    m = n - f - 2
+    acc = torch.zeros(d, dtype=torch.float32, device=DEV)
+    for i in order[:m]:
+      acc = acc + grads[i]
+    want_def = acc / m
+    assert float((defense - want_def).abs().max()) <= 4e-6 * float(want_def.abs().max())
+    past = s_avg

@@ -1,0 +1,165 @@
+"""Host logic of byzantinemomentum_amd.step.AggregationStep on CPU: every momentum placement, clipping,
+both attacks and several rules against the independent loop of tests/step_reference.py, with the
+oracle-backed compute legs; then the same step dim-sharded over two gloo ranks against one rank."""
+
+import math
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import gar_oracle as O
+from tests.step_reference import ReferenceLoop, assert_floats_close
+
+N, F, D = 11, 2, 1536
+
+
+def sampled_for_step(it, h, d=D, extra=0):
+  gen = torch.Generator().manual_seed(1000 + it)
+  base = 0.2 * torch.randn(d, generator=gen)
+  return [base + (0.5 + 0.1 * i) * torch.randn(d, generator=gen) for i in range(h + extra)]
+
+
+CONFIGS = [
+  dict(gar="krum", momentum_at="worker", clip=None, attack="empire", factor=1.1),
+  dict(gar="krum", momentum_at="worker", clip=30.0, attack="empire", factor=1.1),
+  dict(gar="bulyan", momentum_at="server", clip=None, attack="little", factor=1.5),
+  dict(gar="median", momentum_at="update", clip=32.0, attack="empire", factor=1.1),
+  dict(gar="trmean", momentum_at="server", clip=28.0, attack="little", factor=-1.5),
+  dict(gar="aksel", momentum_at="update", clip=None, attack="empire", factor=1.1),
+  dict(gar="brute", momentum_at="worker", clip=None, attack="empire", factor=1.1),
+  dict(gar="average", momentum_at="worker", clip=None, attack="empire", factor=1.1),
+  dict(gar="cge", momentum_at="worker", clip=None, attack="empire", factor=1.1),
+]
+
+
+def make_step(cfg, aggregator=None, n=N, f=F):
+  from byzantinemomentum_amd.sharded import ShardedAggregator
+  from byzantinemomentum_amd.step import AggregationStep
+  from tests.sharded_backend import OracleBackend
+  agg = aggregator or ShardedAggregator(backend=OracleBackend())
+  return AggregationStep(n, f, f, gar=cfg["gar"], momentum=0.9, dampening=0.9, momentum_at=cfg["momentum_at"],
+                         attack=cfg["attack"], attack_factor=cfg["factor"], nb_past=3, gradient_clip=cfg["clip"],
+                         aggregator=agg)
+
+
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: f"{c['gar']}-{c['momentum_at']}-clip{c['clip']}-{c['attack']}")
+def test_step_matches_reference_loop(cfg):
+  assert not dist.is_initialized()
+  h = N - F
+  n = N
+  step = make_step(cfg)
+  ref = ReferenceLoop(n, F, F, cfg["gar"], cfg["momentum_at"], 0.9, 0.9, cfg["attack"], cfg["factor"], cfg["clip"], 3)
+  gen = torch.Generator().manual_seed(5)
+  origin = torch.randn(D, generator=gen)
+  params = origin.clone()
+  for it in range(4):
+    sampled = sampled_for_step(it, h, extra=(1 if it == 2 else 0))  # one step with a gradient sampled only for the study
+    want_def, want_upd, want = ref.step(sampled, params, origin)
+    got_def = step.run([g.clone() for g in sampled], params, origin)
+    if it == 1:
+      step.run  # noqa: B018  (floats() is skipped on this step: the past deque must still advance)
+    else:
+      got = step.floats()
+      assert step.floats() is got                      # idempotent
+      assert_floats_close(got, want, tag=(cfg["gar"], it), tol=2e-6)
+    scale = float(torch.stack(sampled).abs().max())
+    assert float((got_def - want_def).abs().max()) <= 2e-6 * scale, (cfg, it)
+    assert float((step.update_gradient() - want_upd).abs().max()) <= 2e-6 * scale, (cfg, it)
+    params = params - 0.05 * want_upd
+
+
+def test_step_rejects_bad_arguments():
+  from byzantinemomentum_amd.step import AggregationStep, MAX_PAST
+  from byzantinemomentum_amd.sharded import ShardedAggregator
+  from tests.sharded_backend import OracleBackend
+  agg = ShardedAggregator(backend=OracleBackend())
+  with pytest.raises(ValueError):
+    AggregationStep(11, 2, 2, gar="nope", aggregator=agg)
+  with pytest.raises(ValueError):
+    AggregationStep(11, 2, 2, momentum_at="client", aggregator=agg)
+  with pytest.raises(ValueError):
+    AggregationStep(11, 2, 2, nb_past=MAX_PAST + 1, aggregator=agg)
+  step = AggregationStep(11, 2, 2, aggregator=agg)
+  with pytest.raises(ValueError):
+    step.run([torch.zeros(8)] * 3)
+  with pytest.raises(RuntimeError):
+    step.floats()
+
+
+# ---------------------------------------------------------------------------- #
+# Two gloo ranks, each holding a slice of the coordinates (one of them may be short or empty)
+
+def _free_port():
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    return s.getsockname()[1]
+
+
+def _worker(rank, world, port, d, queue):
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  try:
+    from byzantinemomentum_amd.sharded import ShardedAggregator, shard_bounds
+    from tests.sharded_backend import OracleBackend
+    lo, hi = shard_bounds(d, world, rank)
+    out = {}
+    for ci, cfg in enumerate(CONFIGS[:6]):
+      agg = ShardedAggregator(backend=OracleBackend())
+      assert agg.world_size == world and agg.collective
+      step = make_step(cfg, agg)
+      gen = torch.Generator().manual_seed(5)
+      origin = torch.randn(d, generator=gen)
+      params = origin + 0.01
+      for it in range(3):
+        sampled = [g[lo:hi].clone() for g in sampled_for_step(it, N - F, d)]
+        defense = step.run(sampled, params[lo:hi].clone(), origin[lo:hi].clone())
+        floats = step.floats()
+        out[(ci, it)] = (agg.all_gather_output(defense, d).numpy().copy(), floats)
+    queue.put((rank, out))
+    dist.barrier()
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("d", [D, 100])  # d = 100 < 2*64: the second rank's shard is short (36 coordinates)
+def test_two_rank_sharded_step_matches_single_rank(d):
+  world = 2
+  ctx = mp.get_context("spawn")
+  queue = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_worker, args=(r, world, port, d, queue)) for r in range(world)]
+  for p in procs:
+    p.start()
+  results = dict(queue.get(timeout=500) for _ in range(world))
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  for ci, cfg in enumerate(CONFIGS[:6]):
+    single = make_step(cfg)
+    gen = torch.Generator().manual_seed(5)
+    origin = torch.randn(d, generator=gen)
+    params = origin + 0.01
+    for it in range(3):
+      want_def = single.run([g.clone() for g in sampled_for_step(it, N - F, d)], params, origin)
+      want = single.floats()
+      for r in range(world):
+        got_def, got = results[r][(ci, it)]
+        assert torch.equal(torch.from_numpy(got_def), want_def) or \
+            float((torch.from_numpy(got_def) - want_def).abs().max()) <= 1e-6, (cfg, it, r)
+        for key, val in want.items():
+          g = got[key]
+          assert (math.isnan(g) and math.isnan(val)) or abs(g - val) <= 1e-9 * max(abs(val), 1e-6), (cfg, it, key, g, val)
+      # every rank computed the same floats (same packed exchange, same reduction order)
+      a, b = results[0][(ci, it)][1], results[1][(ci, it)][1]
+      assert all(a[k] == b[k] or (math.isnan(a[k]) and math.isnan(b[k])) for k in a)
+
+
+def test_empty_shard_reaches_the_collectives():
+  """d < 64: the second rank's slice is EMPTY; the step must still run (no rank may skip a collective)."""
+  from byzantinemomentum_amd.sharded import shard_bounds
+  assert shard_bounds(40, 2, 1) == (40, 40)
