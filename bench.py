@@ -2,29 +2,38 @@
 
     python bench.py --gpus N --steps K --warmup W [--workload colwise|krum|bulyan|step [--gar RULE]]
 
-Default workload = BASELINE.json configs[1]: coordinate-wise median + trimmed mean (f=5) over a
-synthetic stack of n=25 worker gradients x d=11 173 962 coordinates (ResNet-18-sized), fp32, inputs
-resident in HBM.  One "step" = one pass of the path over one batch = one median aggregation + one
-trimmed-mean aggregation; `value` = aggregations per second over the whole job.
+N = 1 (default): BASELINE.json configs[1] — coordinate-wise median + trimmed mean (f=5) over a synthetic
+stack of n=25 worker gradients x d=11 173 962 coordinates (ResNet-18-sized), fp32, inputs resident in
+HBM.  One "step" = one pass of the path over one batch = one median + one trimmed-mean aggregation;
+`value` = aggregations per second.  The same line carries, under `per_gar`, short measurements of the
+other single-GPU configurations (C3 Multi-Krum n=51, C4 Bulyan n=25, C5 full step at d=36.5 M), each
+with its algorithmic bytes and fraction of the 8 TB/s HBM roofline (skip with --no-extras).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): the path shards along d with no
-data-path collective for the coordinate-wise rules — every rank aggregates its own d-slice of a
-N-times-larger model ("weak" scaling, per-GPU work fixed); `value` counts one aggregation per
-rank-shard pass.  `--workload bulyan` is the dim-sharded rule WITH its one real exchange (a single
-all-reduce of the 25x25 fp64 squared-distance partials over RCCL).  `--workload step` is BASELINE.json
-configs[4] on one GPU: the attack.py:800-878 mirror (worker momentum, empire attack, rule, study
-statistics) at d = 36 546 980 (WRN-28-10 / CIFAR-100), n=25, f=5.
+N > 1 (one rank per GPU; `python bench.py --gpus N` re-executes itself under torch.distributed.run,
+and the driver's own torchrun launch is used as is): BASELINE.json configs[3] — Bulyan n=25, f=5 over a
+FIXED total d = 11 173 962 split across the ranks by shard_bounds ("strong" scaling), with the path's
+one exchange (the all-reduce of the 25x25 fp64 squared-distance partials over RCCL) inside the timed
+step; `value` = aggregations of the whole vector per second.  `per_gar` adds the communication-free
+coordinate-wise pair on the same shards and the optional all-gather of the output, and
+`single_gpu_same_workload` is the unsharded rule timed on rank 0 alone, so that the speed-up of this
+exact workload can be read off one line.
 
-The JSON line also carries `roofline` (algorithmic bytes / HIP-event kernel time vs 8 TB/s HBM)
-and `cpu_baseline` (the oracle's reference-faithful PyTorch-CPU port on this box's host cores,
-rank 0, N=1 only).
+The JSON line also carries `roofline` (algorithmic bytes / HIP-event time of the dominant kernel vs
+8 TB/s; `traffic` = HBM bytes per launch from rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this very
+command, collected live unless --no-traffic) and `cpu_baseline` (the oracle's reference-faithful
+PyTorch-CPU port on this box's host cores, rank 0, N = 1 only).
 """
 
 import argparse
+import csv
+import glob
 import json
 import os
 import pathlib
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import torch
@@ -34,6 +43,7 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (MI355X_MICROARCH.md)
 D_RESNET18 = 11173962
+D_WRN = 36546980         # WRN-28-10 on CIFAR-100
 
 
 def parse():
@@ -41,10 +51,14 @@ def parse():
   p.add_argument("--gpus", type=int, default=1)
   p.add_argument("--steps", type=int, default=50)
   p.add_argument("--warmup", type=int, default=5)
-  p.add_argument("--workload", default="colwise", choices=["colwise", "krum", "bulyan", "step"])
+  p.add_argument("--workload", default=None, choices=["colwise", "krum", "bulyan", "step"],
+                 help="default: colwise on one GPU, bulyan (dim-sharded, strong scaling) on several")
   p.add_argument("--gar", default="krum", help="aggregation rule of --workload step")
-  p.add_argument("--d", type=int, default=D_RESNET18)
+  p.add_argument("--d", type=int, default=None, help="TOTAL number of coordinates (split across the ranks)")
+  p.add_argument("--weak", action="store_true", help="N > 1: keep d per GPU fixed instead of the total")
   p.add_argument("--no-cpu-baseline", action="store_true")
+  p.add_argument("--no-extras", action="store_true", help="N = 1: skip the per_gar measurements of C3/C4/C5")
+  p.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 FETCH_SIZE/WRITE_SIZE passes")
   p.add_argument("--aliased-byz", action="store_true",
                  help="make the f Byzantine rows ONE aliased tensor as the reference's attacks do "
                       "(attacks/identical.py:86); they are then served from cache and the HBM traffic "
@@ -56,8 +70,11 @@ def parse():
 def make_stacks(n, f, d, device, count, seed, aliased):
   """`count` independent stacks (rotated between steps so that the 256 MB Infinity Cache never
   holds the next input). Honest rows N(mu, sigma_i); the f Byzantine rows are -0.1*mean(honest)
-  ("empire", factor 1.1), either ONE aliased tensor (aliased=True, the reference's layout) or f
-  distinct buffers with a 1e-3 relative jitter (default: every row costs its HBM bytes)."""
+  ("empire", factor 1.1), either ONE aliased tensor (aliased=True, the reference's layout: exact zero
+  distances between them) or f distinct buffers = that vector plus independent N(0, 0.3^2) noise
+  (default: every row costs its HBM bytes and no two rows are near-duplicates — near-duplicate but
+  not identical rows are handed to the exact direct-difference kernel by the accuracy gate of the
+  distance pass, which is the slow path and not what this benchmark is meant to time)."""
   gen = torch.Generator(device=device).manual_seed(seed)
   stacks = []
   for _ in range(count):
@@ -69,8 +86,7 @@ def make_stacks(n, f, d, device, count, seed, aliased):
     if aliased:
       stacks.append(honest + [byz] * f)
     else:
-      stacks.append(honest + [byz + 1e-3 * byz.abs().mean() * torch.randn(d, device=device, generator=gen)
-                              for _ in range(f)])
+      stacks.append(honest + [byz + 0.3 * torch.randn(d, device=device, generator=gen) for _ in range(f)])
   return stacks
 
 
@@ -93,6 +109,24 @@ class KernelTimer:
     ps = self.pairs[name]
     return sum(a.elapsed_time(b) for a, b in ps) / len(ps)
 
+
+def entry(ms, nbytes, **more):
+  return dict({"avg_ms": ms, "algorithmic_bytes": nbytes, "gbps": nbytes / ms / 1e6,
+               "frac_of_8TBps": nbytes / ms / 1e6 / HBM_PEAK_GBPS, "agg_per_s": 1e3 / ms}, **more)
+
+
+def timed_loop(fn, steps, warmup, timer, name):
+  for i in range(warmup):
+    fn(i)
+  torch.cuda.synchronize()
+  for i in range(steps):
+    timer.run(name, lambda: fn(i))
+  torch.cuda.synchronize()
+  return timer.mean_ms(name)
+
+
+# ---------------------------------------------------------------------------- #
+# CPU baseline (rank 0, one GPU only): the oracle's f32 port = the reference's torch-CPU operations
 
 def _pick_threads(fn):
   """The host has far more hardware threads than torch's CPU kernels can use on these shapes;
@@ -147,11 +181,58 @@ def cpu_baseline_distance(stack, f, rule, d_sample):
                     f"pass {dt:.2f} s, scaled linearly to d={stack[0].shape[0]}"}
 
 
+# ---------------------------------------------------------------------------- #
+# Live HBM traffic: rocprofv3 PMC passes of this very command (separate runs, --kernel-trace only)
+
+def measure_traffic(argv, kernel_substring):
+  """HBM bytes per launch of the kernel whose name contains `kernel_substring`:
+  FETCH_SIZE and WRITE_SIZE (KiB) from two rocprofv3 --pmc passes, FETCH_SIZE doubled as
+  MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950.  None if rocprofv3 is unavailable."""
+  exe = shutil.which("rocprofv3")
+  if exe is None:
+    return None
+  values = {}
+  env = dict(os.environ, TMPDIR="/tmp", BM_BENCH_CHILD="1")
+  for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+    with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
+      cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "pmc", "--",
+             sys.executable, str(ROOT / "bench.py"), *argv, "--steps", "4", "--warmup", "1", "--no-cpu-baseline",
+             "--no-extras", "--no-traffic"]
+      try:
+        subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, timeout=300, check=True)
+      except Exception:  # noqa: BLE001
+        return None
+      per_dispatch = {}
+      for path in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as fh:
+          for row in csv.DictReader(fh):
+            if kernel_substring in row["Kernel_Name"] and row["Counter_Name"] == counter:
+              key = row["Dispatch_Id"]
+              per_dispatch[key] = per_dispatch.get(key, 0.0) + float(row["Counter_Value"])
+      if not per_dispatch:
+        return None
+      values[counter] = sum(per_dispatch.values()) / len(per_dispatch)
+  return int(1024 * (2 * values["FETCH_SIZE"] + values["WRITE_SIZE"]))
+
+
+# ---------------------------------------------------------------------------- #
+
 def main():
   args = parse()
+  if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    # `python bench.py --gpus N`: become N ranks, one per GPU (torch.distributed.run, RCCL over xGMI)
+    import socket
+    with socket.socket() as s:
+      s.bind(("127.0.0.1", 0))
+      port = s.getsockname()[1]
+    os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+                              f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port",
+                              str(port), str(ROOT / "bench.py"), *sys.argv[1:]])
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+  if world != args.gpus and "WORLD_SIZE" in os.environ and args.gpus != 1:
+    raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks")
   if not torch.cuda.is_available():
     raise SystemExit("bench.py needs an MI355X: no GPU visible")
   device = torch.device("cuda", local_rank)
@@ -162,21 +243,37 @@ def main():
   if distributed:
     import torch.distributed as dist
     dist.init_process_group("nccl", device_id=device)
+    world = dist.get_world_size()  # the ranks RCCL actually sees
   from byzantinemomentum_amd import build as bm_build
   if rank == 0:
     bm_build.build()  # no-op when the in-tree libbm_gar.so is current
   if distributed:
     dist.barrier()
   import byzantinemomentum_amd as bm
+  from byzantinemomentum_amd.sharded import ShardedAggregator, shard_bounds
   bm._lib.load()
 
-  d = args.d
+  workload = args.workload or ("colwise" if world == 1 else "bulyan")
+  d_total = args.d or (D_WRN if workload == "step" else D_RESNET18)
+  if world > 1 and args.weak:
+    d_total *= world
+  lo, hi = shard_bounds(d_total, world, rank)
+  d = hi - lo  # this rank's coordinates
+  agg = ShardedAggregator(force_collectives=distributed)
   timer = KernelTimer()
-  if args.workload == "colwise":
+  per_gar = {}
+  extra = {}
+
+  def barrier():
+    if distributed:
+      dist.barrier()
+    torch.cuda.synchronize()
+
+  if workload == "colwise":
     n, f = 25, 5
     stacks = make_stacks(n, f, d, device, 2, 1234 + rank, args.aliased_byz)
     aggs_per_step = 2
-    algo_bytes = {"median": 4 * d * (n + 1), "trmean": 4 * d * (n + 1)}
+    algo_bytes = {"median": 4 * d_total * (n + 1), "trmean": 4 * d_total * (n + 1)}
 
     def step(i, timed):
       st = stacks[i & 1]
@@ -186,24 +283,20 @@ def main():
       else:
         bm.median(st)
         bm.trmean(st, f)
-    workload_name = f"C2 colwise: median + trmean(f={f}), n={n}, d={d} per GPU"
-  elif args.workload == "step":
+    workload_name = f"C2 colwise: median + trmean(f={f}), n={n}, total d={d_total}"
+    dominant_kernel = "colwise_kernel"
+  elif workload == "step":
     from byzantinemomentum_amd.step import AggregationStep
     n, f = 25, 5
     h = n - f
-    if args.d == D_RESNET18:
-      d = 36546980  # WRN-28-10 on CIFAR-100
-    runner = AggregationStep(n, f, f, gar=args.gar, momentum=0.99, dampening=0.99, attack_factor=1.1, nb_past=25)
+    runner = AggregationStep(n, f, f, gar=args.gar, momentum=0.99, dampening=0.99, attack_factor=1.1, nb_past=25,
+                             aggregator=agg)
     gen = torch.Generator(device=device).manual_seed(77 + rank)
     mu_vec = 0.1 * torch.randn(d, device=device, generator=gen)
     sets = [[mu_vec + s * torch.randn(d, device=device, generator=gen) for s in torch.linspace(0.5, 1.5, h).tolist()]
             for _ in range(2)]
     aggs_per_step = 1
-    m = n - f - 2
-    gar_units = {"krum": n + m + 1, "bulyan": n + m + 1, "median": n + 1, "trmean": n + 1}.get(args.gar, n + 1)
-    # 4-byte units of d per step: momentum 3h, attack+honest stats h+2, rule,
-    # sampled stats h+1, attack stats 2, defense stats 1, dots 4+25
-    algo_bytes = {"step": 4 * d * (3 * h + (h + 2) + gar_units + (h + 1) + 2 + 1 + 29)}
+    algo_bytes = {"step": step_algorithmic_bytes(d_total, n, f, args.gar)}
 
     def step(i, timed):
       if timed:
@@ -211,34 +304,27 @@ def main():
       else:
         runner.run(sets[i & 1])
         runner.floats()
-    workload_name = (f"C5 full step mirror (attack.py:800-878): worker momentum 0.99, empire 1.1, rule {args.gar}, "
-                     f"study statistics with 25 past gradients; n={n}, f={f}, d={d}")
+    workload_name = (f"C5 full step mirror (attack.py:757-878): worker momentum 0.99, empire 1.1, rule {args.gar}, "
+                     f"study statistics with 25 past gradients; n={n}, f={f}, total d={d_total}")
+    dominant_kernel = "momentum_stats_kernel"
   else:
-    from byzantinemomentum_amd.sharded import ShardedAggregator
-    agg = ShardedAggregator(force_collectives=distributed)
-    if args.workload == "krum":
-      n, f = 51, 12
-    else:
-      n, f = 25, 5
+    n, f = (51, 12) if workload == "krum" else (25, 5)
     m = n - f - 2
     stacks = make_stacks(n, f, d, device, 2, 4321 + rank, args.aliased_byz)
     aggs_per_step = 1
-    algo_bytes = {args.workload: 4 * d * n + 4 * d * (m + 1)}
-    rule = agg.krum if args.workload == "krum" else agg.bulyan
+    algo_bytes = {workload: 4 * d_total * n + 4 * d_total * (m + 1)}
+    rule = agg.krum if workload == "krum" else agg.bulyan
 
     def step(i, timed):
       st = stacks[i & 1]
       if timed:
-        timer.run(args.workload, lambda: rule(st, f))
+        timer.run(workload, lambda: rule(st, f))
       else:
         rule(st, f)
-    workload_name = (f"{'C3 multi-krum' if args.workload == 'krum' else 'C4 bulyan'}: n={n}, f={f}, m={m}, "
-                     f"d={d} per GPU, dim-sharded, one all-reduce of the {n}x{n} fp64 partial matrix")
-
-  def barrier():
-    if distributed:
-      dist.barrier()
-    torch.cuda.synchronize()
+    workload_name = (f"{'C3 multi-krum' if workload == 'krum' else 'C4 bulyan'}: n={n}, f={f}, m={m}, total d={d_total}"
+                     + (f" dim-sharded over {world} ranks, one all-reduce of the {n}x{n} fp64 partial matrix"
+                        if distributed else ""))
+    dominant_kernel = "gram3_partial_kernel"
 
   for i in range(args.warmup):
     step(i, False)
@@ -253,46 +339,121 @@ def main():
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = t.item()
 
+  for name, nbytes in algo_bytes.items():
+    per_gar[name] = entry(timer.mean_ms(name), nbytes, config=workload_name)
+
+  # ---- N > 1: the same shards through the communication-free pair, the all-gather, one-GPU reference ----
+  if world > 1 and workload in ("bulyan", "krum"):
+    ms = timed_loop(lambda i: bm.median(stacks[i & 1]), 10, 2, timer, "x_median")
+    ms2 = timed_loop(lambda i: bm.trmean(stacks[i & 1], f), 10, 2, timer, "x_trmean")
+    out = rule(stacks[0], f)
+    ms3 = timed_loop(lambda i: agg.all_gather_output(out, d_total), 10, 2, timer, "x_allgather")
+    for key, val in (("median_sharded", ms), ("trmean_sharded", ms2), ("allgather_output", ms3)):
+      t = torch.tensor([val], dtype=torch.float64, device=device)
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      nbytes = 4 * d_total * (n + 1) if key != "allgather_output" else 4 * d_total
+      per_gar[key] = entry(t.item(), nbytes, config=f"same shards, n={n}, total d={d_total}, max over ranks")
+    del stacks
+    torch.cuda.empty_cache()
+    single = None
+    if rank == 0:
+      full = make_stacks(n, f, d_total, device, 2, 4321, args.aliased_byz)
+      fn = bm.krum if workload == "krum" else bm.bulyan
+      single = timed_loop(lambda i: fn(full[i & 1], f), 10, 3, timer, "x_single")
+      del full
+    dist.barrier()
+    if rank == 0:
+      extra["single_gpu_same_workload"] = {"value": 1e3 / single, "unit": "agg/s", "ms": single,
+                                           "note": "the unsharded rule on rank 0 alone, same total d"}
+
+  # ---- N = 1: the other single-GPU configurations, briefly ----
+  if world == 1 and workload == "colwise" and not args.no_extras and rank == 0:
+    first = stacks[0]
+    if not args.no_cpu_baseline:
+      extra["cpu_baseline"] = cpu_baseline_colwise(first, f)
+    del stacks, first
+    torch.cuda.empty_cache()
+    per_gar.update(extras_single_gpu(bm, device, timer, args.aliased_byz))
+  elif world == 1 and rank == 0 and not args.no_cpu_baseline:
+    if workload == "colwise":
+      extra["cpu_baseline"] = cpu_baseline_colwise(stacks[0], f)
+    elif workload in ("krum", "bulyan"):
+      extra["cpu_baseline"] = cpu_baseline_distance(stacks[0], f, workload, min(d, 1 << 20))  # bounded sample
+
   if rank == 0:
-    per_kernel = {}
-    for name, nbytes in algo_bytes.items():
-      ms = timer.mean_ms(name)
-      per_kernel[name] = {"avg_ms": ms, "algorithmic_bytes": nbytes, "gbps": nbytes / ms / 1e6,
-                          "frac_of_8TBps": nbytes / ms / 1e6 / HBM_PEAK_GBPS, "agg_per_s": 1e3 / ms}
-    dominant = max(per_kernel, key=lambda k: per_kernel[k]["avg_ms"])
-    dk = per_kernel[dominant]
+    dominant = max(algo_bytes, key=lambda k: per_gar[k]["avg_ms"])
+    dk = per_gar[dominant]
     traffic = None
-    prof = ROOT / "profiles" / "pmc_traffic.json"
-    if prof.exists():
-      try:
-        traffic = json.loads(prof.read_text()).get(args.workload, {}).get(dominant)
-      except Exception:  # noqa: BLE001
-        traffic = None
+    if world == 1 and not args.no_traffic and "BM_BENCH_CHILD" not in os.environ:
+      child = ["--workload", workload, "--gar", args.gar] + (["--d", str(args.d)] if args.d else []) + \
+          (["--aliased-byz"] if args.aliased_byz else [])
+      traffic = measure_traffic(child, dominant_kernel)
     line = {
       "metric": "aggregations/sec (Byzantine-robust GAR over n workers x d dims; achieved HBM GB/s per GAR in roofline/per_gar)",
-      "value": aggs_per_step * args.steps * world / elapsed,
+      "value": aggs_per_step * args.steps / elapsed,
       "unit": "agg/s",
       "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
       "ms_per_step": elapsed / args.steps * 1e3,
-      "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+      "higher_is_better": True, "scaling": "weak" if (world > 1 and args.weak) else "strong", "vs_baseline": None,
       "dtype": "f32", "data": "synthetic",
-      "config": {"workload": workload_name, "n_workers": n, "f": f, "d_per_gpu": d,
+      "config": {"workload": workload_name, "n_workers": n, "f": f, "d_total": d_total, "d_per_gpu": d,
                  "byzantine_rows": "aliased" if args.aliased_byz else "distinct buffers",
                  "parallelism": f"dim-shard x{world}" if world > 1 else "single GPU"},
-      "roofline": {"bound": "hbm", "kernel": dominant, "achieved": dk["gbps"], "peak": HBM_PEAK_GBPS,
-                   "unit": "GB/s", "frac": dk["frac_of_8TBps"], "traffic": traffic},
-      "per_gar": per_kernel,
+      "roofline": {"bound": "hbm", "kernel": dominant, "achieved": dk["gbps"], "peak": HBM_PEAK_GBPS * world,
+                   "unit": "GB/s", "frac": dk["gbps"] / (HBM_PEAK_GBPS * world), "traffic": traffic,
+                   "traffic_source": None if traffic is None else
+                   f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, kernel {dominant_kernel}: "
+                   "1024*(2*FETCH_SIZE + WRITE_SIZE) per launch"},
+      "per_gar": per_gar,
     }
-    if world == 1 and not args.no_cpu_baseline:
-      if args.workload == "colwise":
-        line["cpu_baseline"] = cpu_baseline_colwise(stacks[0], f)
-      elif args.workload == "step":
-        pass  # the CPU baseline of the full step is the reference's attack.py itself
-      else:
-        line["cpu_baseline"] = cpu_baseline_distance(stacks[0], f, args.workload, min(d, 1 << 20))  # bounded sample
+    line.update(extra)
     print(json.dumps(line))
   if distributed:
     dist.destroy_process_group()
+
+
+def step_algorithmic_bytes(d, n, f, gar):
+  """4-byte units of d per step, fused first pass: sampled + buffers read,
+  buffers written, three d-vectors written (ks + 2h + 3); rule; attack stats 2, defense stats 1, dots 4 + 25."""
+  h = n - f
+  m = n - f - 2
+  gar_units = {"krum": n + m + 1, "bulyan": n + m + 1, "median": n + 1, "trmean": n + 1}.get(gar, n + 1)
+  return 4 * d * ((h + 2 * h + 3) + gar_units + 2 + 1 + 29)
+
+
+def extras_single_gpu(bm, device, timer, aliased):
+  """C3, C4 (one GPU) and C5 in a few iterations each: the driver-run record then carries every
+  single-GPU configuration of BASELINE.json, not only the headline one."""
+  from byzantinemomentum_amd.step import AggregationStep
+  out = {}
+  d = D_RESNET18
+  for name, n, f in (("krum_c3", 51, 12), ("bulyan_c4_1gpu", 25, 5)):
+    m = n - f - 2
+    stacks = make_stacks(n, f, d, device, 2, 4321, aliased)
+    fn = bm.krum if name.startswith("krum") else bm.bulyan
+    ms = timed_loop(lambda i: fn(stacks[i & 1], f), 12, 3, timer, name)
+    ms_pair = timed_loop(lambda i: bm.gars.pairwise_sqdist(stacks[i & 1]), 12, 3, timer, name + "_dist")
+    out[name] = entry(ms, 4 * d * n + 4 * d * (m + 1), config=f"n={n}, f={f}, m={m}, d={d}, one GPU",
+                      distance_pass_ms=ms_pair, distance_pass_gbps=4 * d * n / ms_pair / 1e6)
+    del stacks
+    torch.cuda.empty_cache()
+  n, f, d = 25, 5, D_WRN
+  h = n - f
+  gen = torch.Generator(device=device).manual_seed(77)
+  mu_vec = 0.1 * torch.randn(d, device=device, generator=gen)
+  sets = [[mu_vec + s * torch.randn(d, device=device, generator=gen) for s in torch.linspace(0.5, 1.5, h).tolist()]
+          for _ in range(2)]
+  for gar in ("krum", "median"):
+    runner = AggregationStep(n, f, f, gar=gar, momentum=0.99, dampening=0.99, attack_factor=1.1, nb_past=25)
+
+    def one(i):
+      runner.run(sets[i & 1])
+      runner.floats()
+    ms = timed_loop(one, 8, 3, timer, "step_" + gar)
+    out[f"step_c5_{gar}"] = entry(ms, step_algorithmic_bytes(d, n, f, gar),
+                                  config=f"full step mirror, rule {gar}, n={n}, f={f}, d={d}, one GPU")
+    del runner
+  return out
 
 
 if __name__ == "__main__":

@@ -16,9 +16,10 @@ import torch  # noqa: F401  (must be imported before the CDLL, see above)
 _PKG_DIR = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _PKG_DIR / "libbm_gar.so"
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 MAX_ROWS = 64
 EINVAL = -100000
+ENOCOMM, ECOMM = -100001, -100002
 
 OP_MEDIAN, OP_TRMEAN, OP_PHOCAS, OP_MEAMED = 0, 1, 2, 3
 WS_PAIRWISE, WS_AKSEL, WS_STATS, WS_DOT, WS_STEP = 0, 1, 2, 3, 4
@@ -62,6 +63,20 @@ SIGNATURES = {
   "bm_clip_factors": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_void_p,
                                      ctypes.c_void_p]),
   "bm_multi_scale": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+  "bm_comm_available": (ctypes.c_int, []),
+  "bm_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+  "bm_comm_init": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_int, ctypes.c_void_p]),
+  "bm_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+  "bm_comm_size": (ctypes.c_int, [ctypes.c_void_p]),
+  "bm_allreduce_sum_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
+  "bm_allgather_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                      ctypes.c_void_p]),
+  "bm_sharded_workspace_bytes": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int64]),
+  "bm_sharded_krum": (ctypes.c_int, [ctypes.c_void_p, _c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                     ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+  "bm_sharded_bulyan": (ctypes.c_int, [ctypes.c_void_p, _c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p]),
 }
 
 

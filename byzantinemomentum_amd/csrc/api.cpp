@@ -23,11 +23,13 @@ const Tuning& tuning() {
 }
 }  // namespace bm
 
-extern "C" int bm_abi_version(void) { return 4; }
+extern "C" int bm_abi_version(void) { return 5; }
 
 extern "C" const char* bm_error_string(int code) {
   if (code == 0) return "success";
   if (code == BM_EINVAL) return "invalid argument for libbm_gar";
+  if (code == BM_ENOCOMM) return "RCCL is not available in this process (librccl.so.1 could not be bound)";
+  if (code == BM_ECOMM) return "an RCCL call failed";
   if (code < 0) return hipGetErrorString(static_cast<hipError_t>(-code));
   return "unknown libbm_gar status";
 }

@@ -6,18 +6,6 @@ namespace bm {
 
 constexpr int kColBlock = 256;
 
-// Trimmed mean when the wave holds neither NaN nor infinity (checked by the caller, i.e. always in
-// practice): the trimmed sum is one v_fmac per rank with a wave-uniform 0/1 weight instead of a
-// v_cndmask + v_add pair (0 * inf would be NaN, hence the infinity check), and no NaN bookkeeping.
-template <int N>
-__device__ __forceinline__ float trmean_finite(float (&x)[N], int f, float inv_keep) {
-  sort_network<N>(x);
-  float tsum = 0.0f;
-#pragma unroll
-  for (int i = 0; i < N; ++i) tsum = __builtin_fmaf(x[i], (i >= f && i < N - f) ? 1.0f : 0.0f, tsum);
-  return div_small_int(tsum, (float)(N - 2 * f), inv_keep);
-}
-
 // Per-column rule on N register-resident values.  `lds` points at this lane's slot of a
 // [N][kColBlock] scratch array (only used by the closest-to-centre rules).
 template <int N, int OP>

@@ -37,7 +37,6 @@ namespace bm {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int kGramWaves = 4;         // waves per workgroup
-constexpr int kGramFlushSteps = 16;   // 16 steps x 16 coordinates = 256-coordinate fp32 chains
 constexpr int kGramDmaBlock = 1024;   // bytes per wave-wide global_load_lds_dwordx4
 constexpr int kGramDmaPitch = 1024 + 16;
 
@@ -98,12 +97,17 @@ __global__ __launch_bounds__(64 * W) void gram_partial_kernel(RowTable rows, Gra
   const int li = lane & 15, lq = lane >> 4;
   const int tile_bytes = (g.nb + 1) * kGramDmaPitch;  // + one block that stays zero
 
-  for (int r = tid; r < BM_MAX_ROWS; r += blockDim.x) row_ptr[r] = nullptr;
+  // Row pointers: one per-lane load from the kernarg segment (the table is the first kernel argument,
+  // passed by value).  Round 1 filled the table from ONE thread (~7 us per workgroup) after a dynamic
+  // index into the by-value struct (`rows.p[tid]`) had faulted: that form makes the compiler spill
+  // the 512-byte struct to scratch; reading the kernarg segment itself needs no copy.
+  if (tid < BM_MAX_ROWS) {
+    typedef const float* __attribute__((address_space(4))) const* KargTable;
+    KargTable karg = (KargTable)__builtin_amdgcn_kernarg_segment_ptr();
+    row_ptr[tid] = tid < n ? (const float*)karg[tid] : nullptr;
+  }
   for (int o = tid * 16; o < NBUF * tile_bytes; o += blockDim.x * 16)
     *reinterpret_cast<f32x4*>(tiles + o) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  __syncthreads();
-  if (tid == 0)
-    for (int r = 0; r < n; ++r) row_ptr[r] = rows.p[r];  // uniform index: scalar loads
   __syncthreads();
 
   // byte offset of this lane's row in a tile buffer plus its 16-byte column slot; lanes whose

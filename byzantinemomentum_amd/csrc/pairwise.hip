@@ -154,12 +154,14 @@ __global__ __launch_bounds__(kPairMaxThreads) void pairwise_partial_kernel(
   const int tile_bytes = g.nb * kDmaPitch;
 
   // one-time: pointer table, zeroed tiles (rows >= n and block padding are never written again)
-  for (int r = tid; r < BM_MAX_ROWS; r += blockDim.x) row_ptr[r] = nullptr;
+  // row pointers: per-lane loads from the kernarg segment (see gram.hip)
+  if (tid < BM_MAX_ROWS) {
+    typedef const float* __attribute__((address_space(4))) const* KargTable;
+    KargTable karg = (KargTable)__builtin_amdgcn_kernarg_segment_ptr();
+    row_ptr[tid] = tid < g.n ? (const float*)karg[tid] : nullptr;
+  }
   for (int o = tid * 16; o < 2 * tile_bytes; o += blockDim.x * 16)
     *reinterpret_cast<f32x4*>(tiles + o) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-  __syncthreads();
-  if (tid == 0)
-    for (int r = 0; r < g.n; ++r) row_ptr[r] = rows.p[r];  // uniform index: scalar loads
   __syncthreads();
 
   int unit_in_wave, pos;

@@ -20,14 +20,16 @@ tests of tests/test_sharded_gloo.py inject an oracle-backed one to exercise part
 collectives without a GPU.  With world_size 1 no collective is ever issued.
 """
 
+import ctypes
 import math
+import warnings
 
 import torch
 import torch.distributed as dist
 
 from . import _lib
 
-__all__ = ["shard_bounds", "ShardedAggregator", "HipBackend"]
+__all__ = ["shard_bounds", "owned_workers", "ShardedAggregator", "HipBackend", "NativeComm"]
 
 
 def shard_bounds(d, world_size, rank, align=64):
@@ -38,6 +40,45 @@ def shard_bounds(d, world_size, rank, align=64):
   lo = min(rank * per, d)
   hi = min(lo + per, d)
   return lo, hi
+
+
+def owned_workers(n, world_size, rank):
+  """Workers whose gradients rank `rank` produces in the worker-parallel layout: rank, rank+P, ...
+  (round robin, so that a worker count that P does not divide still spreads evenly)."""
+  return list(range(rank, n, world_size))
+
+
+class NativeComm:
+  """RCCL communicator owned by libbm_gar.so (bm_comm_*): lets the sharded rules run as ONE C call
+  per aggregation with the all-reduce issued from C on the caller's stream.  Bootstrapped through the
+  existing torch.distributed group (rank 0's unique id is broadcast as a Python object)."""
+
+  def __init__(self, group=None):
+    lib = _lib.load()
+    if not lib.bm_comm_available():
+      raise RuntimeError("RCCL could not be bound by libbm_gar.so")
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    ident = [None]
+    if rank == 0:
+      buf = ctypes.create_string_buffer(128)
+      _lib.check(lib.bm_comm_unique_id(buf), "bm_comm_unique_id")
+      ident[0] = buf.raw
+    dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    handle = ctypes.c_void_p()
+    _lib.check(lib.bm_comm_init(ctypes.byref(handle), world, rank, ctypes.c_char_p(ident[0])), "bm_comm_init")
+    self.handle = handle
+    self.world_size = world
+
+  def close(self):
+    if self.handle is not None and self.handle.value:
+      _lib.load().bm_comm_destroy(self.handle)
+      self.handle = None
+
+  def __del__(self):
+    try:
+      self.close()
+    except Exception:  # noqa: BLE001  (interpreter shutdown)
+      pass
 
 
 class HipBackend:
@@ -75,6 +116,21 @@ class HipBackend:
   def brute_select(self, dist_host, n, f):
     return self.gars.brute_select_host(dist_host, n, f)
 
+  def sharded_rule(self, name, comm, gradients, f, m):
+    """Multi-Krum / Bulyan of the local slice in one C call (bm_sharded_krum / bm_sharded_bulyan);
+    comm: NativeComm or None (one rank)."""
+    gars = self.gars
+    n, d, device = gars._validate(gradients)
+    lib = _lib.load()
+    out = torch.empty(d, dtype=torch.float32, device=device)
+    nbytes = lib.bm_sharded_workspace_bytes(n, d)
+    ws = gars._Scratch.get(device, "ws_sharded", nbytes=int(nbytes))
+    fn = lib.bm_sharded_krum if name == "krum" else lib.bm_sharded_bulyan
+    with torch.cuda.device(device):
+      _lib.check(fn(comm.handle if comm is not None else None, _lib.pointer_table(gradients), n, d, f, m,
+                    gars._ptr(out), None, gars._ptr(ws), gars._stream(device)), "bm_sharded_" + name)
+    return out
+
   def index_tensor(self, indices, like):
     return torch.tensor(indices, dtype=torch.int32, device=like.device)
 
@@ -105,7 +161,10 @@ class HipBackend:
 class ShardedAggregator:
   """Aggregation rules over gradients whose coordinates are sharded across the ranks of `group`."""
 
-  def __init__(self, backend=None, group=None, force_collectives=False):
+  def __init__(self, backend=None, group=None, force_collectives=False, native_comm="auto"):
+    """native_comm: "auto" (default) gives the HIP backend its own RCCL communicator when there is
+    more than one rank, so that Multi-Krum / Bulyan are single C calls; False keeps every collective
+    in torch.distributed; True insists (raises if RCCL cannot be bound)."""
     self.backend = backend if backend is not None else HipBackend()
     self.group = group
     initialised = dist.is_available() and dist.is_initialized()
@@ -114,6 +173,16 @@ class ShardedAggregator:
     # force_collectives: issue the all-reduce / all-gather calls even with one rank (used to
     # exercise the RCCL path on a single-GPU box); never set in production with world_size 1
     self.collective = self.world_size > 1 or (force_collectives and initialised)
+    self.native = None
+    self.single_call = isinstance(self.backend, HipBackend) and native_comm is not False
+    if self.single_call and self.collective:
+      try:
+        self.native = NativeComm(group)
+      except Exception as err:  # noqa: BLE001
+        if native_comm is True:
+          raise
+        warnings.warn(f"libbm_gar RCCL communicator unavailable ({err}); using torch.distributed collectives")
+        self.single_call = False
 
   # -- collectives (never called when world_size == 1) ----------------------- #
 
@@ -154,6 +223,34 @@ class ShardedAggregator:
     dist.all_gather_into_tensor(full, padded, group=self.group)
     return full[:d]
 
+  def to_dim_sharded(self, my_gradients, n, d):
+    """Worker-major -> dimension-major in ONE all-to-all (the step before the
+    path when the honest gradients are PRODUCED in parallel, experiments/model.py:333-366 run once per
+    worker).  `my_gradients`: the full-length gradients of owned_workers(n, P, rank), in that order.
+    Returns the n gradients restricted to this rank's coordinate slice (shard_bounds), in worker order:
+    views into one receive buffer, 256-byte aligned, ready for the rules.  Each rank sends (P-1)/P of
+    what it produced — n/P * d * 4 bytes spread over the P-1 peers' links at once — never more."""
+    world, rank = self.world_size, self.rank
+    mine = owned_workers(n, world, rank)
+    if len(my_gradients) != len(mine):
+      raise ValueError(f"rank {rank} must pass the gradients of workers {mine}")
+    if not self.collective or world == 1:
+      return list(my_gradients)
+    lo0, hi0 = shard_bounds(d, world, 0)
+    per = hi0 - lo0                       # padded shard length (multiple of 64 coordinates)
+    n_max = -(-n // world)
+    like = my_gradients[0]
+    send = torch.zeros((world, n_max, per), dtype=like.dtype, device=like.device)
+    for j, g in enumerate(my_gradients):
+      full = g.shape[0] // per
+      send[:full, j, :] = g[:full * per].view(full, per)
+      if full < world and g.shape[0] > full * per:
+        send[full, j, :g.shape[0] - full * per] = g[full * per:]
+    recv = torch.empty_like(send)
+    dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group)
+    lo, hi = shard_bounds(d, world, rank)
+    return [recv[i % world, i // world, :hi - lo] for i in range(n)]
+
   # -- rules ------------------------------------------------------------------ #
 
   def median(self, local):
@@ -179,6 +276,8 @@ class ShardedAggregator:
     n = len(local)
     if m is None:
       m = n - f - 2
+    if self.single_call:
+      return self.backend.sharded_rule("krum", self.native, local, f, m)
     order = self.backend.rank(self.global_sqdist(local), n, f, m, _lib.RANK_KRUM)
     return self.backend.selected_mean(local, order, m)
 
@@ -186,6 +285,8 @@ class ShardedAggregator:
     n = len(local)
     if m is None:
       m = n - f - 2
+    if self.single_call:
+      return self.backend.sharded_rule("bulyan", self.native, local, f, m)
     order = self.backend.rank(self.global_sqdist(local), n, f, m, _lib.RANK_BULYAN)
     return self.backend.bulyan_pass2(local, order, f, m)
 

@@ -33,6 +33,8 @@ extern "C" {
 
 #define BM_MAX_ROWS 64
 #define BM_EINVAL   (-100000)
+#define BM_ENOCOMM  (-100001) /* RCCL is not available in this process      */
+#define BM_ECOMM    (-100002) /* an RCCL call failed                        */
 
 /* Column-wise rules (coordinate-per-coordinate over the worker axis). */
 enum bm_colwise_op {
@@ -166,6 +168,36 @@ int bm_multi_scale(float* const* y, int k, int64_t d, const float* factors, void
  * distances (host memory).  Writes n-f ascending indices; returns 0, or
  * BM_EINVAL if no finite subset exists. */
 int bm_brute_select(const double* dist_nxn, int n, int f, int32_t* sel_out);
+
+/* ---------------------------------------------------------------------------------------------
+ * Dim-sharded aggregation: one process per GPU, every rank holds all n rows
+ * restricted to its d_local coordinates.  The reference has no counterpart (its aggregation is
+ * single-device, attack.py:811-825); these are the entry points a multi-GPU binding would use.
+ * RCCL is bound lazily with dlopen (no link-time dependency).  A NULL comm means "one rank".
+ */
+typedef struct bm_comm bm_comm;
+
+int bm_comm_available(void);                  /* 1 if RCCL could be bound in this process        */
+int bm_comm_unique_id(void* id128);           /* rank 0: 128 bytes to hand to every other rank   */
+int bm_comm_init(bm_comm** out, int nranks, int rank, const void* id128);  /* collective         */
+int bm_comm_destroy(bm_comm* comm);
+int bm_comm_size(const bm_comm* comm);
+
+/* In-place sum over the ranks of `count` doubles on the caller's stream (the n x n squared-distance
+ * partials, the packed step statistics); no-op for one rank. */
+int bm_allreduce_sum_f64(bm_comm* comm, double* buf, int64_t count, void* stream);
+/* all[r*count .. (r+1)*count) = rank r's `mine`: the full output vector from the per-rank slices. */
+int bm_allgather_f32(bm_comm* comm, const float* mine, float* all, int64_t count_per_rank, void* stream);
+
+/* Multi-Krum / Bulyan of the local slice in ONE call: partial squared distances -> all-reduce ->
+ * score + stable rank (identical on every rank) -> selected mean / Bulyan pass 2 of the slice
+ * (aggregators/krum.py:31-80, bulyan.py:31-84).  order_out (DEVICE, BM_MAX_ROWS int32, may be NULL)
+ * receives the ranking.  ws: bm_sharded_workspace_bytes(n, d_local). */
+int64_t bm_sharded_workspace_bytes(int n, int64_t d_local);
+int bm_sharded_krum(bm_comm* comm, const float* const* rows, int n, int64_t d_local, int f, int m,
+                    float* out_local, int32_t* order_out, void* ws, void* stream);
+int bm_sharded_bulyan(bm_comm* comm, const float* const* rows, int n, int64_t d_local, int f, int m,
+                      float* out_local, int32_t* order_out, void* ws, void* stream);
 
 #ifdef __cplusplus
 }

@@ -413,6 +413,7 @@ def test_rccl_path_on_one_gpu(bm):
     dev = to_dev(rows)
     agg = ShardedAggregator(force_collectives=True)
     assert agg.collective
+    assert agg.native is not None and agg.single_call   # libbm_gar's own RCCL communicator, one C call per rule
     out = agg.bulyan(dev, 5)
     assert torch.equal(out, bm.bulyan(dev, 5))
     assert torch.equal(agg.all_gather_output(out, 40007), out)
@@ -420,6 +421,19 @@ def test_rccl_path_on_one_gpu(bm):
     want = bm.compute_avg_dev_max(dev[:h])
     got = agg.compute_avg_dev_max(dev[:h])
     assert torch.equal(got[0], want[0]) and got[1:] == want[1:]
+    # the torch.distributed form of the same rules (native_comm=False) must give the same bits
+    plain = ShardedAggregator(force_collectives=True, native_comm=False)
+    assert plain.native is None and not plain.single_call
+    assert torch.equal(plain.bulyan(dev, 5), out) and torch.equal(plain.krum(dev, 5), bm.krum(dev, 5))
+    # a whole step through forced collectives equals the step without any
+    from byzantinemomentum_amd.step import AggregationStep
+    a = AggregationStep(25, 5, 5, gar="bulyan", nb_past=2, aggregator=agg)
+    b = AggregationStep(25, 5, 5, gar="bulyan", nb_past=2)
+    for it in range(3):
+      sampled = [g * (1.0 + 0.1 * it) for g in dev[:h]]
+      assert torch.equal(a.run(sampled), b.run([g.clone() for g in sampled]))
+      fa, fb = a.floats(), b.floats()
+      assert all(fa[k] == fb[k] or (math.isnan(fa[k]) and math.isnan(fb[k])) for k in fa)
   finally:
     dist.destroy_process_group()
 

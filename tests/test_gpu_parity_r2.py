@@ -92,7 +92,9 @@ def test_full_size_c3_krum_against_fp64(bm, kind):
   # rank with the oracle's own logic (krum.py:50-62) on the fp64 distances
   scores = O.krum_scores(np.sqrt(want_sq), f)
   order = O._stable_order(scores)
-  assert all(decisive(scores, k) for k in range(1, m + 1)), "generator is meant to be well separated"
+  # neighbours in the ranking are either exactly tied (the aliased Byzantine rows: index order, like the
+  # reference's stable sort) or decisively apart
+  assert all(scores[a] == scores[b] or scores[b] - scores[a] > 1e-5 * scores[b] for a, b in zip(order, order[1:m + 1]))
   got = bm.gars.krum_selection(rows, f)
   assert got == order[:m]
   # the average: torch's own sequential fp32 sum on the same GPU, true division on the host

@@ -90,6 +90,46 @@ def test_two_rank_sharded_aggregation_matches_single_process():
   assert torch.equal(results[0]["sq"], results[1]["sq"])   # every rank ranks the same bits
 
 
+def _a2a_worker(rank, world, port, n, d, queue):
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  try:
+    from byzantinemomentum_amd.sharded import ShardedAggregator, owned_workers, shard_bounds
+    from tests.sharded_backend import OracleBackend
+    rows, _ = O.make_stack("iid", n, 0, d, seed=7)          # every rank can regenerate every worker's gradient
+    agg = ShardedAggregator(backend=OracleBackend())
+    local = agg.to_dim_sharded([rows[i] for i in owned_workers(n, world, rank)], n, d)
+    lo, hi = shard_bounds(d, world, rank)
+    ok = len(local) == n and all(torch.equal(local[i], rows[i][lo:hi]) for i in range(n))
+    med = agg.all_gather_output(agg.median(local), d)       # and the rules run on the exchanged layout
+    queue.put((rank, ok, med.numpy().copy()))
+    dist.barrier()
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("n,d", [(5, 1000), (4, 130), (3, 40)])
+def test_worker_major_to_dim_major_all_to_all(n, d):
+  """Worker-parallel production (rank p holds workers p, p+P, ...) -> one all-to-all -> every rank holds
+  its coordinate slice of ALL workers; uneven worker counts, a short last shard and an empty one."""
+  world = 2
+  ctx = mp.get_context("spawn")
+  queue = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_a2a_worker, args=(r, world, port, n, d, queue)) for r in range(world)]
+  for p in procs:
+    p.start()
+  results = [queue.get(timeout=240) for _ in range(world)]
+  for p in procs:
+    p.join(timeout=60)
+    assert p.exitcode == 0
+  rows, _ = O.make_stack("iid", n, 0, d, seed=7)
+  for rank, ok, med in results:
+    assert ok, f"rank {rank}: exchanged slices differ"
+    assert torch.equal(torch.from_numpy(med), O.median(rows))
+
+
 def test_shard_bounds_cover_everything_once():
   from byzantinemomentum_amd.sharded import shard_bounds
   for d in (1, 63, 64, 65, 1000, 11173962, 36546980):
