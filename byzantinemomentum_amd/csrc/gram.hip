@@ -298,19 +298,20 @@ __global__ __launch_bounds__(64 * kGramRedWaves) void gram_reduce_kernel(const d
 }
 
 // sq[i][j] = G_ii + G_jj - 2 G_ij in fp64, one workgroup.  Also decides whether the Gram form was
-// accurate enough: its absolute error is ~eps_G * (G_ii + G_jj) (eps_G ~ 1e-8, measured), so a pair
-// whose squared distance is below tau * (G_ii + G_jj) — rows that nearly coincide relative to their
-// (centred) norms — has lost relative accuracy eps_G / tau and raises *flag; the caller then
-// recomputes the matrix with the direct-difference kernel (pairwise.hip), which has no
-// cancellation.  Bitwise-equal rows (G_ii == G_jj == G_ij) are exact (d2 = 0) and never flag.
+// accurate enough: its absolute error is ~eps_G * (G_ii + G_jj) (eps_G ~ 6e-9, measured), so a pair
+// whose squared distance is below tau * (G_ii + G_jj) — two rows that nearly coincide relative to
+// their (centred) norms — has lost relative accuracy eps_G / tau.  The rows of such pairs are listed in
+// `sub` (sub[0] = count, sub[1..] = indices, ascending); the caller recomputes the distances among them
+// with the direct-difference kernel (pairwise.hip), which has no cancellation: near-duplicate rows
+// lie close to EACH OTHER, so that sub-stack is exactly where the Gram form cannot be trusted.
+// Bitwise-equal rows (G_ii == G_jj == G_ij) are exact (d2 = 0) and never listed.
 constexpr int kSqThreads = 1024;
 __global__ __launch_bounds__(kSqThreads) void gram_to_sqdist_kernel(const double* __restrict__ gram, int n,
                                                                     double tau, double* __restrict__ sq,
-                                                                    int* __restrict__ flag) {
-  __shared__ int any;
-  if (threadIdx.x == 0) any = 0;
+                                                                    int* __restrict__ sub) {
+  __shared__ int listed[BM_MAX_ROWS];
+  if (threadIdx.x < BM_MAX_ROWS) listed[threadIdx.x] = 0;
   __syncthreads();
-  bool bad = false;
   for (int e = threadIdx.x; e < n * n; e += kSqThreads) {
     const int i = e / n, j = e - i * n;
     if (i == j) {
@@ -324,13 +325,20 @@ __global__ __launch_bounds__(kSqThreads) void gram_to_sqdist_kernel(const double
     const double gij = gram[tri_index(lo, hi, n)];
     double v = (gii + gjj) - 2.0 * gij;
     const bool same = (gii == gjj) && (gij == gii);
-    if (!same && v < tau * (gii + gjj)) bad = true;  // NaN compares false: non-finite rows never flag
+    if (!same && v < tau * (gii + gjj)) {  // NaN compares false: non-finite rows are never listed
+      listed[i] = 1;                       // benign race: every writer stores 1
+      listed[j] = 1;
+    }
     if (v < 0.0) v = 0.0;  // rounding of nearly identical rows; NaN stays NaN
     sq[e] = v;
   }
-  if (bad) any = 1;  // benign race: every writer stores 1
   __syncthreads();
-  if (threadIdx.x == 0 && flag != nullptr) *flag = any;
+  if (threadIdx.x == 0 && sub != nullptr) {
+    int count = 0;
+    for (int r = 0; r < n; ++r)
+      if (listed[r]) sub[1 + count++] = r;
+    sub[0] = count;
+  }
 }
 
 constexpr int kGramMaxBlocks = 2048;
@@ -388,19 +396,19 @@ static int launch_gram(const RowTable& tab, const GramGeom& g, int64_t d, bool a
 }
 
 // Fixed-order sum of the per-workgroup partial Gram matrices, then squared distances + accuracy flag.
-int gram_finish(const double* partial, int blocks, int n, double* gram, double* sq_nxn, int* flag, double tau,
+int gram_finish(const double* partial, int blocks, int n, double* gram, double* sq_nxn, int* sub, double tau,
                 hipStream_t s) {
   const int64_t per_block = (int64_t)n * (n + 1) / 2;
   hipLaunchKernelGGL(gram_reduce_kernel, dim3((int)((per_block + 63) / 64)), dim3(64 * kGramRedWaves), 0, s,
                      partial, blocks, n, gram);
   BM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gram_to_sqdist_kernel, dim3(1), dim3(kSqThreads), 0, s, gram, n, tau, sq_nxn, flag);
+  hipLaunchKernelGGL(gram_to_sqdist_kernel, dim3(1), dim3(kSqThreads), 0, s, gram, n, tau, sq_nxn, sub);
   BM_LAUNCH_CHECK();
   return 0;
 }
 
 int gram_sqdist(const float* const* rows, int n, int64_t d, double* sq_nxn, double* partial, double* gram,
-                int* flag, double tau, hipStream_t s) {
+                int* sub, double tau, hipStream_t s) {
   RowTable tab{};
   for (int i = 0; i < n; ++i) tab.p[i] = rows[i];
   const bool aligned = common_vec_width(reinterpret_cast<const void* const*>(rows), n, nullptr) == 4;
@@ -418,7 +426,7 @@ int gram_sqdist(const float* const* rows, int n, int64_t d, double* sq_nxn, doub
     default: rc = launch_gram<4>(tab, g, d, aligned, partial, blocks, s); break;
   }
   if (rc != 0) return rc;
-  return gram_finish(partial, blocks, n, gram, sq_nxn, flag, tau, s);
+  return gram_finish(partial, blocks, n, gram, sq_nxn, sub, tau, s);
 }
 
 }  // namespace bm

@@ -52,7 +52,7 @@ struct PairGeom {
   int nb;         // DMA blocks per tile = ng * (4/rb)
 };
 
-static PairGeom pair_geometry(int n) {
+__host__ __device__ inline PairGeom pair_geometry(int n, int forced) {
   PairGeom g;
   g.n = n;
   g.ng = (n + kTileR - 1) / kTileR;
@@ -60,30 +60,30 @@ static PairGeom pair_geometry(int n) {
   g.ut = (g.tiles + 15) / 16;
   // Candidates (strips, slots) with row_bytes = 16*slots*strips in {256, 512, 1024}.  Pick the best
   // lane utilisation; among equals the largest tile whose two buffers stay within 32 KB (so that
-  // four or five workgroups fit in the 160 KB of LDS of a CU).
-  static const int cand[][2] = {{2, 8}, {4, 8}, {8, 8}, {1, 16}, {2, 16}, {4, 16}};
-  const int forced = tuning().pair_strips;
-  double best_u = -1.0;
-  int best = -1, best_bytes = 0;
+  // four or five workgroups fit in the 160 KB of LDS of a CU).  forced = strips*100+slots (experiments).
+  const int cand[6][2] = {{2, 8}, {4, 8}, {8, 8}, {1, 16}, {2, 16}, {4, 16}};
+  int best = -1, best_bytes = 0, best_num = -1, best_den = 1;  // utilisation as the fraction num/den
   for (int c = 0; c < 6; ++c) {
-    const int s = cand[c][0], sl = cand[c][1];
-    const int lanes = 16 * g.ut * s;
+    const int st = cand[c][0], sl = cand[c][1];
+    const int lanes = 16 * g.ut * st;
     const int thr = ((lanes + 63) / 64) * 64;
-    const int rowb = 16 * sl * s;
+    const int rowb = 16 * sl * st;
     const int tile_bytes = g.ng * (4 * rowb / kDmaBlock) * kDmaPitch;
     if (thr > kPairMaxThreads) continue;
     if (forced > 0) {
-      if (forced == s * 100 + sl) {
+      if (forced == st * 100 + sl) {
         best = c;
         break;
       }
       continue;
     }
     if (2 * tile_bytes > 32 * 1024) continue;
-    const double u = (double)lanes / thr;
-    if (u > best_u + 1e-9 || (u > best_u - 1e-9 && tile_bytes > best_bytes)) {
-      best_u = u;
+    // lanes/thr > best_num/best_den, or equal with a larger tile (exact integer comparison)
+    const long lhs = (long)lanes * best_den, rhs = (long)best_num * thr;
+    if (best < 0 || lhs > rhs || (lhs == rhs && tile_bytes > best_bytes)) {
       best = c;
+      best_num = lanes;
+      best_den = thr;
       best_bytes = tile_bytes;
     }
   }
@@ -142,9 +142,14 @@ __device__ __forceinline__ int row_offset_bytes(const PairGeom& g, int I, int a)
 // use a plain load + ds_write loop (same layout, not overlapped).
 template <bool ALIGNED, int ABLATE = 0>
 __global__ __launch_bounds__(kPairMaxThreads) void pairwise_partial_kernel(
-    RowTable rows, PairGeom g, int64_t d, double* __restrict__ partial, const int* __restrict__ gate) {
-  // gate: accuracy flag of the Gram path (gram_to_sqdist_kernel); 0 = this launch has nothing to do
-  if (gate != nullptr && *gate == 0) return;
+    RowTable rows, PairGeom g, int64_t d, double* __restrict__ partial, const int* __restrict__ sub) {
+  // sub (device, may be NULL): the rows the accuracy gate of the Gram path asks to recompute
+  // (gram_to_sqdist_kernel): sub[0] = how many (0: this launch has nothing to do), sub[1..] = their
+  // indices.  The kernel then works on that sub-stack with the geometry of ITS row count.
+  if (sub != nullptr) {
+    if (sub[0] == 0) return;
+    g = pair_geometry(sub[0], 0);
+  }
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const float** row_ptr = reinterpret_cast<const float**>(smem);  // 512 B pointer table
   char* tiles = smem + BM_MAX_ROWS * sizeof(float*);
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(kPairMaxThreads) void pairwise_partial_kernel(
   if (tid < BM_MAX_ROWS) {
     typedef const float* __attribute__((address_space(4))) const* KargTable;
     KargTable karg = (KargTable)__builtin_amdgcn_kernarg_segment_ptr();
-    row_ptr[tid] = tid < g.n ? (const float*)karg[tid] : nullptr;
+    row_ptr[tid] = tid < g.n ? (const float*)karg[sub != nullptr ? sub[1 + tid] : tid] : nullptr;
   }
   for (int o = tid * 16; o < 2 * tile_bytes; o += blockDim.x * 16)
     *reinterpret_cast<f32x4*>(tiles + o) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -326,9 +331,12 @@ __global__ __launch_bounds__(kPairMaxThreads) void pairwise_partial_kernel(
 // scatters the value to sq[i][j] and sq[j][i].
 constexpr int kRedWaves = 8;
 __global__ __launch_bounds__(64 * kRedWaves) void pairwise_reduce_kernel(
-    const double* __restrict__ partial, int nblocks, PairGeom g, double* __restrict__ sq,
-    const int* __restrict__ gate) {
-  if (gate != nullptr && *gate == 0) return;
+    const double* __restrict__ partial, int nblocks, PairGeom g, int n_full, double* __restrict__ sq,
+    const int* __restrict__ sub) {
+  if (sub != nullptr) {
+    if (sub[0] == 0) return;
+    g = pair_geometry(sub[0], 0);
+  }
   __shared__ double wsum[kRedWaves][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int per_block = g.tiles * 16;
@@ -353,12 +361,17 @@ __global__ __launch_bounds__(64 * kRedWaves) void pairwise_reduce_kernel(
     ++I;
   }
   const int J = I + t;
-  const int i = I * kTileR + a, j = J * kTileR + b;
-  const int n = g.n;
-  if (i >= n || j >= n) return;
+  int i = I * kTileR + a, j = J * kTileR + b;
+  if (i >= g.n || j >= g.n) return;
+  const bool keep = (i != j) && (I != J || a < b);
+  if (sub != nullptr) {  // sub-stack position -> row of the full stack
+    i = sub[1 + i];
+    j = sub[1 + j];
+  }
+  const int n = n_full;
   if (i == j) {
     sq[i * n + j] = 0.0;
-  } else if (I != J || a < b) {
+  } else if (keep) {
     // off-diagonal tiles hold each unordered pair once; diagonal tiles hold (a,b) and (b,a)
     // with bitwise-equal sums, keep the a<b copy
     sq[i * n + j] = tot;
@@ -435,31 +448,46 @@ __global__ __launch_bounds__(kRankThreads) void krum_rank_kernel(const double* _
 
 namespace bm {
 int gram_sqdist(const float* const* rows, int n, int64_t d, double* sq_nxn, double* partial, double* gram,
-                int* flag, double tau, hipStream_t s);
-int gram_finish(const double* partial, int blocks, int n, double* gram, double* sq_nxn, int* flag, double tau,
+                int* sub, double tau, hipStream_t s);
+int gram_finish(const double* partial, int blocks, int n, double* gram, double* sq_nxn, int* sub, double tau,
                 hipStream_t s);
 int64_t gram_partial_doubles(int n);
 int gram3_partials(const float* const* rows, int n, int64_t d, double* partial, int* blocks_out, hipStream_t s);
 int64_t gram3_partial_doubles(int n);
 
-// Workspace layout of bm_pairwise_sqdist: [flag: 64 B][Gram partials][Gram n(n+1)/2][direct partials]
+// Workspace layout of bm_pairwise_sqdist: [row list of the gate: 512 B][Gram partials][Gram n(n+1)/2][direct partials]
 static int64_t pair_gram_doubles(int n) {
   const int64_t a = gram_partial_doubles(n), b = gram3_partial_doubles(n);
   return (a > b ? a : b) + (int64_t)n * (n + 1) / 2;
 }
 
-// Direct-difference kernel + its reduction.  gate == nullptr: unconditional; otherwise both launches
-// return immediately unless *gate != 0 (device-side decision, no host synchronisation).
+// Direct-difference kernel + its reduction.  sub == nullptr: the whole stack, unconditionally.
+// Otherwise sub is the DEVICE row list written by gram_to_sqdist_kernel: both launches return
+// immediately when it is empty, else recompute exactly the pairs among the listed rows (device-side
+// decision, no host synchronisation; the launch is shaped for the worst case, all n rows).
 static int pairwise_direct(const float* const* rows, int n, int64_t d, double* sq_nxn, double* partial,
-                           const int* gate, hipStream_t s) {
-  const PairGeom g = pair_geometry(n);
+                           const int* sub, hipStream_t s) {
+  const int forced = tuning().pair_strips;
+  const PairGeom g = pair_geometry(n, sub == nullptr ? forced : 0);
   RowTable tab{};
   for (int i = 0; i < n; ++i) tab.p[i] = rows[i];
-  const int blocks = pair_grid_blocks(g, d);
-  size_t lds_bytes = (size_t)2 * g.nb * kDmaPitch;  // two tile buffers
-  const size_t red_bytes = (size_t)g.strips * g.tiles * 16 * sizeof(float);
-  if (red_bytes > lds_bytes) lds_bytes = red_bytes;
+  int threads = g.threads, per_block = g.tiles * 16;
+  size_t lds_bytes = 0;
+  int64_t min_width = g.width;
+  // worst case over the sub-stack sizes the device may pick
+  for (int k = (sub == nullptr ? n : 2); k <= n; ++k) {
+    const PairGeom gk = (k == n) ? g : pair_geometry(k, 0);
+    size_t need = (size_t)2 * gk.nb * kDmaPitch;  // two tile buffers
+    const size_t red_bytes = (size_t)gk.strips * gk.tiles * 16 * sizeof(float);
+    if (red_bytes > need) need = red_bytes;
+    if (need > lds_bytes) lds_bytes = need;
+    if (gk.threads > threads) threads = gk.threads;
+    if (gk.width < min_width) min_width = gk.width;
+  }
   lds_bytes += BM_MAX_ROWS * sizeof(float*);  // row pointer table in front
+  PairGeom gw = g;
+  gw.width = (int)min_width;
+  const int blocks = pair_grid_blocks(gw, d);
   const bool aligned =
       common_vec_width(reinterpret_cast<const void* const*>(rows), n, nullptr) == 4;
   const int ablate = tuning().pair_ablate;  // experiments only (BM_PAIR_ABLATE)
@@ -472,11 +500,10 @@ static int pairwise_direct(const float* const* rows, int n, int64_t d, double* s
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return hip_code(e);
   }
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(g.threads), lds_bytes, s, tab, g, d, partial, gate);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds_bytes, s, tab, g, d, partial, sub);
   BM_LAUNCH_CHECK();
-  const int per_block = g.tiles * 16;
   hipLaunchKernelGGL(pairwise_reduce_kernel, dim3((per_block + 63) / 64), dim3(64 * kRedWaves), 0, s,
-                     partial, blocks, g, sq_nxn, gate);
+                     partial, blocks, g, n, sq_nxn, sub);
   BM_LAUNCH_CHECK();
   return 0;
 }
@@ -488,14 +515,14 @@ extern "C" int bm_pairwise_sqdist(const float* const* rows, int n, int64_t d, do
   if (rows == nullptr || sq_nxn == nullptr || ws == nullptr || n < 1 || n > BM_MAX_ROWS || d < 0)
     return BM_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int* flag = static_cast<int*>(ws);
-  double* gram_partial = reinterpret_cast<double*>(static_cast<char*>(ws) + 64);
+  int* flag = static_cast<int*>(ws);  // flag[0] = rows to recompute, flag[1..] = their indices
+  double* gram_partial = reinterpret_cast<double*>(static_cast<char*>(ws) + 512);
   double* direct_partial = gram_partial + pair_gram_doubles(n);
   // BM_PAIR_MODE: 0 (default) centred Gram on the bf16 matrix cores, three-way split (gram_bf16.hip);
   //               1 direct differences on the VALU (this file), no cancellation at all;
   //               2 uncentred Gram on the fp32 matrix cores (gram.hip), kept as the measured alternative.
-  // Modes 0 and 2 end with the accuracy check of gram_to_sqdist_kernel; if it flags a pair the direct
-  // kernel recomputes the whole matrix (gated on the device, no host round trip).
+  // Modes 0 and 2 end with the accuracy check of gram_to_sqdist_kernel; the rows of the pairs it flags
+  // are recomputed among themselves by the direct kernel (decided on the device, no host round trip).
   const int mode = tuning().pair_mode;
   if (mode == 1) return pairwise_direct(rows, n, d, sq_nxn, direct_partial, nullptr, s);
   const double tau = tuning().pair_tau;
@@ -528,12 +555,12 @@ extern "C" int bm_krum_rank(const double* sq_nxn, int n, int f, int m, int mode,
 
 namespace bm {
 int64_t pairwise_workspace_bytes(int n, int64_t d) {
-  const PairGeom g = pair_geometry(n);
+  const PairGeom g = pair_geometry(n, 0);
   // upper bound on the grid (BM_PAIR_BLOCKS may raise it, keep a floor of 4096 workgroups)
   int blocks = tuning().pair_blocks > 0 ? tuning().pair_blocks : 256 * 4;
   if (blocks < 4096) blocks = 4096;
   (void)d;
   const int64_t direct = (int64_t)blocks * g.tiles * 16 * (int64_t)sizeof(double);
-  return 64 + pair_gram_doubles(n) * (int64_t)sizeof(double) + direct;
+  return 512 + pair_gram_doubles(n) * (int64_t)sizeof(double) + direct;
 }
 }  // namespace bm

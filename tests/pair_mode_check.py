@@ -56,9 +56,12 @@ def check_stack(kind, n, f, d, seed):
     ob, sb = O.bulyan_order(rows, f, None, "f64")
     if all(decisive(sb, k) for k in range(1, n)):
       assert bm.gars.bulyan_ranking(dev, f) == ob, (kind, n, "bulyan ranking")
-    scale = float(torch.stack(rows[:h]).abs().max())
-    err = (bm.bulyan(dev, f).cpu().double() - O.bulyan(rows, f, None, "f64")).abs().max().item()
-    assert err <= 2e-6 * scale, (kind, n, "bulyan output", err)
+    # output against the reference-faithful f32 oracle (same fp32 suffix means, same median): valid when its
+    # ranking is the float64 one; a float64 pass 2 would flip near-ties of the closest-to-median step
+    if O.bulyan_order(rows, f)[0] == ob:
+      scale = float(torch.stack(rows[:h]).abs().max())
+      err = (bm.bulyan(dev, f).cpu() - O.bulyan(rows, f)).abs().max().item()
+      assert err <= 2e-6 * scale, (kind, n, "bulyan output", err)
   oa, sa = O.aksel_order(rows, "f64")
   c = (n + 1) // 2
   if decisive(sa, c):
@@ -82,6 +85,19 @@ def main():
   want = torch.from_numpy(O.pairwise_distances(rows, "f64")) ** 2
   rel = abs(sq[1, 2].item() - want[1, 2].item()) / want[1, 2].item()
   assert rel <= 1e-5, ("near-duplicate rows", rel)
+  # a clique of near-duplicate rows inside a larger stack (colluding workers that add a little noise):
+  # only that sub-stack goes to the direct kernel, every distance must still be accurate
+  rows, h = O.make_stack("hetero", 25, 5, 100003, seed=6)
+  gen = torch.Generator().manual_seed(1)
+  for k in (3, 9, 17, 18):
+    rows[k] = rows[3] + 1e-4 * torch.randn(rows[3].shape[0], generator=gen)
+  dev = to_dev(rows)
+  sq = bm.gars.pairwise_sqdist(dev).cpu()
+  want = torch.from_numpy(O.pairwise_distances(rows, "f64")) ** 2
+  off = ~torch.eye(25, dtype=torch.bool) & (want > 0)
+  rel = ((sq - want).abs()[off] / want[off]).max().item()
+  assert rel <= 1e-5, ("near-duplicate clique", rel)
+  assert torch.equal(sq, sq.T)
   print(f"pair-mode ok (worst relative error of a squared distance {worst:.2e})")
 
 

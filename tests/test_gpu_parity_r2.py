@@ -58,14 +58,14 @@ def gpu_stack(kind, n, f, d, seed):
 def sqdist_f64_on_gpu(rows):
   """n x n float64 squared distances, direct differences in fp64 on the GPU (no Gram, no cancellation)."""
   n = len(rows)
+  st = torch.stack([r.double() for r in rows])
   out = np.zeros((n, n))
   for i in range(n - 1):
-    xi = rows[i].double()
-    for j in range(i + 1, n):
-      if rows[j] is rows[i]:
-        continue
-      diff = rows[j].double().sub_(xi)
-      out[i, j] = out[j, i] = torch.dot(diff, diff).item()
+    diff = st[i + 1:] - st[i]
+    vals = (diff * diff).sum(dim=1).cpu().numpy()
+    out[i, i + 1:] = vals
+    out[i + 1:, i] = vals
+    del diff
   return out
 
 
@@ -123,21 +123,28 @@ def test_full_size_c4_bulyan_against_fp64(bm):
   # neighbours in the ranking are either exactly tied (aliased Byzantine rows: index order) or well apart
   assert all(scores[a] == scores[b] or scores[b] - scores[a] > 1e-5 * scores[b] for a, b in zip(order, order[1:]))
   assert got == order
-  # pass 2 in fp64 on the GPU from the ranking we obtained (bulyan.py:64-84, static scores)
+  # pass 2 with the reference's own fp32 arithmetic on the GPU (bulyan.py:64-84, static scores): sequential
+  # sums in rank order, true division (tensor / tensor: torch's scalar division multiplies by a reciprocal)
   sel = []
   for i in range(theta):
     cnt = min(m, m - i)
-    acc = torch.zeros(d, dtype=torch.float64, device=DEV)
+    acc = torch.zeros(d, dtype=torch.float32, device=DEV)
     for r in got[i:i + cnt]:
-      acc += rows[r]
-    sel.append((acc / cnt).float())
+      acc = acc + rows[r]
+    sel.append(torch.div(acc, torch.full_like(acc, float(cnt))))
   sel = torch.stack(sel)
   med = sel.median(dim=0).values
-  idx = (sel - med).abs().topk(beta, dim=0, largest=False, sorted=False).indices
+  dev = (sel - med).abs()
+  srt = dev.sort(dim=0).values
+  idx = dev.topk(beta, dim=0, largest=False, sorted=False).indices
   want = sel.gather(0, idx).double().mean(dim=0)
   out = bm.bulyan(rows, f)
   scale = float(torch.stack([r.abs().max() for r in rows[:h]]).max())
-  assert float((out.double() - want).abs().max()) <= 4e-6 * scale
+  bad = (out.double() - want).abs() > 2e-6 * scale
+  # the only legitimate disagreement: the beta-th and (beta+1)-th deviations tie, topk may keep either
+  tie = srt[beta - 1] == srt[beta]
+  assert int((bad & ~tie).sum()) == 0, int((bad & ~tie).sum())
+  assert int(tie.sum()) <= d // 1000, ("tie columns", int(tie.sum()))
 
 
 # ---------------------------------------------------------------------------- #
@@ -153,8 +160,8 @@ def test_tight_and_momentum_stacks_in_every_pair_mode(mode):
 
 
 def test_accuracy_gate_hands_over_to_the_direct_kernel():
-  """BM_PAIR_TAU=1e30 flags every pair: the gated direct kernel must then produce exactly what
-  BM_PAIR_MODE=1 produces (same kernel, same reduction order)."""
+  """BM_PAIR_TAU=1e30 lists every row: the gated direct kernel must then produce what BM_PAIR_MODE=1
+  produces (same kernel; the grid may differ, hence equality to fp64 rounding, not bitwise)."""
   code = (
     "import torch, sys\n"
     "import byzantinemomentum_amd as bm\n"
@@ -172,7 +179,8 @@ def test_accuracy_gate_hands_over_to_the_direct_kernel():
       out = subprocess.run([sys.executable, "-c", code, path], capture_output=True, text=True, env=env, cwd=ROOT)
       assert out.returncode == 0, out.stderr[-2000:]
       paths.append(path)
-    assert torch.equal(torch.load(paths[0]), torch.load(paths[1]))
+    a, b = torch.load(paths[0]), torch.load(paths[1])
+    assert float(((a - b).abs() / b.clamp(min=1e-300)).max()) <= 1e-9 and torch.equal(a, a.T)
 
 
 # ---------------------------------------------------------------------------- #
