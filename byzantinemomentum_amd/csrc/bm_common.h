@@ -211,6 +211,8 @@ struct Tuning {
   int pair_mode;       // BM_PAIR_MODE: 0 = centred bf16x3 Gram (default), 1 = direct differences, 2 = fp32 Gram
   int pair_centre;     // BM_PAIR_CENTRE (mode 0): 2 (default) median of three rows, 1 row mean, 0 none (experiments)
   int pair_planes;     // BM_PAIR_PLANES (mode 0): 0 (default) by length, 2 or 3 forced
+  int step_stream;     // BM_STEP_STREAM: 1 = streaming (pivot) form of bm_momentum_stats, 0 = register-resident two-pass form
+  int step_vec;        // BM_STEP_VEC: 0 (default) automatic, 1/2/4 cap the vector width of bm_momentum_stats (experiments)
   double pair_tau;     // BM_PAIR_TAU: accuracy gate of the Gram modes (see gram_to_sqdist_kernel); <= 0 disables
 };
 const Tuning& tuning();

@@ -150,6 +150,131 @@ __global__ __launch_bounds__(kStepBlock) void momentum_stats_kernel(
   }
 }
 
+// Streaming form of the same pass: the rows of a coordinate group are consumed one after the other and
+// only running sums are kept, so the register footprint does not grow with the number of rows
+// (VEC = 4 at four waves per SIMD instead of two).  Deviations use the first row p = x_0 as a pivot:
+//   sum_i (x_i - a)^2 = sum_i d_i^2 - 2 (a - p) sum_i d_i + k (a - p)^2,   d_i = x_i - p,
+// with a the (rounded, sequential) mean.  The pivot's own deviation (a - p)^2 is part of the result, hence
+// sum d_i^2 <= (k + 1) * result: the subtraction cancels at most a factor k + 1, never catastrophically.
+template <int T, int VEC>
+__global__ __launch_bounds__(kStepBlock, 4) void momentum_stats_stream_kernel(
+    StepTable tab, int ks, int h, int64_t nvec, float mu, float omd, const float* __restrict__ clipf,
+    float* __restrict__ s_avg_out, float* __restrict__ h_avg_out, float* __restrict__ byz_out, float scale,
+    int attack_kind, double* __restrict__ partial) {
+  __shared__ double red[kStepBlock / 64];
+  __shared__ float mred[kStepBlock / 64];
+  const float fks = (float)ks, fh = (float)h;
+  float n2s = 0.0f, dvs = 0.0f, mxs = 0.0f, n2h = 0.0f, dvh = 0.0f, mxh = 0.0f;
+  bool nan_s = false, nan_h = false;
+  float cf[T];
+#pragma unroll
+  for (int i = 0; i < T; ++i) cf[i] = (clipf != nullptr && i < ks) ? clipf[i] : 1.0f;
+  const int64_t stride = (int64_t)gridDim.x * kStepBlock;
+  for (int64_t v = (int64_t)blockIdx.x * kStepBlock + threadIdx.x; v < nvec; v += stride) {
+    float ps[VEC], ss[VEC], qs[VEC], ts[VEC];  // sampled: pivot, sequential sum, sum d^2, sum d
+    float ph[VEC], sh[VEC], qh[VEC], th[VEC];  // honest
+    // rows in batches of kBatch: the 2*kBatch loads of a batch are issued together (row indices clamped,
+    // so no load sits behind a branch), the arithmetic of rows that do not exist is skipped
+    constexpr int kBatch = 4;
+#pragma unroll
+    for (int base = 0; base < T; base += kBatch) {
+      if (base < ks) {  // wave-uniform
+        float g[kBatch][VEC], b[kBatch][VEC];
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+          const int i = base + j;
+          load_stream<VEC>(tab.g[i] + v * VEC, g[j]);  // entries >= ks repeat the last row (host-side padding)
+          if (base < h) load_stream<VEC>(tab.b[i] + v * VEC, b[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j) {
+          const int i = base + j;
+          // branch-free arithmetic (rows that do not exist are masked with wave-uniform selects): a load
+          // whose only use sits behind a branch would be sunk into it and lose its place in the batch
+          const bool on_s = i < ks, on_h = i < h;
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) {
+            const float gv = g[j][c] * cf[i < T ? i : T - 1];
+            if (i == 0) {
+              ps[c] = gv;
+              ss[c] = gv;
+              qs[c] = 0.0f;
+              ts[c] = 0.0f;
+            } else {
+              const float dd = on_s ? gv - ps[c] : 0.0f;
+              ss[c] += on_s ? gv : 0.0f;
+              qs[c] = __builtin_fmaf(dd, dd, qs[c]);
+              ts[c] += dd;
+            }
+            g[j][c] = gv;
+          }
+          if (base < h) {  // wave-uniform, the loads of b sit in the same region
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) b[j][c] = __builtin_fmaf(omd, g[j][c], mu * b[j][c]);
+            if (on_h) store_stream<VEC>(tab.b[i] + v * VEC, b[j]);
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) {
+              if (i == 0) {
+                ph[c] = b[j][c];
+                sh[c] = b[j][c];
+                qh[c] = 0.0f;
+                th[c] = 0.0f;
+              } else {
+                const float dd = on_h ? b[j][c] - ph[c] : 0.0f;
+                sh[c] += on_h ? b[j][c] : 0.0f;
+                qh[c] = __builtin_fmaf(dd, dd, qh[c]);
+                th[c] += dd;
+              }
+            }
+          }
+        }
+      }
+    }
+    float sa[VEC], ha[VEC], bz[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      const float s = ss[c] / fks;
+      sa[c] = s;
+      n2s = __builtin_fmaf(s, s, n2s);
+      mxs = fmaxf(mxs, __builtin_fabsf(s));
+      nan_s |= (s != s);
+      const float es = s - ps[c];
+      dvs += __builtin_fmaf(es, __builtin_fmaf(fks, es, -2.0f * ts[c]), qs[c]);
+      const float t = sh[c] / fh;
+      ha[c] = t;
+      n2h = __builtin_fmaf(t, t, n2h);
+      mxh = fmaxf(mxh, __builtin_fabsf(t));
+      nan_h |= (t != t);
+      const float eh = t - ph[c];
+      float colq = __builtin_fmaf(eh, __builtin_fmaf(fh, eh, -2.0f * th[c]), qh[c]);
+      colq = colq < 0.0f ? 0.0f : colq;  // rounding of a column whose rows coincide; NaN stays NaN
+      dvh += colq;
+      const float dir = (attack_kind == BM_ATTACK_LITTLE) ? __builtin_sqrtf(colq / (fh - 1.0f)) : -t;
+      bz[c] = t + dir * scale;
+    }
+    if (s_avg_out != nullptr) store_stream<VEC>(s_avg_out + v * VEC, sa);
+    if (h_avg_out != nullptr) store_stream<VEC>(h_avg_out + v * VEC, ha);
+    if (byz_out != nullptr) store_stream<VEC>(byz_out + v * VEC, bz);
+  }
+  if (nan_s) mxs = __builtin_nanf("");
+  if (nan_h) mxh = __builtin_nanf("");
+  const double r0 = block_reduce_sum<kStepBlock>((double)n2s, red);
+  const double r1 = block_reduce_sum<kStepBlock>((double)dvs, red);
+  const double r3 = block_reduce_sum<kStepBlock>((double)n2h, red);
+  const double r4 = block_reduce_sum<kStepBlock>((double)dvh, red);
+  const float r2 = block_reduce_absmax<kStepBlock>(mxs, mred);
+  const float r5 = block_reduce_absmax<kStepBlock>(mxh, mred);
+  if (threadIdx.x == 0) {
+    double* p = partial + (int64_t)blockIdx.x * 6;
+    p[0] = r0;
+    p[1] = r1 < 0.0 ? 0.0 : r1;
+    p[2] = (double)r2;
+    p[3] = r3;
+    p[4] = r4;
+    p[5] = (double)r5;
+  }
+}
+
 // Fixed-order reduction of [nparts][6] partials: slots 0,1,3,4 are sums, 2 and 5 NaN-propagating maxima.
 __global__ __launch_bounds__(64) void step_finish_kernel(const double* __restrict__ partial, int nparts,
                                                          double* __restrict__ out6) {
@@ -193,8 +318,22 @@ template <int T, int VEC>
 static int launch_momentum_stats(const StepTable& tab, int ks, int h, int64_t nvec, float mu, float omd,
                                  const float* clipf, float* s_avg, float* h_avg, float* byz, float scale, int kind,
                                  double* partial, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((momentum_stats_kernel<T, VEC>), dim3(grid), dim3(kStepBlock), 0, s, tab, ks, h, nvec, mu, omd,
-                     clipf, s_avg, h_avg, byz, scale, kind, partial);
+  if (tuning().step_stream)
+    hipLaunchKernelGGL((momentum_stats_stream_kernel<T, VEC>), dim3(grid), dim3(kStepBlock), 0, s, tab, ks, h, nvec,
+                       mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial);
+  else
+    hipLaunchKernelGGL((momentum_stats_kernel<T, VEC>), dim3(grid), dim3(kStepBlock), 0, s, tab, ks, h, nvec, mu, omd,
+                       clipf, s_avg, h_avg, byz, scale, kind, partial);
+  BM_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int T, int VEC>
+static int launch_momentum_stats_stream(const StepTable& tab, int ks, int h, int64_t nvec, float mu, float omd,
+                                        const float* clipf, float* s_avg, float* h_avg, float* byz, float scale,
+                                        int kind, double* partial, int grid, hipStream_t s) {
+  hipLaunchKernelGGL((momentum_stats_stream_kernel<T, VEC>), dim3(grid), dim3(kStepBlock), 0, s, tab, ks, h, nvec,
+                     mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial);
   BM_LAUNCH_CHECK();
   return 0;
 }
@@ -209,6 +348,10 @@ static int dispatch_momentum_stats(const StepTable& tab, int ks, int h, int64_t 
   if (t <= 8) return launch_momentum_stats<8, VEC>(BM_STEP_ARGS);
   if (t <= 12) return launch_momentum_stats<12, VEC>(BM_STEP_ARGS);
   if (t <= 20) return launch_momentum_stats<20, VEC>(BM_STEP_ARGS);
+  if (tuning().step_stream) {
+    if (t <= 40) return launch_momentum_stats_stream<40, VEC>(BM_STEP_ARGS);
+    return launch_momentum_stats_stream<64, VEC>(BM_STEP_ARGS);
+  }
   if constexpr (VEC <= 2) {
     if (t <= 40) return launch_momentum_stats<40, VEC>(BM_STEP_ARGS);
   }
@@ -306,11 +449,17 @@ extern "C" int bm_momentum_stats(const float* const* sampled, int ks, float* con
     tab.b[i] = buffers[i];
     bits |= reinterpret_cast<uintptr_t>(buffers[i]);
   }
+  // pad the tables with their last row: the streaming kernel loads whole batches unconditionally
+  for (int i = ks; i < BM_MAX_ROWS; ++i) tab.g[i] = sampled[ks - 1];
+  for (int i = h; i < BM_MAX_ROWS; ++i) tab.b[i] = buffers[h - 1];
   double* partial = static_cast<double*>(ws);
   int vec = vec_of(bits);
   const int t = ks > h ? ks : h;
-  if (t > 20 && vec > 2) vec = 2;   // register budget: 2*T*VEC values per lane
-  if (t > 40) vec = 1;
+  if (tuning().step_vec > 0 && vec > tuning().step_vec) vec = tuning().step_vec;
+  if (!tuning().step_stream) {
+    if (t > 20 && vec > 2) vec = 2;  // register-resident form: 2*T*VEC values per lane
+    if (t > 40) vec = 1;
+  }
   int nparts = 0;
   int64_t body = 0;
   int rc = 0;
@@ -327,8 +476,10 @@ extern "C" int bm_momentum_stats(const float* const* sampled, int ks, float* con
   }
   if (body < d) {
     StepTable tail = tab;
-    for (int i = 0; i < ks; ++i) tail.g[i] += body;
-    for (int i = 0; i < h; ++i) tail.b[i] += body;
+    for (int i = 0; i < BM_MAX_ROWS; ++i) {
+      tail.g[i] += body;
+      tail.b[i] += body;
+    }
     const int64_t rest = d - body;
     const int grid = (body == 0) ? stream_grid(rest, kStepBlock, kStepMaxBlocks) : 1;
     rc = dispatch_momentum_stats<1>(tail, ks, h, rest, mu, one_minus_damp, clip_factors,

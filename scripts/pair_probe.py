@@ -102,10 +102,39 @@ def timing(ns=(25, 51, 16, 64)):
     del stacks
 
 
+def near_duplicates():
+  """Timing of the accuracy gate's slow path: f rows that are near-duplicates of each other (1e-3 relative
+  jitter) inside an otherwise ordinary stack -> the direct kernel recomputes that sub-stack."""
+  d = 11173962
+  for n, f in ((25, 5), (51, 12)):
+    gen = torch.Generator(device="cuda").manual_seed(n)
+    rows = [torch.randn(d, device="cuda", generator=gen) for _ in range(n - f)]
+    byz = -0.1 * torch.stack(rows[:4]).mean(dim=0)
+    rows += [byz + 1e-3 * byz.abs().mean() * torch.randn(d, device="cuda", generator=gen) for _ in range(f)]
+    for i in range(3):
+      bm.gars.pairwise_sqdist(rows)
+    torch.cuda.synchronize()
+    evs = []
+    for i in range(10):
+      a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+      a.record()
+      sq = bm.gars.pairwise_sqdist(rows)
+      b.record()
+      evs.append((a, b))
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    i, j = n - 1, n - 2
+    want = (rows[i].double() - rows[j].double()).pow(2).sum().item()
+    print(f"dup n={n} f={f} pairwise median {ts[5]*1e3:.0f} us best {ts[0]*1e3:.0f} us; near-duplicate pair relerr "
+          f"{abs(sq[i, j].item() - want) / want:.1e} [{TAG}]", flush=True)
+
+
 if __name__ == "__main__":
   what = sys.argv[1:] or ["acc", "time"]
   if "acc" in what:
     accuracy()
+  if "dup" in what:
+    near_duplicates()
   for w in what:
     if w.startswith("time"):
       timing(tuple(int(v) for v in w.split(":")[1].split(",")) if ":" in w else (25, 51, 16, 64))
