@@ -158,6 +158,37 @@ __device__ __forceinline__ void store_stream_off(float* base, uint32_t byte_off,
   store_stream<VEC>(reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off), src);
 }
 
+// Stores of RESULT vectors (the aggregated gradient, averages, the Byzantine vector) with the default
+// cache policy instead of non-temporal — the measured alternative, selected with BM_RESULT_NT=0.
+// A/B on one GPU (profiles/r02_b_store_policy_ab.txt): kernel times are the same either way, but a whole
+// C5 step takes 4.8-5.0 ms with cacheable result stores against 3.6-3.7 ms with non-temporal ones (dirty
+// lines are written back at the kernel boundaries).  What a result store really costs is its place in the
+// in-order vmcnt queue, see colwise_kernels.h.
+template <int VEC>
+__device__ __forceinline__ void store_result(float* p, const float (&src)[VEC]) {
+  using T = typename VecLoad<VEC>::T;
+  T v;
+  if constexpr (VEC == 1) {
+    v = src[0];
+  } else {
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) v[c] = src[c];
+  }
+  *reinterpret_cast<T*>(p) = v;
+}
+template <int VEC>
+__device__ __forceinline__ void store_result_off(float* base, uint32_t byte_off, const float (&src)[VEC]) {
+  store_result<VEC>(reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off), src);
+}
+// wave-uniform choice between the two policies (BM_RESULT_NT, A/B runs)
+template <int VEC>
+__device__ __forceinline__ void store_result_policy(float* p, const float (&src)[VEC], int nt) {
+  if (nt)
+    store_stream<VEC>(p, src);
+  else
+    store_result<VEC>(p, src);
+}
+
 // Columns per launch such that every byte offset fits 32 bits (saddr addressing).
 constexpr int64_t kMaxColsPerLaunch = (int64_t)1 << 29;
 
@@ -212,6 +243,10 @@ struct Tuning {
   int pair_centre;     // BM_PAIR_CENTRE (mode 0): 2 (default) median of three rows, 1 row mean, 0 none (experiments)
   int pair_planes;     // BM_PAIR_PLANES (mode 0): 0 (default) by length, 2 or 3 forced
   int step_stream;     // BM_STEP_STREAM: 1 = streaming (pivot) form of bm_momentum_stats, 0 = register-resident two-pass form
+  int result_nt;       // BM_RESULT_NT: 1 (default) non-temporal stores for result vectors, 0 = default cache policy (experiments)
+  int col_ablate;      // BM_COL_ABLATE: 1 = median/trmean at n=25 without the output store (experiment)
+  int step_store;      // BM_STEP_STORE: 0 non-temporal buffer stores (default), 1 plain stores (experiments)
+  int step_blocks;     // BM_STEP_BLOCKS: grid cap of bm_momentum_stats, 0 = default
   int step_vec;        // BM_STEP_VEC: 0 (default) automatic, 1/2/4 cap the vector width of bm_momentum_stats (experiments)
   double pair_tau;     // BM_PAIR_TAU: accuracy gate of the Gram modes (see gram_to_sqdist_kernel); <= 0 disables
 };

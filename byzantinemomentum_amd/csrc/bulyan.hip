@@ -23,7 +23,7 @@ constexpr int kBulBlock = 256;
 template <int N, int F, int VEC>
 __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(RowTable rows,
                                                                  const int32_t* __restrict__ order,
-                                                                 int64_t nvec,
+                                                                 int64_t nvec, int nt_result,
                                                                  float* __restrict__ out) {
   constexpr int MMAX = N - F - 2;
   constexpr int THETA = N - 2 * F - 2;
@@ -45,9 +45,9 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(RowTable rows,
   const float kNaN = __builtin_nanf("");
   const uint32_t nv = (uint32_t)nvec;  // nvec * VEC * 4 < 2^32: the host splits longer gradients
   const uint32_t stride = gridDim.x * kBulBlock;
-  for (uint32_t v = blockIdx.x * kBulBlock + threadIdx.x; v < nv; v += stride) {
-    const uint32_t off = v * (uint32_t)(VEC * sizeof(float));
-    float x[VEC][MMAX];
+  // per column group: load the m_max ranked values, store the PREVIOUS group's result behind those loads
+  // (in-order vmcnt, see colwise_kernels.h), then the arithmetic
+  auto load_group = [&](uint32_t off, float (&x)[VEC][MMAX]) {
 #pragma unroll
     for (int t = 0; t < MMAX; ++t) {
       float tmp[VEC];
@@ -55,7 +55,8 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(RowTable rows,
 #pragma unroll
       for (int c = 0; c < VEC; ++c) x[c][t] = tmp[c];
     }
-    float r[VEC];
+  };
+  auto rule = [&](float (&x)[VEC][MMAX], float (&r)[VEC]) {
 #pragma unroll
     for (int c = 0; c < VEC; ++c) {
       // selected[i]: forward sequential sum from rank i to m_max-1, exact division by the count
@@ -86,7 +87,21 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(RowTable rows,
       const float res = div_small_int(w, (float)BETA, 1.0f / (float)BETA);
       r[c] = has_nan ? kNaN : res;
     }
-    store_stream_off<VEC>(out, off, r);
+  };
+  uint32_t v = blockIdx.x * kBulBlock + threadIdx.x;
+  if (v < nv) {
+    float x[VEC][MMAX], pend[VEC];
+    uint32_t pend_off = v * (uint32_t)(VEC * sizeof(float));
+    load_group(pend_off, x);
+    rule(x, pend);
+    for (v += stride; v < nv; v += stride) {
+      const uint32_t off = v * (uint32_t)(VEC * sizeof(float));
+      load_group(off, x);
+      store_result_policy<VEC>(reinterpret_cast<float*>(reinterpret_cast<char*>(out) + pend_off), pend, nt_result);
+      rule(x, pend);
+      pend_off = off;
+    }
+    store_result_policy<VEC>(reinterpret_cast<float*>(reinterpret_cast<char*>(out) + pend_off), pend, nt_result);
   }
 }
 
@@ -160,14 +175,14 @@ static int launch_bulyan_fast(const float* const* rows_host, const int32_t* orde
       const int64_t nvec = d / 4;
       hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 4 ? 4 : 1)>),
                          dim3(stream_grid(nvec, kBulBlock, tuning().col_max_blocks)), dim3(kBulBlock), 0,
-                         s, tab, order, nvec, out);
+                         s, tab, order, nvec, tuning().result_nt, out);
       BM_LAUNCH_CHECK();
       body = nvec * 4;
     } else if (vec == 2 && kMaxVec >= 2 && d / 2 > 0) {
       const int64_t nvec = d / 2;
       hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 2 ? 2 : 1)>),
                          dim3(stream_grid(nvec, kBulBlock, tuning().col_max_blocks)), dim3(kBulBlock), 0,
-                         s, tab, order, nvec, out);
+                         s, tab, order, nvec, tuning().result_nt, out);
       BM_LAUNCH_CHECK();
       body = nvec * 2;
     }
@@ -177,7 +192,7 @@ static int launch_bulyan_fast(const float* const* rows_host, const int32_t* orde
       const int64_t rest = d - body;
       hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, 1>),
                          dim3(stream_grid(rest, kBulBlock, tuning().col_max_blocks)), dim3(kBulBlock), 0,
-                         s, tail, order, rest, out + body);
+                         s, tail, order, rest, tuning().result_nt, out + body);
       BM_LAUNCH_CHECK();
     }
   }
@@ -218,7 +233,7 @@ __global__ __launch_bounds__(kColBlock) void aksel_pass1_kernel(RowTable rows, i
         acc[i] += df * df;  // (x - m).pow_(2).sum()
       }
     }
-    if (median_out != nullptr) store_stream<VEC>(median_out + v * VEC, med);
+    if (median_out != nullptr) store_result<VEC>(median_out + v * VEC, med);
   }
 #pragma unroll
   for (int i = 0; i < N; ++i) {
@@ -290,7 +305,7 @@ int64_t pairwise_workspace_bytes(int n, int64_t d);  // pairwise.hip
 extern "C" int bm_bulyan_pass2(const float* const* rows, int n, const int32_t* order, int f, int m,
                                int64_t d, float* out, void* stream) {
   using namespace bm;
-  if (rows == nullptr || order == nullptr || out == nullptr || n < 1 || n > BM_MAX_ROWS || f < 1 ||
+  if (rows == nullptr || order == nullptr || (out == nullptr && d > 0) || n < 1 || n > BM_MAX_ROWS || f < 1 ||
       n < 4 * f + 3 || m < 1 || m > n - f - 2 || d < 0)
     return BM_EINVAL;
   if (d == 0) return 0;
@@ -336,7 +351,8 @@ extern "C" int bm_bulyan_pass2(const float* const* rows, int n, const int32_t* o
 extern "C" int bm_aksel_pass1(const float* const* rows, int n, int64_t d, float* median_out,
                               double* sq_out, void* ws, void* stream) {
   using namespace bm;
-  if (rows == nullptr || sq_out == nullptr || ws == nullptr || n < 1 || n > BM_MAX_ROWS || d < 1)
+  // d == 0 (an empty shard) is legal: no partials, the finish kernel writes zeros
+  if (rows == nullptr || sq_out == nullptr || ws == nullptr || n < 1 || n > BM_MAX_ROWS || d < 0)
     return BM_EINVAL;
   return dispatch_aksel(std::make_integer_sequence<int, BM_MAX_ROWS>{}, rows, n, d, median_out,
                         sq_out, static_cast<double*>(ws), static_cast<hipStream_t>(stream));

@@ -33,8 +33,16 @@ static int launch_colwise_vec(const RowTable& rows_all, int64_t d_all, int f, fl
     const int64_t nvec = d / VEC;
     const int tail = (int)(d - nvec * VEC);
     const int grid = stream_grid(nvec, kColBlock, tuning().col_max_blocks);
+    if constexpr (N == 25 && VEC == 4 && (OP == BM_OP_MEDIAN || OP == BM_OP_TRMEAN)) {
+      if (tuning().col_ablate == 1) {  // experiment only: the read-only rate of the same kernel
+        hipLaunchKernelGGL((colwise_kernel<N, OP, VEC, true>), dim3(grid), dim3(kColBlock), 0, stream, rows,
+                           nvec, tail, f, inv_keep, tuning().result_nt, out_all + lo);
+        BM_LAUNCH_CHECK();
+        continue;
+      }
+    }
     hipLaunchKernelGGL((colwise_kernel<N, OP, VEC>), dim3(grid), dim3(kColBlock), 0, stream, rows,
-                       nvec, tail, f, inv_keep, out_all + lo);
+                       nvec, tail, f, inv_keep, tuning().result_nt, out_all + lo);
     BM_LAUNCH_CHECK();
   }
   return 0;
@@ -74,7 +82,7 @@ static int dispatch_n(std::integer_sequence<int, Ns...>, const float* const* row
 extern "C" int bm_colwise(int op, const float* const* rows, int n, int64_t d, int f, float* out,
                           void* stream) {
   using namespace bm;
-  if (rows == nullptr || out == nullptr || n < 1 || n > BM_MAX_ROWS || d < 0) return BM_EINVAL;
+  if (rows == nullptr || (out == nullptr && d > 0) || n < 1 || n > BM_MAX_ROWS || d < 0) return BM_EINVAL;
   if (d == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   auto seq = std::make_integer_sequence<int, BM_MAX_ROWS>{};

@@ -275,7 +275,7 @@ __global__ __launch_bounds__(64 * W) void gram_partial_kernel(RowTable rows, Gra
 }
 
 // G = sum over workgroups (fixed order), then sq[i][j] = G_ii + G_jj - 2 G_ij in fp64.
-constexpr int kGramRedWaves = 8;
+constexpr int kGramRedWaves = 16;  // 16 waves x 16 loads in flight: the sum is a latency chain over L2/HBM
 __global__ __launch_bounds__(64 * kGramRedWaves) void gram_reduce_kernel(const double* __restrict__ partial,
                                                                          int nblocks, int n,
                                                                          double* __restrict__ gram) {
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(64 * kGramRedWaves) void gram_reduce_kernel(const d
   const int e = blockIdx.x * 64 + lane;
   double s = 0.0;
   if (e < per_block) {
-#pragma unroll 8
+#pragma unroll 16
     for (int blk = wave; blk < nblocks; blk += kGramRedWaves) s += partial[(int64_t)blk * per_block + e];
   }
   wsum[wave][lane] = s;

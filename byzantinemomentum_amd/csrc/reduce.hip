@@ -21,27 +21,45 @@ constexpr int kMaxPartialBlocks = 2048;
 template <int VEC>
 __global__ __launch_bounds__(kRedBlock) void selected_mean_kernel(RowTable rows,
                                                                   const int32_t* __restrict__ idx,
-                                                                  int m, int64_t nvec, float fm,
+                                                                  int m, int64_t nvec, float fm, int nt_result,
                                                                   float* __restrict__ out) {
   __shared__ const float* sel[BM_MAX_ROWS];
   if (threadIdx.x < m) sel[threadIdx.x] = rows.p[idx[threadIdx.x]];
   __syncthreads();
   const int64_t stride = (int64_t)gridDim.x * kRedBlock;
+  // The mean of column group v is stored after the first loads of group v+stride have been issued: loads
+  // and stores share the in-order vmcnt counter on gfx950, a store issued first would make the wait for the
+  // next loads also wait for the store's acknowledgement (see colwise_kernels.h).
+  constexpr int kFirst = 8;  // loads issued before the pending store
+  float pend[VEC];
+  int64_t pend_v = -1;
   for (int64_t v = (int64_t)blockIdx.x * kRedBlock + threadIdx.x; v < nvec; v += stride) {
+    float first[kFirst][VEC];
+#pragma unroll
+    for (int k = 0; k < kFirst; ++k)
+      if (k < m) load_stream<VEC>(sel[k] + v * VEC, first[k]);
+    if (pend_v >= 0) store_result_policy<VEC>(out + pend_v * VEC, pend, nt_result);
     float acc[VEC];
 #pragma unroll
     for (int c = 0; c < VEC; ++c) acc[c] = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kFirst; ++k)
+      if (k < m) {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) acc[c] += first[k][c];
+      }
 #pragma unroll 8
-    for (int k = 0; k < m; ++k) {
+    for (int k = kFirst; k < m; ++k) {
       float t[VEC];
       load_stream<VEC>(sel[k] + v * VEC, t);
 #pragma unroll
       for (int c = 0; c < VEC; ++c) acc[c] += t[c];
     }
 #pragma unroll
-    for (int c = 0; c < VEC; ++c) acc[c] = acc[c] / fm;
-    store_stream<VEC>(out + v * VEC, acc);
+    for (int c = 0; c < VEC; ++c) pend[c] = acc[c] / fm;
+    pend_v = v;
   }
+  if (pend_v >= 0) store_result_policy<VEC>(out + pend_v * VEC, pend, nt_result);
 }
 
 template <int VEC>
@@ -50,7 +68,7 @@ static int launch_selected_mean(const RowTable& tab, const int32_t* idx, int m, 
   if (nvec <= 0) return 0;
   const int grid = stream_grid(nvec, kRedBlock, 256 * 32);
   hipLaunchKernelGGL(selected_mean_kernel<VEC>, dim3(grid), dim3(kRedBlock), 0, s, tab, idx, m, nvec,
-                     (float)m, out);
+                     (float)m, tuning().result_nt, out);
   BM_LAUNCH_CHECK();
   return 0;
 }
@@ -98,7 +116,7 @@ __global__ __launch_bounds__(kRedBlock) void stack_stats_kernel(RowTable rows, i
       dev2 += q;
       colq[c] = q;
     }
-    if (avg_out != nullptr) store_stream<VEC>(avg_out + v * VEC, avg);
+    if (avg_out != nullptr) store_result<VEC>(avg_out + v * VEC, avg);
     if (scaled_out != nullptr) {
       float sc[VEC];
 #pragma unroll
@@ -108,7 +126,7 @@ __global__ __launch_bounds__(kRedBlock) void stack_stats_kernel(RowTable rows, i
         const float att = dir * scale;  // grad_att.mul_(factor)
         sc[c] = avg[c] + att;           // byz_grad = grad_avg.add_(grad_att)
       }
-      store_stream<VEC>(scaled_out + v * VEC, sc);
+      store_result<VEC>(scaled_out + v * VEC, sc);
     }
   }
   // torch's abs().max() propagates NaN; fmaxf does not
@@ -330,7 +348,7 @@ __global__ __launch_bounds__(64) void stable_argsort_kernel(const double* __rest
 extern "C" int bm_selected_mean(const float* const* rows, int n, const int32_t* idx, int m,
                                 int64_t d, float* out, void* stream) {
   using namespace bm;
-  if (rows == nullptr || idx == nullptr || out == nullptr || n < 1 || n > BM_MAX_ROWS || m < 1 ||
+  if (rows == nullptr || idx == nullptr || (out == nullptr && d > 0) || n < 1 || n > BM_MAX_ROWS || m < 1 ||
       m > BM_MAX_ROWS || d < 0)
     return BM_EINVAL;
   if (d == 0) return 0;

@@ -147,8 +147,9 @@ extern "C" int64_t bm_sharded_workspace_bytes(int n, int64_t d_local) {
 
 extern "C" int bm_sharded_krum(bm_comm* comm, const float* const* rows, int n, int64_t d_local, int f, int m,
                                float* out_local, int32_t* order_out, void* ws, void* stream) {
-  if (rows == nullptr || out_local == nullptr || ws == nullptr || n < 1 || n > BM_MAX_ROWS || d_local < 0 || f < 0 ||
-      m < 1 || m > n)
+  // an empty shard (d_local == 0) has no output buffer: torch.empty(0).data_ptr() is NULL
+  if (rows == nullptr || (out_local == nullptr && d_local > 0) || ws == nullptr || n < 1 || n > BM_MAX_ROWS ||
+      d_local < 0 || f < 0 || m < 1 || m > n)
     return BM_EINVAL;
   double* sq;
   int32_t* order;
@@ -164,8 +165,9 @@ extern "C" int bm_sharded_krum(bm_comm* comm, const float* const* rows, int n, i
 
 extern "C" int bm_sharded_bulyan(bm_comm* comm, const float* const* rows, int n, int64_t d_local, int f, int m,
                                  float* out_local, int32_t* order_out, void* ws, void* stream) {
-  if (rows == nullptr || out_local == nullptr || ws == nullptr || n < 1 || n > BM_MAX_ROWS || d_local < 0 || f < 0 ||
-      m < 1 || m > n)
+  // an empty shard (d_local == 0) has no output buffer: torch.empty(0).data_ptr() is NULL
+  if (rows == nullptr || (out_local == nullptr && d_local > 0) || ws == nullptr || n < 1 || n > BM_MAX_ROWS ||
+      d_local < 0 || f < 0 || m < 1 || m > n)
     return BM_EINVAL;
   double* sq;
   int32_t* order;

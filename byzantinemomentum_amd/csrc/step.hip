@@ -49,11 +49,11 @@ __device__ __forceinline__ float block_reduce_absmax(float m, float* lds) {
 }
 
 // T = compile-time bound on max(ks, h); rows beyond ks / h are predicated off (wave-uniform).
-template <int T, int VEC>
+template <int T, int VEC, bool PLAIN_STORE = false>
 __global__ __launch_bounds__(kStepBlock) void momentum_stats_kernel(
     StepTable tab, int ks, int h, int64_t nvec, float mu, float omd, const float* __restrict__ clipf,
     float* __restrict__ s_avg_out, float* __restrict__ h_avg_out, float* __restrict__ byz_out, float scale,
-    int attack_kind, double* __restrict__ partial) {
+    int attack_kind, int nt_result, double* __restrict__ partial) {
   __shared__ double red[kStepBlock / 64];
   __shared__ float mred[kStepBlock / 64];
   const float fks = (float)ks, fh = (float)h;
@@ -81,7 +81,19 @@ __global__ __launch_bounds__(kStepBlock) void momentum_stats_kernel(
       if (i < h) {
 #pragma unroll
         for (int c = 0; c < VEC; ++c) b[i][c] = __builtin_fmaf(omd, g[i][c], mu * b[i][c]);
-        store_stream<VEC>(tab.b[i] + v * VEC, b[i]);
+        if constexpr (PLAIN_STORE) {
+          using TV = typename VecLoad<VEC>::T;
+          TV ov;
+          if constexpr (VEC == 1) {
+            ov = b[i][0];
+          } else {
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) ov[c] = b[i][c];
+          }
+          *reinterpret_cast<TV*>(tab.b[i] + v * VEC) = ov;
+        } else {
+          store_stream<VEC>(tab.b[i] + v * VEC, b[i]);
+        }
       }
     }
     float sa[VEC], ha[VEC], bz[VEC];
@@ -127,9 +139,9 @@ __global__ __launch_bounds__(kStepBlock) void momentum_stats_kernel(
       const float dir = (attack_kind == BM_ATTACK_LITTLE) ? __builtin_sqrtf(qh / (fh - 1.0f)) : -t;
       bz[c] = t + dir * scale;  // grad_att.mul_(factor); byz_grad = grad_avg.add_(grad_att)
     }
-    if (s_avg_out != nullptr) store_stream<VEC>(s_avg_out + v * VEC, sa);
-    if (h_avg_out != nullptr) store_stream<VEC>(h_avg_out + v * VEC, ha);
-    if (byz_out != nullptr) store_stream<VEC>(byz_out + v * VEC, bz);
+    if (s_avg_out != nullptr) store_result_policy<VEC>(s_avg_out + v * VEC, sa, nt_result);
+    if (h_avg_out != nullptr) store_result_policy<VEC>(h_avg_out + v * VEC, ha, nt_result);
+    if (byz_out != nullptr) store_result_policy<VEC>(byz_out + v * VEC, bz, nt_result);
   }
   if (nan_s) mxs = __builtin_nanf("");  // torch's abs().max() propagates NaN; fmaxf does not
   if (nan_h) mxh = __builtin_nanf("");
@@ -160,7 +172,7 @@ template <int T, int VEC>
 __global__ __launch_bounds__(kStepBlock, 4) void momentum_stats_stream_kernel(
     StepTable tab, int ks, int h, int64_t nvec, float mu, float omd, const float* __restrict__ clipf,
     float* __restrict__ s_avg_out, float* __restrict__ h_avg_out, float* __restrict__ byz_out, float scale,
-    int attack_kind, double* __restrict__ partial) {
+    int attack_kind, int nt_result, double* __restrict__ partial) {
   __shared__ double red[kStepBlock / 64];
   __shared__ float mred[kStepBlock / 64];
   const float fks = (float)ks, fh = (float)h;
@@ -170,12 +182,23 @@ __global__ __launch_bounds__(kStepBlock, 4) void momentum_stats_stream_kernel(
 #pragma unroll
   for (int i = 0; i < T; ++i) cf[i] = (clipf != nullptr && i < ks) ? clipf[i] : 1.0f;
   const int64_t stride = (int64_t)gridDim.x * kStepBlock;
+  // Stores are issued BEHIND the next loads: loads and stores share the in-order vmcnt counter on gfx950,
+  // so a store placed before a batch of loads makes the wait for those loads also wait for the store's
+  // acknowledgement from memory (measured on the column kernels: a result stream of 4 % of the bytes cost
+  // 11 % of the time).  The updated buffers of batch k are stored after the loads of batch k+1, the three
+  // result vectors of a column group after the first loads of the next group.
+  constexpr int kBatch = 4;
+  float r_sa[VEC], r_ha[VEC], r_bz[VEC];
+  int64_t r_v = -1;  // column group whose result vectors are still in registers
+  auto flush_results = [&]() {
+    if (s_avg_out != nullptr) store_result_policy<VEC>(s_avg_out + r_v * VEC, r_sa, nt_result);
+    if (h_avg_out != nullptr) store_result_policy<VEC>(h_avg_out + r_v * VEC, r_ha, nt_result);
+    if (byz_out != nullptr) store_result_policy<VEC>(byz_out + r_v * VEC, r_bz, nt_result);
+  };
   for (int64_t v = (int64_t)blockIdx.x * kStepBlock + threadIdx.x; v < nvec; v += stride) {
     float ps[VEC], ss[VEC], qs[VEC], ts[VEC];  // sampled: pivot, sequential sum, sum d^2, sum d
     float ph[VEC], sh[VEC], qh[VEC], th[VEC];  // honest
-    // rows in batches of kBatch: the 2*kBatch loads of a batch are issued together (row indices clamped,
-    // so no load sits behind a branch), the arithmetic of rows that do not exist is skipped
-    constexpr int kBatch = 4;
+    float bq[kBatch][VEC];                      // updated buffers of the previous batch, not stored yet
 #pragma unroll
     for (int base = 0; base < T; base += kBatch) {
       if (base < ks) {  // wave-uniform
@@ -185,6 +208,14 @@ __global__ __launch_bounds__(kStepBlock, 4) void momentum_stats_stream_kernel(
           const int i = base + j;
           load_stream<VEC>(tab.g[i] + v * VEC, g[j]);  // entries >= ks repeat the last row (host-side padding)
           if (base < h) load_stream<VEC>(tab.b[i] + v * VEC, b[j]);
+        }
+        // ---- behind these loads: what the previous batch / the previous column group left pending ----
+        if (base == 0) {
+          if (r_v >= 0) flush_results();
+        } else if (base - kBatch < h) {
+#pragma unroll
+          for (int j = 0; j < kBatch; ++j)
+            if (base - kBatch + j < h) store_stream<VEC>(tab.b[base - kBatch + j] + v * VEC, bq[j]);
         }
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
@@ -210,18 +241,17 @@ __global__ __launch_bounds__(kStepBlock, 4) void momentum_stats_stream_kernel(
           }
           if (base < h) {  // wave-uniform, the loads of b sit in the same region
 #pragma unroll
-            for (int c = 0; c < VEC; ++c) b[j][c] = __builtin_fmaf(omd, g[j][c], mu * b[j][c]);
-            if (on_h) store_stream<VEC>(tab.b[i] + v * VEC, b[j]);
-#pragma unroll
             for (int c = 0; c < VEC; ++c) {
+              const float bv = __builtin_fmaf(omd, g[j][c], mu * b[j][c]);
+              bq[j][c] = bv;
               if (i == 0) {
-                ph[c] = b[j][c];
-                sh[c] = b[j][c];
+                ph[c] = bv;
+                sh[c] = bv;
                 qh[c] = 0.0f;
                 th[c] = 0.0f;
               } else {
-                const float dd = on_h ? b[j][c] - ph[c] : 0.0f;
-                sh[c] += on_h ? b[j][c] : 0.0f;
+                const float dd = on_h ? bv - ph[c] : 0.0f;
+                sh[c] += on_h ? bv : 0.0f;
                 qh[c] = __builtin_fmaf(dd, dd, qh[c]);
                 th[c] += dd;
               }
@@ -230,18 +260,26 @@ __global__ __launch_bounds__(kStepBlock, 4) void momentum_stats_stream_kernel(
         }
       }
     }
-    float sa[VEC], ha[VEC], bz[VEC];
+    // the buffers of the last batch that held honest rows (a run-time batch index: wave-uniform table lookups)
+    {
+      const int lastb = ((h - 1) / kBatch) * kBatch;
+      if (lastb + kBatch >= ks) {  // otherwise a later (gradient-only) batch has already flushed it
+#pragma unroll
+        for (int j = 0; j < kBatch; ++j)
+          if (lastb + j < h) store_stream<VEC>(tab.b[lastb + j] + v * VEC, bq[j]);
+      }
+    }
 #pragma unroll
     for (int c = 0; c < VEC; ++c) {
       const float s = ss[c] / fks;
-      sa[c] = s;
+      r_sa[c] = s;
       n2s = __builtin_fmaf(s, s, n2s);
       mxs = fmaxf(mxs, __builtin_fabsf(s));
       nan_s |= (s != s);
       const float es = s - ps[c];
       dvs += __builtin_fmaf(es, __builtin_fmaf(fks, es, -2.0f * ts[c]), qs[c]);
       const float t = sh[c] / fh;
-      ha[c] = t;
+      r_ha[c] = t;
       n2h = __builtin_fmaf(t, t, n2h);
       mxh = fmaxf(mxh, __builtin_fabsf(t));
       nan_h |= (t != t);
@@ -250,12 +288,11 @@ __global__ __launch_bounds__(kStepBlock, 4) void momentum_stats_stream_kernel(
       colq = colq < 0.0f ? 0.0f : colq;  // rounding of a column whose rows coincide; NaN stays NaN
       dvh += colq;
       const float dir = (attack_kind == BM_ATTACK_LITTLE) ? __builtin_sqrtf(colq / (fh - 1.0f)) : -t;
-      bz[c] = t + dir * scale;
+      r_bz[c] = t + dir * scale;
     }
-    if (s_avg_out != nullptr) store_stream<VEC>(s_avg_out + v * VEC, sa);
-    if (h_avg_out != nullptr) store_stream<VEC>(h_avg_out + v * VEC, ha);
-    if (byz_out != nullptr) store_stream<VEC>(byz_out + v * VEC, bz);
+    r_v = v;
   }
+  if (r_v >= 0) flush_results();
   if (nan_s) mxs = __builtin_nanf("");
   if (nan_h) mxh = __builtin_nanf("");
   const double r0 = block_reduce_sum<kStepBlock>((double)n2s, red);
@@ -320,10 +357,13 @@ static int launch_momentum_stats(const StepTable& tab, int ks, int h, int64_t nv
                                  double* partial, int grid, hipStream_t s) {
   if (tuning().step_stream)
     hipLaunchKernelGGL((momentum_stats_stream_kernel<T, VEC>), dim3(grid), dim3(kStepBlock), 0, s, tab, ks, h, nvec,
-                       mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial);
+                       mu, omd, clipf, s_avg, h_avg, byz, scale, kind, tuning().result_nt, partial);
+  else if (tuning().step_store == 1)
+    hipLaunchKernelGGL((momentum_stats_kernel<T, VEC, true>), dim3(grid), dim3(kStepBlock), 0, s, tab, ks, h, nvec, mu,
+                       omd, clipf, s_avg, h_avg, byz, scale, kind, tuning().result_nt, partial);
   else
     hipLaunchKernelGGL((momentum_stats_kernel<T, VEC>), dim3(grid), dim3(kStepBlock), 0, s, tab, ks, h, nvec, mu, omd,
-                       clipf, s_avg, h_avg, byz, scale, kind, partial);
+                       clipf, s_avg, h_avg, byz, scale, kind, tuning().result_nt, partial);
   BM_LAUNCH_CHECK();
   return 0;
 }
@@ -333,7 +373,7 @@ static int launch_momentum_stats_stream(const StepTable& tab, int ks, int h, int
                                         const float* clipf, float* s_avg, float* h_avg, float* byz, float scale,
                                         int kind, double* partial, int grid, hipStream_t s) {
   hipLaunchKernelGGL((momentum_stats_stream_kernel<T, VEC>), dim3(grid), dim3(kStepBlock), 0, s, tab, ks, h, nvec,
-                     mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial);
+                     mu, omd, clipf, s_avg, h_avg, byz, scale, kind, tuning().result_nt, partial);
   BM_LAUNCH_CHECK();
   return 0;
 }
@@ -465,7 +505,9 @@ extern "C" int bm_momentum_stats(const float* const* sampled, int ks, float* con
   int rc = 0;
   if (vec >= 2 && d / vec > 0) {
     const int64_t nvec = d / vec;
-    const int grid = stream_grid(nvec, kStepBlock, kStepMaxBlocks - 1);
+    int cap = tuning().step_blocks > 0 ? tuning().step_blocks : kStepMaxBlocks - 1;
+    if (cap > kStepMaxBlocks - 1) cap = kStepMaxBlocks - 1;
+    const int grid = stream_grid(nvec, kStepBlock, cap);
     rc = (vec == 4) ? dispatch_momentum_stats<4>(tab, ks, h, nvec, mu, one_minus_damp, clip_factors, sampled_avg,
                                                   honest_avg, byz_out, scale, attack_kind, partial, grid, s)
                     : dispatch_momentum_stats<2>(tab, ks, h, nvec, mu, one_minus_damp, clip_factors, sampled_avg,

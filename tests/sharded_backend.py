@@ -96,12 +96,22 @@ class OracleBackend:
 
   @staticmethod
   def _byz(samples, avg, scale, attack):
-    att = avg.neg() if attack == "empire" else torch.stack(samples).var(dim=0).sqrt_()
+    if attack == "empire":
+      att = avg.neg()
+    else:
+      att = torch.stack(samples).var(dim=0).sqrt_() if avg.numel() else avg.clone()
     att.mul_(scale)
     return avg.add(att)
 
+  @staticmethod
+  def _seq_mean(samples):
+    avg = samples[0].clone()
+    for t in samples[1:]:
+      avg.add_(t)
+    return avg.div_(len(samples))
+
   def stack_stats(self, samples, scale=None, attack="empire"):
-    avg, _, _, _ = O.compute_avg_dev_max(samples)
+    avg = self._seq_mean(samples)
     out3 = self._out3(samples, avg)
     if scale is not None:
       return avg, out3, self._byz(samples, avg, scale, attack)
@@ -112,8 +122,8 @@ class OracleBackend:
     clipped = [g * factors[i] if factors is not None else g for i, g in enumerate(sampled)]
     for buf, g in zip(buffers, clipped[:h]):
       buf.mul_(mu).add_(g, alpha=omd)
-    s_avg, _, _, _ = O.compute_avg_dev_max(clipped)
-    h_avg, _, _, _ = O.compute_avg_dev_max(list(buffers))
+    s_avg = self._seq_mean(clipped)
+    h_avg = self._seq_mean(list(buffers))
     out6 = torch.cat([self._out3(clipped, s_avg), self._out3(list(buffers), h_avg)])
     byz = self._byz(list(buffers), h_avg, scale, attack) if scale is not None else None
     return s_avg, h_avg, byz, out6

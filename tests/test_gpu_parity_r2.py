@@ -518,3 +518,43 @@ def test_full_size_c5_step_against_fp64(bm):
     want_def = acc / m
     assert float((defense - want_def).abs().max()) <= 4e-6 * float(want_def.abs().max())
     past = s_avg
+
+
+# ---------------------------------------------------------------------------- #
+# The NaN attack (attacks/nan.py: f all-NaN gradients) through every rule, against the real reference's outputs
+
+def test_nan_attack_through_every_rule(bm):
+  g = Golden("nan_n11_f2")
+  dev = to_dev(g.gradients)
+  scale = float(torch.stack(g.honests).abs().max())
+  assert same_bits(bm.median(dev), g.tensor("median"))                 # NaN everywhere: torch's median propagates
+  assert bool(torch.isnan(g.tensor("median")).all())
+  assert same_bits(bm.meamed(dev, g.f), g.tensor("meamed"))             # NaN centre -> NaN, as the reference returns here
+  assert float((bm.trmean(dev, g.f).cpu() - g.tensor("trmean")).abs().max()) <= 1e-6 * scale
+  assert float((bm.phocas(dev, g.f).cpu() - g.tensor("phocas")).abs().max()) <= 2e-6 * scale   # no column exempt
+  assert same_bits(bm.krum(dev, g.f), g.tensor("krum"))
+  assert float((bm.bulyan(dev, g.f).cpu() - g.tensor("bulyan")).abs().max()) <= 2e-6 * scale
+  assert same_bits(bm.average(dev), g.tensor("average"))
+  avg, norm, devi, mx = bm.compute_avg_dev_max(dev[g.h:])                # statistics of the all-NaN attack stack
+  assert math.isnan(norm) and math.isnan(mx)
+
+
+def test_zero_length_inputs_through_every_entry_point(bm):
+  """d = 0 (an empty trailing shard of a sharded job): every entry point must succeed and write
+  neutral values, so that every rank reaches its collectives."""
+  from byzantinemomentum_amd.sharded import ShardedAggregator
+  n, f = 7, 1
+  rows = [torch.zeros(0, device=DEV) for _ in range(n)]
+  assert bool((bm.gars.pairwise_sqdist(rows) == 0).all())
+  avg, out3 = bm.stats.stack_stats_async(rows)
+  assert avg.shape == (0,) and out3.tolist() == [0.0, 0.0, 0.0]
+  gram, ex = bm.stats.study_dots(rows[:3], rows[3:5])
+  assert bool((gram == 0).all()) and bool((ex == 0).all())
+  s_avg, h_avg, byz, out6 = bm.stats.momentum_stats(rows, [torch.zeros(0, device=DEV) for _ in range(n)], 0.9, 0.1,
+                                                    None, 1.1, "empire")
+  assert out6.tolist() == [0.0] * 6 and byz.shape == (0,)
+  for rule in (bm.krum, bm.bulyan, bm.trmean, bm.aksel, bm.cge):
+    assert rule(rows, f).shape == (0,)
+  agg = ShardedAggregator()
+  assert agg.krum(rows, f).shape == (0,) and agg.bulyan(rows, f).shape == (0,)
+  assert bm.gars.krum_selection(rows, f) == list(range(n - f - 2))      # all-zero distances: ties by index

@@ -126,7 +126,7 @@ def _worker(rank, world, port, d, queue):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("d", [D, 100])  # d = 100 < 2*64: the second rank's shard is short (36 coordinates)
+@pytest.mark.parametrize("d", [D, 100, 40])  # 100: the second rank's shard is short (36 coordinates); 40: it is EMPTY
 def test_two_rank_sharded_step_matches_single_rank(d):
   world = 2
   ctx = mp.get_context("spawn")
@@ -159,7 +159,8 @@ def test_two_rank_sharded_step_matches_single_rank(d):
       assert all(a[k] == b[k] or (math.isnan(a[k]) and math.isnan(b[k])) for k in a)
 
 
-def test_empty_shard_reaches_the_collectives():
-  """d < 64: the second rank's slice is EMPTY; the step must still run (no rank may skip a collective)."""
+def test_empty_shard_layout():
+  """d < 64: the second rank's slice is EMPTY (the d = 40 case above runs the whole step on it: no rank
+  may skip a collective)."""
   from byzantinemomentum_amd.sharded import shard_bounds
   assert shard_bounds(40, 2, 1) == (40, 40)
