@@ -242,7 +242,7 @@ struct Tuning {
   int pair_mode;       // BM_PAIR_MODE: 0 = centred bf16x3 Gram (default), 1 = direct differences, 2 = fp32 Gram
   int pair_centre;     // BM_PAIR_CENTRE (mode 0): 2 (default) median of three rows, 1 row mean, 0 none (experiments)
   int pair_planes;     // BM_PAIR_PLANES (mode 0): 0 (default) by length, 2 or 3 forced
-  int step_stream;     // BM_STEP_STREAM: 1 = streaming (pivot) form of bm_momentum_stats, 0 = register-resident two-pass form
+  int step_stream;     // BM_STEP_STREAM: 0 (default) register-resident form of bm_momentum_stats up to 20 rows, streaming above; 1 = streaming form at every size
   int result_nt;       // BM_RESULT_NT: 1 (default) non-temporal stores for result vectors, 0 = default cache policy (experiments)
   int col_ablate;      // BM_COL_ABLATE: 1 = median/trmean at n=25 without the output store (experiment)
   int step_store;      // BM_STEP_STORE: 0 non-temporal buffer stores (default), 1 plain stores (experiments)

@@ -45,8 +45,6 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(RowTable rows,
   const float kNaN = __builtin_nanf("");
   const uint32_t nv = (uint32_t)nvec;  // nvec * VEC * 4 < 2^32: the host splits longer gradients
   const uint32_t stride = gridDim.x * kBulBlock;
-  // per column group: load the m_max ranked values, store the PREVIOUS group's result behind those loads
-  // (in-order vmcnt, see colwise_kernels.h), then the arithmetic
   auto load_group = [&](uint32_t off, float (&x)[VEC][MMAX]) {
 #pragma unroll
     for (int t = 0; t < MMAX; ++t) {
@@ -88,20 +86,12 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(RowTable rows,
       r[c] = has_nan ? kNaN : res;
     }
   };
-  uint32_t v = blockIdx.x * kBulBlock + threadIdx.x;
-  if (v < nv) {
-    float x[VEC][MMAX], pend[VEC];
-    uint32_t pend_off = v * (uint32_t)(VEC * sizeof(float));
-    load_group(pend_off, x);
-    rule(x, pend);
-    for (v += stride; v < nv; v += stride) {
-      const uint32_t off = v * (uint32_t)(VEC * sizeof(float));
-      load_group(off, x);
-      store_result_policy<VEC>(reinterpret_cast<float*>(reinterpret_cast<char*>(out) + pend_off), pend, nt_result);
-      rule(x, pend);
-      pend_off = off;
-    }
-    store_result_policy<VEC>(reinterpret_cast<float*>(reinterpret_cast<char*>(out) + pend_off), pend, nt_result);
+  for (uint32_t v = blockIdx.x * kBulBlock + threadIdx.x; v < nv; v += stride) {
+    const uint32_t off = v * (uint32_t)(VEC * sizeof(float));
+    float x[VEC][MMAX], r[VEC];
+    load_group(off, x);
+    rule(x, r);
+    store_result_policy<VEC>(reinterpret_cast<float*>(reinterpret_cast<char*>(out) + off), r, nt_result);
   }
 }
 

@@ -73,10 +73,14 @@ __device__ __forceinline__ float column_rule(float (&x)[N], int f, float inv_kee
   }
 }
 
-// N*VEC <= 100 values: ask for four waves per SIMD (<= 128 VGPRs), which is what the register-resident
-// design relies on to cover the HBM latency
+// ABLATE_STORE (BM_COL_ABLATE=1, n = 25 only) keeps the arithmetic and drops the result store: the
+// read-only rate of the same kernel.  Measured at n = 25, d = 11.2 M: 172 us without the store, 195 us
+// with it — the 4 % of result bytes cost 11 % of the time.  It is not the store's place in the in-order
+// vmcnt queue (scripts/probes/store_order_probe.hip: a store issued behind the next loads changes
+// nothing, 189.8 vs 189.4 us on a bare 25-row stream) and not its cache policy (BM_RESULT_NT A/B): a
+// write stream interleaved with 25 read streams simply costs about twice its bytes on this HBM system.
 template <int N, int OP, int VEC, bool ABLATE_STORE = false>
-__global__ __launch_bounds__(kColBlock, (N * VEC <= 100 ? 4 : 1)) void colwise_kernel(RowTable rows, int64_t nvec, int tail,
+__global__ __launch_bounds__(kColBlock) void colwise_kernel(RowTable rows, int64_t nvec, int tail,
                                                             int f, float inv_keep, int nt_result,
                                                             float* __restrict__ out) {
   constexpr bool kNeedsLds = (OP == BM_OP_PHOCAS || OP == BM_OP_MEAMED);
@@ -86,29 +90,9 @@ __global__ __launch_bounds__(kColBlock, (N * VEC <= 100 ? 4 : 1)) void colwise_k
   // nvec * VEC * 4 < 2^32 (the host splits longer gradients): 32-bit byte offsets, saddr loads
   const uint32_t nv = (uint32_t)nvec;
   const uint32_t stride = gridDim.x * kColBlock;
-  // The result of iteration i is stored AFTER the loads of iteration i+1 have been issued: on gfx950 loads
-  // and stores share the in-order vmcnt counter, so a store issued before the next loads makes the wait for
-  // those loads also wait for the store's acknowledgement from memory.  Measured at n = 25, d = 11.2 M:
-  // 194.6 us with the store right after the rule, 172.3 us with no store at all (6.5 TB/s read rate).
-  bool pending = false;
-  uint32_t pending_off = 0;
-  float pending_r[VEC];
-  auto flush = [&]() {
-    if constexpr (ABLATE_STORE) {
-      // experiment (BM_COL_ABLATE=1): keep the arithmetic alive, write (practically) nothing
-      if (pending_r[0] == 1.2345678e-30f) store_stream_off<VEC>(out, pending_off, pending_r);
-    } else if (nt_result) {  // wave-uniform; BM_RESULT_NT=1 (round-1 policy, kept for A/B runs)
-      store_stream_off<VEC>(out, pending_off, pending_r);
-    } else {
-      store_result_off<VEC>(out, pending_off, pending_r);
-    }
-  };
-  // first iteration peeled: inside the loop the store ALWAYS follows the loads, so the compiler's counted
-  // waits for the loaded values are vmcnt(>= 1) and never include the store
-  uint32_t v = blockIdx.x * kColBlock + threadIdx.x;
-  if (v < nv) {
-    float x[VEC][N];
+  for (uint32_t v = blockIdx.x * kColBlock + threadIdx.x; v < nv; v += stride) {
     const uint32_t off = v * (uint32_t)(VEC * sizeof(float));
+    float x[VEC][N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       float t[VEC];
@@ -116,26 +100,17 @@ __global__ __launch_bounds__(kColBlock, (N * VEC <= 100 ? 4 : 1)) void colwise_k
 #pragma unroll
       for (int c = 0; c < VEC; ++c) x[c][i] = t[c];
     }
+    float r[VEC];
 #pragma unroll
-    for (int c = 0; c < VEC; ++c) pending_r[c] = column_rule<N, OP>(x[c], f, inv_keep, lds);
-    pending_off = off;
-    pending = true;
-    for (v += stride; v < nv; v += stride) {
-      const uint32_t off2 = v * (uint32_t)(VEC * sizeof(float));
-#pragma unroll
-      for (int i = 0; i < N; ++i) {
-        float t[VEC];
-        load_stream_off<VEC>(rows.p[i], off2, t);
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) x[c][i] = t[c];
-      }
-      flush();  // the previous result, behind this iteration's loads in the memory queue
-#pragma unroll
-      for (int c = 0; c < VEC; ++c) pending_r[c] = column_rule<N, OP>(x[c], f, inv_keep, lds);
-      pending_off = off2;
+    for (int c = 0; c < VEC; ++c) r[c] = column_rule<N, OP>(x[c], f, inv_keep, lds);
+    if constexpr (ABLATE_STORE) {
+      if (r[0] == 1.2345678e-30f) store_stream_off<VEC>(out, off, r);
+    } else if (nt_result) {  // wave-uniform; BM_RESULT_NT=0 selects the default cache policy (A/B runs)
+      store_stream_off<VEC>(out, off, r);
+    } else {
+      store_result_off<VEC>(out, off, r);
     }
   }
-  if (pending) flush();
   // the d % VEC trailing columns: one lane each, in the last workgroup (no second launch)
   if (VEC > 1 && blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < tail) {
     const int64_t j = nvec * VEC + threadIdx.x;

@@ -368,12 +368,13 @@ int gram3_partials(const float* const* rows, int n, int64_t d, double* partial, 
   const int64_t need = (chunks + kB3Waves - 1) / kB3Waves;
   if (blocks > need) blocks = (int)(need > 0 ? need : 1);
   const int centre = tuning().pair_centre;
-  // Planes: the exact three-way split below 2^17 coordinates; above, two planes (x ~ h + m, 16
+  // Planes: the exact three-way split below 2^20 coordinates; above, two planes (x ~ h + m, 16
   // significant bits, unbiased remainder <= 2^-17 |x|): the rounding noise of a Gram entry averages
-  // as 4.4e-6 * sqrt(3/d) <= 2.1e-8 relative, the same order as the fp32 accumulation error, for a third
-  // fewer MFMAs and conversion ops.  BM_PAIR_PLANES forces 2 or 3.
+  // as 4.4e-6 * sqrt(3/d) <= 7.6e-9 relative, the order of the fp32 accumulation error itself (so that a
+  // pair just above the accuracy gate, tau = 2e-3, still has ~4e-6 relative accuracy), for a third fewer
+  // MFMAs and conversion ops.  BM_PAIR_PLANES forces 2 or 3.
   int planes = tuning().pair_planes;
-  if (planes != 2 && planes != 3) planes = (d >= ((int64_t)1 << 17)) ? 2 : 3;
+  if (planes != 2 && planes != 3) planes = (d >= ((int64_t)1 << 20)) ? 2 : 3;
   int rc;
   switch (K) {
 #define BM_B3_CASE(KK) \

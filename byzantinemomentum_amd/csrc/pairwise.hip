@@ -414,7 +414,8 @@ __global__ __launch_bounds__(kRankThreads) void krum_rank_kernel(const double* _
     if (i == j) continue;
     const double v = dist[i][j];
     int rank = 0;
-    for (int l = 0; l < n; ++l) {
+#pragma unroll 8
+    for (int l = 0; l < n; ++l) {  // independent LDS reads: unrolled so that they pipeline
       const double o = dist[i][l];
       rank += (l != i && (o < v || (o == v && l < j))) ? 1 : 0;
     }
@@ -427,7 +428,8 @@ __global__ __launch_bounds__(kRankThreads) void krum_rank_kernel(const double* _
     if (take > n - 1) take = n - 1;
     if (take < 0) take = 0;
     double s = 0.0;
-    for (int t = 0; t < take; ++t) s += dist[tid][pos[tid][t]];
+#pragma unroll 8
+    for (int t = 0; t < take; ++t) s += dist[tid][pos[tid][t]];  // additions stay in ascending order
     score[tid] = s;
     if (scores_out != nullptr) scores_out[tid] = s;
   }
@@ -436,6 +438,7 @@ __global__ __launch_bounds__(kRankThreads) void krum_rank_kernel(const double* _
     // stable argsort: rank = #rows with a smaller score, ties to the lower index
     const double si = score[tid];
     int rank = 0;
+#pragma unroll 8
     for (int j = 0; j < n; ++j) {
       const double sj = score[j];
       rank += (sj < si || (sj == si && j < tid)) ? 1 : 0;

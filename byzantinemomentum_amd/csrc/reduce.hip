@@ -27,39 +27,21 @@ __global__ __launch_bounds__(kRedBlock) void selected_mean_kernel(RowTable rows,
   if (threadIdx.x < m) sel[threadIdx.x] = rows.p[idx[threadIdx.x]];
   __syncthreads();
   const int64_t stride = (int64_t)gridDim.x * kRedBlock;
-  // The mean of column group v is stored after the first loads of group v+stride have been issued: loads
-  // and stores share the in-order vmcnt counter on gfx950, a store issued first would make the wait for the
-  // next loads also wait for the store's acknowledgement (see colwise_kernels.h).
-  constexpr int kFirst = 8;  // loads issued before the pending store
-  float pend[VEC];
-  int64_t pend_v = -1;
   for (int64_t v = (int64_t)blockIdx.x * kRedBlock + threadIdx.x; v < nvec; v += stride) {
-    float first[kFirst][VEC];
-#pragma unroll
-    for (int k = 0; k < kFirst; ++k)
-      if (k < m) load_stream<VEC>(sel[k] + v * VEC, first[k]);
-    if (pend_v >= 0) store_result_policy<VEC>(out + pend_v * VEC, pend, nt_result);
     float acc[VEC];
 #pragma unroll
     for (int c = 0; c < VEC; ++c) acc[c] = 0.0f;
-#pragma unroll
-    for (int k = 0; k < kFirst; ++k)
-      if (k < m) {
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) acc[c] += first[k][c];
-      }
 #pragma unroll 8
-    for (int k = kFirst; k < m; ++k) {
+    for (int k = 0; k < m; ++k) {
       float t[VEC];
       load_stream<VEC>(sel[k] + v * VEC, t);
 #pragma unroll
       for (int c = 0; c < VEC; ++c) acc[c] += t[c];
     }
 #pragma unroll
-    for (int c = 0; c < VEC; ++c) pend[c] = acc[c] / fm;
-    pend_v = v;
+    for (int c = 0; c < VEC; ++c) acc[c] = acc[c] / fm;
+    store_result_policy<VEC>(out + v * VEC, acc, nt_result);
   }
-  if (pend_v >= 0) store_result_policy<VEC>(out + pend_v * VEC, pend, nt_result);
 }
 
 template <int VEC>

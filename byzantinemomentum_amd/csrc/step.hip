@@ -162,9 +162,12 @@ __global__ __launch_bounds__(kStepBlock) void momentum_stats_kernel(
   }
 }
 
-// Streaming form of the same pass: the rows of a coordinate group are consumed one after the other and
-// only running sums are kept, so the register footprint does not grow with the number of rows
-// (VEC = 4 at four waves per SIMD instead of two).  Deviations use the first row p = x_0 as a pivot:
+// Streaming form of the same pass, used above 20 rows (where the register-resident form would have to drop
+// to 8- or 4-byte loads, or spill): the rows of a coordinate group are consumed in batches of four and only
+// running sums are kept, so the register footprint does not grow with the number of rows (108 VGPRs at
+// any row count, VEC = 4).  At ks = h = 20 both forms take the same time (1.55-1.6 ms at d = 36.5 M,
+// profiles/r02_b_*): the kernel is bound by its 40:23 read:write mix, not by occupancy.
+// Deviations use the first row p = x_0 as a pivot:
 //   sum_i (x_i - a)^2 = sum_i d_i^2 - 2 (a - p) sum_i d_i + k (a - p)^2,   d_i = x_i - p,
 // with a the (rounded, sequential) mean.  The pivot's own deviation (a - p)^2 is part of the result, hence
 // sum d_i^2 <= (k + 1) * result: the subtraction cancels at most a factor k + 1, never catastrophically.
@@ -182,23 +185,10 @@ __global__ __launch_bounds__(kStepBlock, 4) void momentum_stats_stream_kernel(
 #pragma unroll
   for (int i = 0; i < T; ++i) cf[i] = (clipf != nullptr && i < ks) ? clipf[i] : 1.0f;
   const int64_t stride = (int64_t)gridDim.x * kStepBlock;
-  // Stores are issued BEHIND the next loads: loads and stores share the in-order vmcnt counter on gfx950,
-  // so a store placed before a batch of loads makes the wait for those loads also wait for the store's
-  // acknowledgement from memory (measured on the column kernels: a result stream of 4 % of the bytes cost
-  // 11 % of the time).  The updated buffers of batch k are stored after the loads of batch k+1, the three
-  // result vectors of a column group after the first loads of the next group.
   constexpr int kBatch = 4;
-  float r_sa[VEC], r_ha[VEC], r_bz[VEC];
-  int64_t r_v = -1;  // column group whose result vectors are still in registers
-  auto flush_results = [&]() {
-    if (s_avg_out != nullptr) store_result_policy<VEC>(s_avg_out + r_v * VEC, r_sa, nt_result);
-    if (h_avg_out != nullptr) store_result_policy<VEC>(h_avg_out + r_v * VEC, r_ha, nt_result);
-    if (byz_out != nullptr) store_result_policy<VEC>(byz_out + r_v * VEC, r_bz, nt_result);
-  };
   for (int64_t v = (int64_t)blockIdx.x * kStepBlock + threadIdx.x; v < nvec; v += stride) {
     float ps[VEC], ss[VEC], qs[VEC], ts[VEC];  // sampled: pivot, sequential sum, sum d^2, sum d
     float ph[VEC], sh[VEC], qh[VEC], th[VEC];  // honest
-    float bq[kBatch][VEC];                      // updated buffers of the previous batch, not stored yet
 #pragma unroll
     for (int base = 0; base < T; base += kBatch) {
       if (base < ks) {  // wave-uniform
@@ -208,14 +198,6 @@ __global__ __launch_bounds__(kStepBlock, 4) void momentum_stats_stream_kernel(
           const int i = base + j;
           load_stream<VEC>(tab.g[i] + v * VEC, g[j]);  // entries >= ks repeat the last row (host-side padding)
           if (base < h) load_stream<VEC>(tab.b[i] + v * VEC, b[j]);
-        }
-        // ---- behind these loads: what the previous batch / the previous column group left pending ----
-        if (base == 0) {
-          if (r_v >= 0) flush_results();
-        } else if (base - kBatch < h) {
-#pragma unroll
-          for (int j = 0; j < kBatch; ++j)
-            if (base - kBatch + j < h) store_stream<VEC>(tab.b[base - kBatch + j] + v * VEC, bq[j]);
         }
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
@@ -241,9 +223,11 @@ __global__ __launch_bounds__(kStepBlock, 4) void momentum_stats_stream_kernel(
           }
           if (base < h) {  // wave-uniform, the loads of b sit in the same region
 #pragma unroll
+            for (int c = 0; c < VEC; ++c) b[j][c] = __builtin_fmaf(omd, g[j][c], mu * b[j][c]);
+            if (on_h) store_stream<VEC>(tab.b[i] + v * VEC, b[j]);
+#pragma unroll
             for (int c = 0; c < VEC; ++c) {
-              const float bv = __builtin_fmaf(omd, g[j][c], mu * b[j][c]);
-              bq[j][c] = bv;
+              const float bv = b[j][c];
               if (i == 0) {
                 ph[c] = bv;
                 sh[c] = bv;
@@ -260,15 +244,7 @@ __global__ __launch_bounds__(kStepBlock, 4) void momentum_stats_stream_kernel(
         }
       }
     }
-    // the buffers of the last batch that held honest rows (a run-time batch index: wave-uniform table lookups)
-    {
-      const int lastb = ((h - 1) / kBatch) * kBatch;
-      if (lastb + kBatch >= ks) {  // otherwise a later (gradient-only) batch has already flushed it
-#pragma unroll
-        for (int j = 0; j < kBatch; ++j)
-          if (lastb + j < h) store_stream<VEC>(tab.b[lastb + j] + v * VEC, bq[j]);
-      }
-    }
+    float r_sa[VEC], r_ha[VEC], r_bz[VEC];
 #pragma unroll
     for (int c = 0; c < VEC; ++c) {
       const float s = ss[c] / fks;
@@ -290,9 +266,10 @@ __global__ __launch_bounds__(kStepBlock, 4) void momentum_stats_stream_kernel(
       const float dir = (attack_kind == BM_ATTACK_LITTLE) ? __builtin_sqrtf(colq / (fh - 1.0f)) : -t;
       r_bz[c] = t + dir * scale;
     }
-    r_v = v;
+    if (s_avg_out != nullptr) store_result_policy<VEC>(s_avg_out + v * VEC, r_sa, nt_result);
+    if (h_avg_out != nullptr) store_result_policy<VEC>(h_avg_out + v * VEC, r_ha, nt_result);
+    if (byz_out != nullptr) store_result_policy<VEC>(byz_out + v * VEC, r_bz, nt_result);
   }
-  if (r_v >= 0) flush_results();
   if (nan_s) mxs = __builtin_nanf("");
   if (nan_h) mxh = __builtin_nanf("");
   const double r0 = block_reduce_sum<kStepBlock>((double)n2s, red);
@@ -355,10 +332,7 @@ template <int T, int VEC>
 static int launch_momentum_stats(const StepTable& tab, int ks, int h, int64_t nvec, float mu, float omd,
                                  const float* clipf, float* s_avg, float* h_avg, float* byz, float scale, int kind,
                                  double* partial, int grid, hipStream_t s) {
-  if (tuning().step_stream)
-    hipLaunchKernelGGL((momentum_stats_stream_kernel<T, VEC>), dim3(grid), dim3(kStepBlock), 0, s, tab, ks, h, nvec,
-                       mu, omd, clipf, s_avg, h_avg, byz, scale, kind, tuning().result_nt, partial);
-  else if (tuning().step_store == 1)
+  if (tuning().step_store == 1)
     hipLaunchKernelGGL((momentum_stats_kernel<T, VEC, true>), dim3(grid), dim3(kStepBlock), 0, s, tab, ks, h, nvec, mu,
                        omd, clipf, s_avg, h_avg, byz, scale, kind, tuning().result_nt, partial);
   else
@@ -378,26 +352,27 @@ static int launch_momentum_stats_stream(const StepTable& tab, int ks, int h, int
   return 0;
 }
 
-// Tiers by max(ks, h): registers hold 2 * T * VEC values per lane.
+// Tiers by max(ks, h): the register-resident form holds 2 * T * VEC values per lane (T <= 20), the
+// streaming form takes over above.
 template <int VEC>
 static int dispatch_momentum_stats(const StepTable& tab, int ks, int h, int64_t nvec, float mu, float omd,
                                    const float* clipf, float* s_avg, float* h_avg, float* byz, float scale, int kind,
                                    double* partial, int grid, hipStream_t s) {
   const int t = ks > h ? ks : h;
 #define BM_STEP_ARGS tab, ks, h, nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial, grid, s
-  if (t <= 8) return launch_momentum_stats<8, VEC>(BM_STEP_ARGS);
-  if (t <= 12) return launch_momentum_stats<12, VEC>(BM_STEP_ARGS);
-  if (t <= 20) return launch_momentum_stats<20, VEC>(BM_STEP_ARGS);
-  if (tuning().step_stream) {
-    if (t <= 40) return launch_momentum_stats_stream<40, VEC>(BM_STEP_ARGS);
-    return launch_momentum_stats_stream<64, VEC>(BM_STEP_ARGS);
+  // BM_STEP_STREAM: 0 (default) register-resident form up to 20 rows, 1 = streaming form at every size,
+
+  const int form = tuning().step_stream;
+  if (form != 1) {
+    if (t <= 8) return launch_momentum_stats<8, VEC>(BM_STEP_ARGS);
+    if (t <= 12) return launch_momentum_stats<12, VEC>(BM_STEP_ARGS);
+    if (t <= 20) return launch_momentum_stats<20, VEC>(BM_STEP_ARGS);
+  } else {
+    if (t <= 20) return launch_momentum_stats_stream<20, VEC>(BM_STEP_ARGS);
   }
-  if constexpr (VEC <= 2) {
-    if (t <= 40) return launch_momentum_stats<40, VEC>(BM_STEP_ARGS);
-  }
-  if constexpr (VEC == 1) return launch_momentum_stats<64, 1>(BM_STEP_ARGS);
+  if (t <= 40) return launch_momentum_stats_stream<40, VEC>(BM_STEP_ARGS);
+  return launch_momentum_stats_stream<64, VEC>(BM_STEP_ARGS);
 #undef BM_STEP_ARGS
-  return BM_EINVAL;  // caller picks a narrower vector
 }
 
 // ---------------------------------------------------------------------------
@@ -496,10 +471,7 @@ extern "C" int bm_momentum_stats(const float* const* sampled, int ks, float* con
   int vec = vec_of(bits);
   const int t = ks > h ? ks : h;
   if (tuning().step_vec > 0 && vec > tuning().step_vec) vec = tuning().step_vec;
-  if (!tuning().step_stream) {
-    if (t > 20 && vec > 2) vec = 2;  // register-resident form: 2*T*VEC values per lane
-    if (t > 40) vec = 1;
-  }
+  (void)t;  // above 20 rows the streaming form keeps VEC at any row count
   int nparts = 0;
   int64_t body = 0;
   int rc = 0;

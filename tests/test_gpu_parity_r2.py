@@ -446,9 +446,10 @@ def test_momentum_stats_kernel_tiers(bm):
 
 
 def test_momentum_stats_other_form():
-  """bm_momentum_stats has two forms (BM_STEP_STREAM: streaming with a pivot / register-resident two-pass);
-  the library reads the knob once per process, so the non-default one runs in a subprocess."""
-  other = "0" if os.environ.get("BM_STEP_STREAM", "1") == "1" else "1"
+  """bm_momentum_stats has two forms (register-resident two-pass up to 20 rows, streaming with a pivot
+  above; BM_STEP_STREAM=1 forces the streaming form at every size); the library reads the knob once per
+  process, so the forced form runs in a subprocess."""
+  other = "1" if os.environ.get("BM_STEP_STREAM", "0") != "1" else "0"
   env = dict(os.environ, BM_STEP_STREAM=other, PYTHONPATH=ROOT)
   out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity_r2.py"), "-q", "-x",
                         "-m", "gpu", "-k", "test_momentum_stats_kernel_tiers or test_step_all_placements"],
