@@ -326,7 +326,7 @@ def main():
                         if distributed else ""))
     dominant_kernel = "gram3_partial_kernel"
 
-  for i in range(args.warmup):
+  for i in range(max(args.warmup, 27) if workload == "step" else args.warmup):  # step: fill the deque of 25 pasts
     step(i, False)
   barrier()
   t0 = time.perf_counter()
@@ -413,12 +413,15 @@ def main():
 
 
 def step_algorithmic_bytes(d, n, f, gar):
-  """4-byte units of d per step, fused first pass: sampled + buffers read,
-  buffers written, three d-vectors written (ks + 2h + 3); rule; attack stats 2, defense stats 1, dots 4 + 25."""
+  """4-byte units of d per step as THIS implementation moves them (lists the
+  reference's 103 + rule + 3 + 29): fused first pass = sampled + buffers read, buffers written, three
+  d-vectors written (ks + 2h + 3 = 63); rule; attack stats 2, defense stats 1; dots of 4 core vectors + the
+  newest past + the curvature combination C (6); update of C in place (two passes of 3: the oldest past
+  out, the new average in) — 12 instead of the 4 + 25 separate past dots."""
   h = n - f
   m = n - f - 2
   gar_units = {"krum": n + m + 1, "bulyan": n + m + 1, "median": n + 1, "trmean": n + 1}.get(gar, n + 1)
-  return 4 * d * ((h + 2 * h + 3) + gar_units + 2 + 1 + 29)
+  return 4 * d * ((h + 2 * h + 3) + gar_units + 2 + 1 + 12)
 
 
 def extras_single_gpu(bm, device, timer, aliased):
@@ -449,7 +452,7 @@ def extras_single_gpu(bm, device, timer, aliased):
     def one(i):
       runner.run(sets[i & 1])
       runner.floats()
-    ms = timed_loop(one, 8, 3, timer, "step_" + gar)
+    ms = timed_loop(one, 8, 27, timer, "step_" + gar)  # 27 warm-up steps: the deque of 25 past averages is full
     out[f"step_c5_{gar}"] = entry(ms, step_algorithmic_bytes(d, n, f, gar),
                                   config=f"full step mirror, rule {gar}, n={n}, f={f}, d={d}, one GPU")
     del runner

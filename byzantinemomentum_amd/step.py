@@ -31,7 +31,7 @@ __all__ = ["AggregationStep"]
 
 _RULES = ("krum", "bulyan", "median", "trmean", "phocas", "meamed", "aksel", "brute", "average", "cge")
 _NEEDS_F = {"krum", "bulyan", "trmean", "phocas", "meamed", "aksel", "brute", "cge"}
-MAX_PAST = 32  # bm_multi_dot takes at most 32 extra vectors
+MAX_PAST = 4096  # past sampled averages kept for the curvature term (each is one d-vector of device memory)
 
 
 class AggregationStep:
@@ -47,7 +47,7 @@ class AggregationStep:
     if attack not in ("empire", "little"):
       raise ValueError(f"unknown attack {attack!r} (empire: factor, little: factor, use a negative one for negative:True)")
     if not 0 <= nb_past <= MAX_PAST:
-      raise ValueError(f"nb_past must be within 0..{MAX_PAST} (the fused dot kernel takes at most {MAX_PAST} past gradients)")
+      raise ValueError(f"nb_past must be within 0..{MAX_PAST}")
     if aggregator is None:
       from .sharded import ShardedAggregator
       aggregator = ShardedAggregator()
@@ -70,6 +70,10 @@ class AggregationStep:
     self.pasts = collections.deque(maxlen=max(nb_past, 1))  # past sampled averages, newest first (attack.py:868)
     self.nb_past = nb_past
     self._prev_s2 = None       # device fp64[1]: (this rank's part of) the squared norm of pasts[0]
+    # C = sum_i mu^i * pasts[i]: the curvature term mu * sum_i mu^i <s, pasts[i]> (attack.py:863-865) is
+    # mu * <s, C>, ONE dot product instead of nb_past of them; C is updated in place each step
+    # (C <- s + mu * (C - mu^(P-1) * oldest) once the deque is full), 6 row passes instead of nb_past
+    self._curv = None
     self._pending = None
     self._update = None
 
@@ -148,14 +152,20 @@ class AggregationStep:
     a_avg, a_out3 = ops.stack_stats(attacks) if self.f_real > 0 else (None, None)
     _, d_out3 = ops.stack_stats([defense])
     core = [s_avg, h_avg, defense] + ([a_avg] if a_avg is not None else [])
-    past_vecs = list(self.pasts) if self.nb_past > 0 else []
-    gram, extra = ops.study_dots(core, past_vecs)
+    have_past = self.nb_past > 0 and len(self.pasts) > 0
+    gram, extra = ops.study_dots(core, [self.pasts[0], self._curv] if have_past else [])
     l2 = ops.pairwise_sqdist([params, origin])[0, 1].reshape(1) if params is not None and origin is not None else None
-    self._pending = dict(s=s_out3, h=h_out3, a=a_out3, d=d_out3, gram=gram, extra=extra, npast=len(past_vecs),
-                         prev_s2=self._prev_s2 if past_vecs else None, l2=l2, ks=ks, floats=None)
+    self._pending = dict(s=s_out3, h=h_out3, a=a_out3, d=d_out3, gram=gram, extra=extra, npast=2 if have_past else 0,
+                         prev_s2=self._prev_s2 if have_past else None, l2=l2, ks=ks, floats=None)
     # grad_pasts.appendleft(PastGrad(sampled_grad_avg, sampled_norm_avg))  (attack.py:868): every step,
     # whether or not the scalars are fetched; the norm of the newest entry stays on the device
     if self.nb_past > 0:
+      if self._curv is None:
+        self._curv = s_avg.clone()
+      else:
+        if len(self.pasts) == self.nb_past:  # the oldest entry leaves the deque: take its term out of C first
+          ops.multi_fma3([self._curv], [self._curv], [self.pasts[-1]], 1.0, -(self.mu ** (self.nb_past - 1)))
+        ops.multi_fma3([self._curv], [self._curv], [s_avg], self.mu, 1.0)
       self.pasts.appendleft(s_avg)
       self._prev_s2 = s_out3[:1]
     return defense
@@ -226,7 +236,7 @@ class AggregationStep:
     }
     if pend["npast"] > 0:
       res["cosin_sampled"] = ex[0] / math.sqrt(s2) / prev_norm
-      res["curv_sampled"] = self.mu * sum(self.mu ** i * ex[i] for i in range(pend["npast"]))
+      res["curv_sampled"] = self.mu * ex[1]
     else:
       res["cosin_sampled"] = math.nan
       res["curv_sampled"] = math.nan
