@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kColBlock) void aksel_pass1_kernel(RowTable rows, i
         acc[i] += df * df;  // (x - m).pow_(2).sum()
       }
     }
-    if (median_out != nullptr) store_result<VEC>(median_out + v * VEC, med);
+    if (median_out != nullptr) store_stream<VEC>(median_out + v * VEC, med);
   }
 #pragma unroll
   for (int i = 0; i < N; ++i) {

@@ -63,7 +63,7 @@ template <int KMAX, int VEC>
 __global__ __launch_bounds__(kRedBlock) void stack_stats_kernel(RowTable rows, int k, int64_t nvec,
                                                                 float* __restrict__ avg_out,
                                                                 float* __restrict__ scaled_out,
-                                                                float scale, int attack_kind,
+                                                                float scale, int attack_kind, int nt_result,
                                                                 double* __restrict__ partial) {
   __shared__ double red[kRedBlock / 64];
   const float fk = (float)k;
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(kRedBlock) void stack_stats_kernel(RowTable rows, i
       dev2 += q;
       colq[c] = q;
     }
-    if (avg_out != nullptr) store_result<VEC>(avg_out + v * VEC, avg);
+    if (avg_out != nullptr) store_result_policy<VEC>(avg_out + v * VEC, avg, nt_result);
     if (scaled_out != nullptr) {
       float sc[VEC];
 #pragma unroll
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kRedBlock) void stack_stats_kernel(RowTable rows, i
         const float att = dir * scale;  // grad_att.mul_(factor)
         sc[c] = avg[c] + att;           // byz_grad = grad_avg.add_(grad_att)
       }
-      store_result<VEC>(scaled_out + v * VEC, sc);
+      store_result_policy<VEC>(scaled_out + v * VEC, sc, nt_result);
     }
   }
   // torch's abs().max() propagates NaN; fmaxf does not
@@ -170,7 +170,7 @@ template <int KMAX, int VEC>
 static int launch_stack_stats(const RowTable& tab, int k, int64_t nvec, float* avg, float* scaled,
                               float scale, int kind, double* partial, int grid, hipStream_t s) {
   hipLaunchKernelGGL((stack_stats_kernel<KMAX, VEC>), dim3(grid), dim3(kRedBlock), 0, s, tab, k, nvec,
-                     avg, scaled, scale, kind, partial);
+                     avg, scaled, scale, kind, tuning().result_nt, partial);
   BM_LAUNCH_CHECK();
   return 0;
 }

@@ -136,8 +136,8 @@ class HipBackend:
 
   # -- step statistics and momentum -------------------------------------------- #
 
-  def stack_stats(self, samples, scale=None, attack="empire"):
-    return self.stats.stack_stats_async(samples, scale=scale, attack=attack)
+  def stack_stats(self, samples, scale=None, attack="empire", want_avg=True):
+    return self.stats.stack_stats_async(samples, scale=scale, attack=attack, want_avg=want_avg)
 
   def momentum_stats(self, sampled, buffers, mu, omd, factors, scale, attack):
     return self.stats.momentum_stats(sampled, buffers, mu, omd, factors, scale, attack)

@@ -20,7 +20,7 @@ __all__ = ["compute_avg_dev_max", "stack_stats_async", "study_dots", "multi_axpb
 _ptr = gars._ptr
 
 
-def stack_stats_async(samples, scale=None, attack="empire"):
+def stack_stats_async(samples, scale=None, attack="empire", want_avg=True):
   """avg vector + device tensor [sum avg^2, sum_i ||s_i-avg||^2, max|avg|] (fp64), no sync.
 
   With `scale`, also returns the Byzantine vector of an "identical" attack computed in the same pass
@@ -29,12 +29,12 @@ def stack_stats_async(samples, scale=None, attack="empire"):
   """
   k, d, device = gars._validate(samples)
   lib = _lib.load()
-  avg = torch.empty(d, dtype=torch.float32, device=device)
+  avg = torch.empty(d, dtype=torch.float32, device=device) if want_avg else None  # None: statistics only
   scaled = torch.empty(d, dtype=torch.float32, device=device) if scale is not None else None
   out3 = torch.empty(3, dtype=torch.float64, device=device)
   ws = gars._workspace(device, _lib.WS_STATS, k, d, "ws_stats")
   with torch.cuda.device(device):
-    _lib.check(lib.bm_stack_stats(_lib.pointer_table(samples), k, d, _ptr(avg),
+    _lib.check(lib.bm_stack_stats(_lib.pointer_table(samples), k, d, _ptr(avg) if avg is not None else None,
                                   _ptr(scaled) if scaled is not None else None,
                                   ctypes.c_float(scale if scale is not None else 0.0),
                                   _lib.ATTACK_LITTLE if attack == "little" else _lib.ATTACK_EMPIRE, _ptr(out3),

@@ -150,7 +150,7 @@ class AggregationStep:
       self._update = defense
     # 5. remaining statistics
     a_avg, a_out3 = ops.stack_stats(attacks) if self.f_real > 0 else (None, None)
-    _, d_out3 = ops.stack_stats([defense])
+    _, d_out3 = ops.stack_stats([defense], want_avg=False)  # norm and max only: the average of one row is the row
     core = [s_avg, h_avg, defense] + ([a_avg] if a_avg is not None else [])
     have_past = self.nb_past > 0 and len(self.pasts) > 0
     gram, extra = ops.study_dots(core, [self.pasts[0], self._curv] if have_past else [])

@@ -110,7 +110,7 @@ class OracleBackend:
       avg.add_(t)
     return avg.div_(len(samples))
 
-  def stack_stats(self, samples, scale=None, attack="empire"):
+  def stack_stats(self, samples, scale=None, attack="empire", want_avg=True):
     avg = self._seq_mean(samples)
     out3 = self._out3(samples, avg)
     if scale is not None:

@@ -1,0 +1,69 @@
+"""bench.py's command line on a machine without a GPU: the self-spawn for --gpus N, the refusal to run
+without a GPU, and the byte model of the step."""
+
+import importlib.util
+import os
+import pathlib
+import sys
+
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+
+def load_bench():
+  spec = importlib.util.spec_from_file_location("bench_under_test", ROOT / "bench.py")
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  return mod
+
+
+def test_gpus_flag_reexecutes_under_torch_distributed_run(monkeypatch):
+  bench = load_bench()
+  calls = []
+
+  def fake_execv(exe, argv):
+    calls.append((exe, argv))
+    raise SystemExit(0)
+  monkeypatch.setattr(os, "execv", fake_execv)
+  monkeypatch.delenv("WORLD_SIZE", raising=False)
+  monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "7", "--warmup", "2"])
+  with pytest.raises(SystemExit):
+    bench.main()
+  (exe, argv), = calls
+  assert exe == sys.executable
+  assert argv[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+  assert "--nproc-per-node=4" in argv and "127.0.0.1" in argv
+  tail = argv[argv.index(str(ROOT / "bench.py")) + 1:]
+  assert tail == ["--gpus", "4", "--steps", "7", "--warmup", "2"]     # the ranks see the same flags
+
+
+def test_launcher_and_flag_must_agree(monkeypatch):
+  bench = load_bench()
+  monkeypatch.setenv("WORLD_SIZE", "2")
+  monkeypatch.setenv("RANK", "0")
+  monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4"])
+  with pytest.raises(SystemExit) as err:
+    bench.main()
+  assert "--gpus 4" in str(err.value)
+
+
+def test_no_gpu_is_refused_loudly(monkeypatch):
+  import torch
+  if torch.cuda.is_available():
+    pytest.skip("a GPU is visible")
+  bench = load_bench()
+  monkeypatch.delenv("WORLD_SIZE", raising=False)
+  monkeypatch.setattr(sys, "argv", ["bench.py"])
+  with pytest.raises(SystemExit) as err:
+    bench.main()
+  assert "no GPU" in str(err.value)
+
+
+def test_step_byte_model():
+  bench = load_bench()
+  d, n, f = 1000, 25, 5
+  h, m = 20, 18
+  assert bench.step_algorithmic_bytes(d, n, f, "krum") == 4 * d * ((3 * h + 3) + (n + m + 1) + 2 + 1 + 12)
+  assert bench.step_algorithmic_bytes(d, n, f, "median") == 4 * d * ((3 * h + 3) + (n + 1) + 2 + 1 + 12)
+  assert bench.entry(2.0, 4_000_000_000)["gbps"] == pytest.approx(2000.0)
