@@ -20,7 +20,10 @@ RULES = {"krum": O.krum, "bulyan": O.bulyan, "trmean": O.trmean, "phocas": O.pho
 
 class ReferenceLoop:
   def __init__(self, n, f_decl, f_real, gar, momentum_at="worker", mu=0.9, damp=0.9, attack="empire", factor=1.1,
-               clip=None, nb_past=3, gar_args=None):
+               clip=None, nb_past=3, gar_args=None, precision="f64"):
+    """precision: arithmetic of the norm-type floats ("f64" ground truth; "f32" = the reference's own fp32
+    operations, bit-faithful: what tests/test_step_reference_vs_reference.py pins against the real loop body)."""
+    self.precision = precision
     self.n, self.f_decl, self.f_real, self.gar = n, f_decl, f_real, gar
     self.h = n - f_real
     self.momentum_at, self.mu, self.damp = momentum_at, mu, damp
@@ -37,7 +40,7 @@ class ReferenceLoop:
     sampled = [g.clone() for g in sampled]
     if self.clip is not None:  # attack.py:791-794 (norm in float64: the reference's fp32 norm() is itself off)
       for g in sampled:
-        norm = math.sqrt(g.double().pow(2).sum().item())
+        norm = g.norm().item() if self.precision == "f32" else math.sqrt(g.double().pow(2).sum().item())
         if norm > self.clip:
           g.mul_(self.clip / norm)
     if self.workers is None:
@@ -64,7 +67,12 @@ class ReferenceLoop:
       defense = O.average(grads)
     else:
       defense = RULES[self.gar](grads, self.f_decl, **self.gar_args)
-    l2 = math.sqrt((params.double() - origin.double()).pow(2).sum().item()) if params is not None else math.nan
+    if params is None:
+      l2 = math.nan
+    elif self.precision == "f32":
+      l2 = params.sub(origin).norm().item()
+    else:
+      l2 = math.sqrt((params.double() - origin.double()).pow(2).sum().item())
     if self.momentum_at == "server":  # attack.py:832-839
       self.server = defense
       update = defense
@@ -74,7 +82,7 @@ class ReferenceLoop:
     else:
       update = defense
     pasts = list(self.pasts) if self.nb_past > 0 else []
-    res = O.study_block(sampled, honests, attacks, defense, pasts, self.mu, "f64")
+    res = O.study_block(sampled, honests, attacks, defense, pasts, self.mu, self.precision)
     res["l2_origin"] = l2
     if self.nb_past > 0:
       self.pasts.appendleft((res["sampled_grad_avg"], res["sampled_norm_avg"]))
