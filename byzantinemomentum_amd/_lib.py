@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported before the CDLL, see above)
 _PKG_DIR = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _PKG_DIR / "libbm_gar.so"
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 MAX_ROWS = 64
 EINVAL = -100000
 ENOCOMM, ECOMM = -100001, -100002
@@ -77,7 +77,23 @@ SIGNATURES = {
   "bm_sharded_bulyan": (ctypes.c_int, [ctypes.c_void_p, _c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p]),
+  "bm_step_stats_count": (ctypes.c_int, []),
+  "bm_step_workspace_bytes": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int64]),
+  "bm_step_worker": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_float_pp, _c_float_pp, ctypes.c_int64]
+                     + [ctypes.c_void_p] * 13),
 }
+
+
+RULE_IDS = {"krum": 0, "bulyan": 1, "median": 2, "trmean": 3, "phocas": 4, "meamed": 5}
+
+
+class StepParams(ctypes.Structure):
+  """bm_step_params of include/bm_gar.h."""
+  _fields_ = [("n", ctypes.c_int32), ("f_decl", ctypes.c_int32), ("f_real", ctypes.c_int32), ("ks", ctypes.c_int32),
+              ("rule", ctypes.c_int32), ("m", ctypes.c_int32), ("attack_kind", ctypes.c_int32),
+              ("nb_past", ctypes.c_int32), ("past_count", ctypes.c_int32), ("attack_scale", ctypes.c_float),
+              ("mu", ctypes.c_float), ("one_minus_damp", ctypes.c_float), ("clip", ctypes.c_float),
+              ("oldest_weight", ctypes.c_float)]
 
 
 class NativeLibraryError(RuntimeError):

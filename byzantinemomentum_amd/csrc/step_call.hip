@@ -1,0 +1,247 @@
+// step_call.hip — one simulation step (attack.py:786-868, worker-side momentum) as ONE C call.
+//
+// The kernels are the ones the Python host mirror launches one by one (byzantinemomentum_amd/step.py);
+// this entry point issues the same sequence from C, on the caller's stream, with every collective of a
+// dim-sharded job (row norms when clipping, the n x n squared distances, the packed statistics) going
+// through the library's RCCL communicator.  At one GPU the host cost of a step is irrelevant (the kernels
+// take milliseconds); at 8 ranks they take tens of microseconds each and a dozen Python-side calls plus
+// three torch.distributed collectives per step would dominate.
+//
+// Sequence (d = the rank's slice):
+//   [clip]   row squared norms of the sampled gradients -> all-reduce -> clipping factors   attack.py:791-794
+//   pass 1   bm_momentum_stats: momentum in place, sampled / honest statistics, Byzantine vector   :800-804,846-847
+//   rule     bm_sharded_krum / bm_sharded_bulyan (distances -> all-reduce -> rank -> mean / pass 2) or bm_colwise   :821
+//   stats    attack stack, defense vector                                                     :848,851-852
+//   dots     Gram of (sampled avg, honest avg, defense, attack avg) + <s, newest past>, <s, C>   :854-866
+//   C        curvature combination C <- s + mu * (C - mu^(P-1) * oldest)                       (see step.py)
+//   l2       ||params - origin||^2                                                            :830
+//   pack     every scalar into one vector -> all-gather -> fixed-order sums / maxima -> stats_out
+#include "bm_common.h"
+
+namespace bm {
+
+constexpr int kStatSums = 26;   // s2 sd h2 hd d2 a2 ad l2 | gram 4x4 | ex0 ex1
+constexpr int kStatMaxes = 4;   // smax hmax dmax amax
+constexpr int kStatSlots = 32;  // kStatSums + kStatMaxes, padded
+
+// scratch scalars of one call, all fp64 on the device
+struct StepScalars {
+  double out6[6];
+  double a3[3];
+  double d3[3];
+  double dots[18];
+  double l2[4];
+  double rowsq[BM_MAX_ROWS];
+  double gram4[4 * 16];  // row norms: Gram blocks of up to four rows at a time
+  double mine[kStatSlots];
+  double all[kStatSlots * BM_MAX_ROWS];  // up to 64 ranks
+  float clipf[BM_MAX_ROWS];
+};
+
+__global__ void step_diag_kernel(const double* __restrict__ gram, int nc, double* __restrict__ rowsq) {
+  const int i = threadIdx.x;
+  if (i < nc) rowsq[i] = gram[i * nc + i];
+}
+
+__global__ void step_pack_kernel(StepScalars* sc, int has_attack, int nc, int has_past, int has_l2) {
+  if (threadIdx.x != 0) return;
+  double* m = sc->mine;
+  for (int i = 0; i < kStatSlots; ++i) m[i] = 0.0;
+  m[0] = sc->out6[0];
+  m[1] = sc->out6[1];
+  m[2] = sc->out6[3];
+  m[3] = sc->out6[4];
+  m[4] = sc->d3[0];
+  m[5] = has_attack ? sc->a3[0] : 0.0;
+  m[6] = has_attack ? sc->a3[1] : 0.0;
+  m[7] = has_l2 ? sc->l2[1] : 0.0;
+  for (int a = 0; a < nc; ++a)
+    for (int b = 0; b < nc; ++b) m[8 + a * 4 + b] = sc->dots[a * nc + b];
+  if (has_past) {
+    m[24] = sc->dots[nc * nc];
+    m[25] = sc->dots[nc * nc + 1];
+  }
+  m[kStatSums + 0] = sc->out6[2];
+  m[kStatSums + 1] = sc->out6[5];
+  m[kStatSums + 2] = sc->d3[2];
+  m[kStatSums + 3] = has_attack ? sc->a3[2] : 0.0;
+}
+
+// stats_out[slot] = sum over ranks in rank order (slots < kStatSums) or NaN-propagating maximum
+__global__ void step_reduce_kernel(const double* __restrict__ all, int nranks, double* __restrict__ out) {
+  const int slot = threadIdx.x;
+  if (slot >= kStatSlots) return;
+  double acc = all[slot];
+  bool nan = acc != acc;
+  for (int r = 1; r < nranks; ++r) {
+    const double v = all[r * kStatSlots + slot];
+    if (slot < kStatSums) {
+      acc += v;
+    } else {
+      nan |= (v != v);
+      acc = v > acc ? v : acc;
+    }
+  }
+  out[slot] = (slot >= kStatSums && nan) ? __builtin_nan("") : acc;
+}
+
+struct StepLayout {
+  int64_t scalars, ws_step, ws_stats, ws_dot, ws_rule, ws_pair2, total;
+};
+
+static StepLayout step_layout(int n, int64_t d) {
+  StepLayout l;
+  auto up = [](int64_t v) { return (v + 255) / 256 * 256; };
+  int64_t off = 0;
+  l.scalars = off;
+  off += up((int64_t)sizeof(StepScalars));
+  l.ws_step = off;
+  off += up(bm_workspace_bytes(BM_WS_STEP, 1, d));
+  l.ws_stats = off;
+  off += up(bm_workspace_bytes(BM_WS_STATS, 1, d));
+  l.ws_dot = off;
+  off += up(bm_workspace_bytes(BM_WS_DOT, 1, d));
+  l.ws_rule = off;
+  off += up(bm_sharded_workspace_bytes(n, d));
+  l.ws_pair2 = off;
+  off += up(bm_workspace_bytes(BM_WS_PAIRWISE, 2, d));
+  l.total = off;
+  return l;
+}
+
+}  // namespace bm
+
+extern "C" int bm_step_stats_count(void) { return bm::kStatSlots; }
+
+extern "C" int64_t bm_step_workspace_bytes(int n, int64_t d_local) {
+  if (n < 1 || n > BM_MAX_ROWS || d_local < 0) return BM_EINVAL;
+  return bm::step_layout(n, d_local).total;
+}
+
+extern "C" int bm_step_worker(bm_comm* comm, const bm_step_params* p, const float* const* sampled,
+                              float* const* buffers, int64_t d, float* defense_out, float* sampled_avg_out,
+                              float* honest_avg_out, float* byz_out, float* attack_avg_out,
+                              const float* past_newest, float* curv, const float* past_oldest, const float* params,
+                              const float* origin, double* stats_out, void* ws, void* stream) {
+  using namespace bm;
+  if (p == nullptr || sampled == nullptr || buffers == nullptr || stats_out == nullptr || ws == nullptr || d < 0)
+    return BM_EINVAL;
+  const int n = p->n, h = p->n - p->f_real, ks = p->ks, fr = p->f_real;
+  if (n < 1 || n > BM_MAX_ROWS || h < 1 || ks < h || ks > BM_MAX_ROWS || fr < 0 ||
+      (d > 0 && (defense_out == nullptr || sampled_avg_out == nullptr || honest_avg_out == nullptr)) ||
+      (fr > 0 && d > 0 && (byz_out == nullptr || attack_avg_out == nullptr)))
+    return BM_EINVAL;
+  const bool distance_rule = p->rule == BM_RULE_KRUM || p->rule == BM_RULE_BULYAN;
+  if (!distance_rule && p->rule != BM_RULE_MEDIAN && p->rule != BM_RULE_TRMEAN && p->rule != BM_RULE_PHOCAS &&
+      p->rule != BM_RULE_MEAMED)
+    return BM_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  char* base = static_cast<char*>(ws);
+  const StepLayout lay = step_layout(n, d);
+  StepScalars* sc = reinterpret_cast<StepScalars*>(base + lay.scalars);
+  int rc;
+
+  // ---- clipping factors (device scalars, global under sharding) ----
+  const float* clipf = nullptr;
+  if (p->clip > 0.0f) {
+    for (int lo = 0; lo < ks; lo += 4) {
+      const int nc = ks - lo < 4 ? ks - lo : 4;
+      rc = bm_multi_dot(sampled + lo, nc, nullptr, 0, d, sc->gram4 + (lo / 4) * 16, base + lay.ws_dot, stream);
+      if (rc != 0) return rc;
+      hipLaunchKernelGGL(step_diag_kernel, dim3(1), dim3(64), 0, s, sc->gram4 + (lo / 4) * 16, nc, sc->rowsq + lo);
+      BM_LAUNCH_CHECK();
+    }
+    rc = bm_allreduce_sum_f64(comm, sc->rowsq, ks, stream);
+    if (rc != 0) return rc;
+    rc = bm_clip_factors(sc->rowsq, ks, p->clip, sc->clipf, stream);
+    if (rc != 0) return rc;
+    clipf = sc->clipf;
+  }
+
+  // ---- pass 1: momentum, statistics of the sampled and honest stacks, Byzantine vector ----
+  rc = bm_momentum_stats(sampled, ks, buffers, h, d, p->mu, p->one_minus_damp, clipf, sampled_avg_out, honest_avg_out,
+                         fr > 0 ? byz_out : nullptr, p->attack_scale, p->attack_kind, sc->out6, base + lay.ws_step,
+                         stream);
+  if (rc != 0) return rc;
+
+  // ---- the rule over honests + [byz] * f_real ----
+  const float* rows[BM_MAX_ROWS];
+  for (int i = 0; i < h; ++i) rows[i] = buffers[i];
+  for (int i = h; i < n; ++i) rows[i] = byz_out;
+  const int m = p->m > 0 ? p->m : n - p->f_decl - 2;
+  switch (p->rule) {
+    case BM_RULE_KRUM:
+      rc = bm_sharded_krum(comm, rows, n, d, p->f_decl, m, defense_out, nullptr, base + lay.ws_rule, stream);
+      break;
+    case BM_RULE_BULYAN:
+      rc = bm_sharded_bulyan(comm, rows, n, d, p->f_decl, m, defense_out, nullptr, base + lay.ws_rule, stream);
+      break;
+    case BM_RULE_MEDIAN: rc = bm_colwise(BM_OP_MEDIAN, rows, n, d, 0, defense_out, stream); break;
+    case BM_RULE_TRMEAN: rc = bm_colwise(BM_OP_TRMEAN, rows, n, d, p->f_decl, defense_out, stream); break;
+    case BM_RULE_PHOCAS: rc = bm_colwise(BM_OP_PHOCAS, rows, n, d, p->f_decl, defense_out, stream); break;
+    default: rc = bm_colwise(BM_OP_MEAMED, rows, n, d, p->f_decl, defense_out, stream); break;
+  }
+  if (rc != 0) return rc;
+
+  // ---- attack stack and defense vector ----
+  if (fr > 0) {
+    rc = bm_stack_stats(rows + h, fr, d, attack_avg_out, nullptr, 0.0f, BM_ATTACK_EMPIRE, sc->a3, base + lay.ws_stats,
+                        stream);
+    if (rc != 0) return rc;
+  }
+  const float* def_row[1] = {defense_out};
+  rc = bm_stack_stats(def_row, 1, d, nullptr, nullptr, 0.0f, BM_ATTACK_EMPIRE, sc->d3, base + lay.ws_stats, stream);
+  if (rc != 0) return rc;
+
+  // ---- dot products of the study block ----
+  const float* core[4] = {sampled_avg_out, honest_avg_out, defense_out, attack_avg_out};
+  const int nc = fr > 0 ? 4 : 3;
+  const bool has_past = p->nb_past > 0 && p->past_count > 0 && past_newest != nullptr && curv != nullptr;
+  const float* extra[2] = {past_newest, curv};
+  rc = bm_multi_dot(core, nc, has_past ? extra : nullptr, has_past ? 2 : 0, d, sc->dots, base + lay.ws_dot, stream);
+  if (rc != 0) return rc;
+
+  // ---- curvature combination (after the dots have read the old one: same stream) ----
+  if (p->nb_past > 0 && curv != nullptr && d > 0) {
+    if (p->past_count == 0) {
+      rc = hip_code(hipMemcpyAsync(curv, sampled_avg_out, (size_t)d * sizeof(float), hipMemcpyDeviceToDevice, s));
+      if (rc != 0) return rc;
+    } else {
+      float* out1[1] = {curv};
+      const float* p1[1] = {curv};
+      if (past_oldest != nullptr) {
+        const float* q0[1] = {past_oldest};
+        rc = bm_multi_fma3(out1, p1, q0, 1, d, 1.0f, p->oldest_weight, nullptr, stream);  // -(mu^(P-1))
+        if (rc != 0) return rc;
+      }
+      const float* q1[1] = {sampled_avg_out};
+      rc = bm_multi_fma3(out1, p1, q1, 1, d, p->mu, 1.0f, nullptr, stream);
+      if (rc != 0) return rc;
+    }
+  }
+
+  // ---- l2 distance from the origin ----
+  const bool has_l2 = params != nullptr && origin != nullptr;
+  if (has_l2) {
+    const float* two[2] = {params, origin};
+    rc = bm_pairwise_sqdist(two, 2, d, sc->l2, base + lay.ws_pair2, stream);
+    if (rc != 0) return rc;
+  }
+
+  // ---- one packed exchange of every scalar ----
+  hipLaunchKernelGGL(step_pack_kernel, dim3(1), dim3(64), 0, s, sc, fr > 0 ? 1 : 0, nc, has_past ? 1 : 0,
+                     has_l2 ? 1 : 0);
+  BM_LAUNCH_CHECK();
+  const int nranks = bm_comm_size(comm);
+  if (nranks > BM_MAX_ROWS) return BM_EINVAL;
+  const double* gathered = sc->mine;
+  if (comm != nullptr) {
+    rc = bm_allgather_f32(comm, reinterpret_cast<const float*>(sc->mine), reinterpret_cast<float*>(sc->all),
+                          2 * kStatSlots, stream);  // doubles moved as pairs of 4-byte words
+    if (rc != 0) return rc;
+    gathered = sc->all;
+  }
+  hipLaunchKernelGGL(step_reduce_kernel, dim3(1), dim3(64), 0, s, gathered, comm != nullptr ? nranks : 1, stats_out);
+  BM_LAUNCH_CHECK();
+  return 0;
+}

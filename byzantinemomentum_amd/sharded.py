@@ -157,6 +157,10 @@ class HipBackend:
   def study_dots(self, core, extra):
     return self.stats.study_dots(core, extra)
 
+  def step_worker(self, comm, *args, **kwargs):
+    """One whole step with worker-side momentum in one C call (bm_step_worker)."""
+    return self.stats.step_worker(comm, *args, **kwargs)
+
 
 class ShardedAggregator:
   """Aggregation rules over gradients whose coordinates are sharded across the ranks of `group`."""

@@ -15,7 +15,8 @@ from . import _lib
 from . import gars
 
 __all__ = ["compute_avg_dev_max", "stack_stats_async", "study_dots", "multi_axpby", "row_sqnorms", "momentum_stats",
-           "multi_fma3", "clip_factors", "clip_factors_from_sq", "multi_scale", "clip_gradients", "l2_distance"]
+           "multi_fma3", "clip_factors", "clip_factors_from_sq", "multi_scale", "clip_gradients", "l2_distance",
+           "step_worker"]
 
 _ptr = gars._ptr
 
@@ -193,3 +194,32 @@ def l2_distance(a, b):
   """||a - b||_2 as a device fp64 scalar tensor (attack.py:830 `l2_origin`), no sync.  Two rows through
   the centred pairwise kernel: the centre is row 0, so the contraction sees a - b itself (no cancellation)."""
   return gars.pairwise_sqdist([a, b])[0, 1].sqrt()
+
+
+def step_worker(comm, sampled, buffers, n, f_decl, f_real, rule, m, mu, one_minus_damp, clip, attack, attack_scale,
+                nb_past, past_count, past_newest, curv, past_oldest, params=None, origin=None):
+  """One simulation step with worker-side momentum as ONE C call (bm_step_worker, include/bm_gar.h).
+
+  comm: sharded.NativeComm or None.  Returns (defense, sampled_avg, honest_avg, byz, attack_avg, stats) with
+  `stats` the device fp64 vector documented in the header (already reduced over the ranks). No sync."""
+  ks, d, device = gars._validate(list(sampled))
+  lib = _lib.load()
+  new = lambda: torch.empty(d, dtype=torch.float32, device=device)  # noqa: E731
+  defense, s_avg, h_avg = new(), new(), new()
+  byz, a_avg = (new(), new()) if f_real > 0 else (None, None)
+  stats = torch.empty(lib.bm_step_stats_count(), dtype=torch.float64, device=device)
+  ws = gars._Scratch.get(device, "ws_stepcall", nbytes=int(lib.bm_step_workspace_bytes(n, d)))
+  par = _lib.StepParams(n=n, f_decl=f_decl, f_real=f_real, ks=ks, rule=_lib.RULE_IDS[rule], m=m or 0,
+                        attack_kind=_lib.ATTACK_LITTLE if attack == "little" else _lib.ATTACK_EMPIRE, nb_past=nb_past,
+                        past_count=past_count, attack_scale=attack_scale, mu=mu, one_minus_damp=one_minus_damp,
+                        clip=clip if clip is not None else 0.0,
+                        oldest_weight=-(mu ** (nb_past - 1)) if nb_past > 0 else 0.0)
+  opt = lambda t: _ptr(t) if t is not None else None  # noqa: E731
+  gars.invalidate_rank_cache()
+  with torch.cuda.device(device):
+    _lib.check(lib.bm_step_worker(comm.handle if comm is not None else None, ctypes.byref(par),
+                                  _lib.pointer_table(sampled), _lib.pointer_table(buffers), d, _ptr(defense),
+                                  _ptr(s_avg), _ptr(h_avg), opt(byz), opt(a_avg), opt(past_newest), opt(curv),
+                                  opt(past_oldest), opt(params), opt(origin), _ptr(stats), _ptr(ws),
+                                  gars._stream(device)), "bm_step_worker")
+  return defense, s_avg, h_avg, byz, a_avg, stats

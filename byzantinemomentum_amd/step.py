@@ -37,9 +37,12 @@ MAX_PAST = 4096  # past sampled averages kept for the curvature term (each is on
 class AggregationStep:
   def __init__(self, nb_workers, nb_decl_byz, nb_real_byz, gar="krum", gar_args=None, momentum=0.99,
                dampening=0.99, momentum_at="worker", attack="empire", attack_factor=1.1, nb_past=25,
-               gradient_clip=None, aggregator=None):
+               gradient_clip=None, aggregator=None, single_call=True):
     """aggregator: a sharded.ShardedAggregator (default: one over the default process group, or a
-    single-rank one when torch.distributed is not initialised)."""
+    single-rank one when torch.distributed is not initialised).
+    single_call: with the HIP backend, worker-side momentum and a rule the C entry point knows
+    (krum, bulyan, median, trmean, phocas, meamed), run() is ONE call into libbm_gar.so (bm_step_worker),
+    collectives included; False keeps the kernel-by-kernel Python sequence (same kernels, same results)."""
     if gar not in _RULES:
       raise ValueError(f"unknown aggregation rule {gar!r}")
     if momentum_at not in ("worker", "server", "update"):
@@ -76,6 +79,11 @@ class AggregationStep:
     self._curv = None
     self._pending = None
     self._update = None
+    self._prev_stats = None    # single-call form: the previous step's reduced statistics (slot 0 = ||avg_s||^2)
+    extra_args = set(self.gar_args) - {"m"}
+    self.single_call = bool(single_call and momentum_at == "worker" and hasattr(self.ops, "step_worker")
+                            and gar in ("krum", "bulyan", "median", "trmean", "phocas", "meamed") and not extra_args
+                            and (not self.agg.collective or self.agg.native is not None))
 
   # ------------------------------------------------------------------------ #
 
@@ -106,6 +114,8 @@ class AggregationStep:
     if ks < h:
       raise ValueError(f"{ks} sampled gradients for {h} honest workers")
     omd = 1.0 - self.damp
+    if self.single_call:
+      return self._run_single_call(sampled, ks, omd, params, origin)
     # 0. clipping factors (device scalars; the all-reduce makes them global under sharding)
     factors = None
     if self.clip is not None:
@@ -170,6 +180,27 @@ class AggregationStep:
       self._prev_s2 = s_out3[:1]
     return defense
 
+  def _run_single_call(self, sampled, ks, omd, params, origin):
+    h = self.h
+    if self.buffers is None:
+      self.buffers = [torch.zeros_like(g) for g in sampled[:h]]
+    count = len(self.pasts) if self.nb_past > 0 else 0
+    if self.nb_past > 0 and self._curv is None:
+      self._curv = torch.empty_like(sampled[0])  # written by the first step (C <- s)
+    full = count == self.nb_past and count > 0
+    defense, s_avg, h_avg, byz, a_avg, stats = self.ops.step_worker(
+      self.agg.native, sampled, self.buffers, self.n, self.f_decl, self.f_real, self.gar, self.gar_args.get("m"),
+      self.mu, omd, self.clip, self.attack, self.factor, self.nb_past, count,
+      self.pasts[0] if count > 0 else None, self._curv, self.pasts[-1] if full else None, params, origin)
+    self._update = defense
+    self._pending = dict(packed=stats, prev=self._prev_stats if count > 0 else None, npast=2 if count > 0 else 0,
+                         has_attack=self.f_real > 0, has_l2=params is not None and origin is not None, ks=ks,
+                         floats=None)
+    if self.nb_past > 0:
+      self.pasts.appendleft(s_avg)
+      self._prev_stats = stats
+    return defense
+
   def update_gradient(self):
     """What attack.py:832-839 passes to model.update(): the defense gradient (worker / server
     placements) or the updated server momentum (update placement)."""
@@ -191,6 +222,39 @@ class AggregationStep:
     sums, maxes = self.agg.exchange(torch.cat(sums), torch.cat(maxes))
     return sums.tolist(), maxes.tolist()
 
+  def _floats_from_packed(self, pend):
+    """Decode the statistics vector of bm_step_worker (layout: include/bm_gar.h)."""
+    vec = pend["packed"] if pend["prev"] is None else torch.cat([pend["packed"], pend["prev"][:1]])
+    v = vec.tolist()  # the only synchronisation
+    nan = math.nan
+    att, k_s, k_h, k_a = pend["has_attack"], pend["ks"], self.h, self.f_real
+
+    def dev(x, k):
+      return math.sqrt(x / (k - 1)) if k >= 2 else nan
+
+    def cos(i, j):
+      if not att and 3 in (i, j):
+        return nan
+      return v[8 + 4 * i + j] / math.sqrt(v[8 + 5 * i]) / math.sqrt(v[8 + 5 * j])
+
+    res = {
+      "l2_origin": math.sqrt(v[7]) if pend["has_l2"] else nan,
+      "sampled_norm_avg": math.sqrt(v[0]), "sampled_norm_dev": dev(v[1], k_s), "sampled_norm_max": v[26],
+      "honest_norm_avg": math.sqrt(v[2]), "honest_norm_dev": dev(v[3], k_h), "honest_norm_max": v[27],
+      "attack_norm_avg": math.sqrt(v[5]) if att else nan, "attack_norm_dev": dev(v[6], k_a) if att else nan,
+      "attack_norm_max": v[29] if att else nan,
+      "defense_norm_avg": math.sqrt(v[4]), "defense_norm_max": v[28],
+      "cosin_splhon": cos(0, 1), "cosin_spldef": cos(0, 2), "cosin_hondef": cos(1, 2),
+      "cosin_splatt": cos(0, 3), "cosin_honatt": cos(1, 3), "cosin_attdef": cos(3, 2),
+    }
+    if pend["npast"] > 0:
+      res["cosin_sampled"] = v[24] / math.sqrt(v[0]) / math.sqrt(v[32])
+      res["curv_sampled"] = self.mu * v[25]
+    else:
+      res["cosin_sampled"] = nan
+      res["curv_sampled"] = nan
+    return res
+
   def floats(self):
     """Python floats of the study row (attack.py:828-868) for the last run(); synchronises once.
     Idempotent: a second call returns the same dictionary without touching the device."""
@@ -198,6 +262,9 @@ class AggregationStep:
     if pend is None:
       raise RuntimeError("floats() needs a run() first")
     if pend["floats"] is not None:
+      return pend["floats"]
+    if "packed" in pend:
+      pend["floats"] = self._floats_from_packed(pend)
       return pend["floats"]
     sums, maxes = self._exchange(pend)
     it = iter(sums)

@@ -199,6 +199,44 @@ int bm_sharded_krum(bm_comm* comm, const float* const* rows, int n, int64_t d_lo
 int bm_sharded_bulyan(bm_comm* comm, const float* const* rows, int n, int64_t d_local, int f, int m,
                       float* out_local, int32_t* order_out, void* ws, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * One simulation step with worker-side momentum (attack.py:786-868) as ONE call on the caller's stream:
+ * [clipping factors] -> bm_momentum_stats -> rule over buffers + [byz] * f_real -> attack / defense
+ * statistics -> study dots -> curvature combination -> l2 from the origin -> one packed exchange.
+ * comm NULL = one rank; otherwise every collective of the dim-sharded step (row norms when clipping, the
+ * n x n squared distances, the packed statistics) goes through it.  d = coordinates of this rank.
+ *
+ * stats_out (DEVICE, bm_step_stats_count() doubles, identical on every rank):
+ *   [0] sum avg_s^2  [1] sum_i |s_i-avg_s|^2  [2] sum avg_h^2  [3] sum_i |b_i-avg_h|^2  [4] |defense|^2
+ *   [5] sum avg_a^2  [6] sum_i |a_i-avg_a|^2  [7] |params-origin|^2
+ *   [8 + 4a + b] <core_a, core_b>, core = (sampled avg, honest avg, defense, attack avg)
+ *   [24] <sampled avg, past_newest>  [25] <sampled avg, curv>   [26..29] max|avg_s|, max|avg_h|, max|defense|, max|avg_a|
+ * curv (in/out, may be NULL when nb_past = 0): C = sum_i mu^i past_i, updated for the NEXT step
+ * (C <- s when past_count = 0, else C <- mu * (C + oldest_weight * past_oldest) ... see step.py);
+ * past_oldest non-NULL only when the caller's ring of nb_past vectors is full (its last entry).
+ */
+enum bm_step_rule { BM_RULE_KRUM = 0, BM_RULE_BULYAN = 1, BM_RULE_MEDIAN = 2, BM_RULE_TRMEAN = 3,
+                    BM_RULE_PHOCAS = 4, BM_RULE_MEAMED = 5 };
+typedef struct bm_step_params {
+  int32_t n, f_decl, f_real;  /* workers, declared and real Byzantine ones; honest = n - f_real      */
+  int32_t ks;                 /* sampled gradients (>= honest)                                        */
+  int32_t rule;               /* bm_step_rule                                                          */
+  int32_t m;                  /* Multi-Krum / Bulyan m, 0 = n - f_decl - 2                             */
+  int32_t attack_kind;        /* bm_attack_kind                                                        */
+  int32_t nb_past;            /* length P of the caller's ring of past sampled averages, 0 = none      */
+  int32_t past_count;         /* entries in the ring before this step                                  */
+  float attack_scale;         /* factor of the attack                                                  */
+  float mu, one_minus_damp;   /* momentum, 1 - dampening                                               */
+  float clip;                 /* gradient clipping threshold, <= 0 = off                               */
+  float oldest_weight;        /* -(mu^(P-1)): weight that takes the leaving entry out of C              */
+} bm_step_params;
+int bm_step_stats_count(void);
+int64_t bm_step_workspace_bytes(int n, int64_t d_local);
+int bm_step_worker(bm_comm* comm, const bm_step_params* p, const float* const* sampled, float* const* buffers,
+                   int64_t d, float* defense_out, float* sampled_avg_out, float* honest_avg_out, float* byz_out,
+                   float* attack_avg_out, const float* past_newest, float* curv, const float* past_oldest,
+                   const float* params, const float* origin, double* stats_out, void* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

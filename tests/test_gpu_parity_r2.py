@@ -559,3 +559,35 @@ def test_zero_length_inputs_through_every_entry_point(bm):
   agg = ShardedAggregator()
   assert agg.krum(rows, f).shape == (0,) and agg.bulyan(rows, f).shape == (0,)
   assert bm.gars.krum_selection(rows, f) == list(range(n - f - 2))      # all-zero distances: ties by index
+
+
+# ---------------------------------------------------------------------------- #
+# The single-call step (bm_step_worker) issues the same kernels as the Python sequence: identical bits
+
+@pytest.mark.parametrize("gar,clip,attack,factor,f_real", [("krum", None, "empire", 1.1, 5), ("bulyan", 150.0, "little", 1.5, 5),
+                                                         ("median", None, "empire", 1.1, 5), ("trmean", 140.0, "little", -1.5, 5),
+                                                         ("meamed", None, "empire", 1.1, 0), ("phocas", None, "empire", 1.1, 3)])
+def test_single_call_step_equals_python_sequence(bm, gar, clip, attack, factor, f_real):
+  from byzantinemomentum_amd.step import AggregationStep
+  n, f, d = 25, 5, 40013
+  h = n - f_real
+  kw = dict(gar=gar, momentum=0.9, dampening=0.9, attack=attack, attack_factor=factor, nb_past=3, gradient_clip=clip)
+  one = AggregationStep(n, f, f_real, single_call=True, **kw)
+  seq = AggregationStep(n, f, f_real, single_call=False, **kw)
+  assert one.single_call and not seq.single_call
+  gen = torch.Generator(device=DEV).manual_seed(31)
+  origin = torch.randn(d, device=DEV, generator=gen)
+  params = origin + 0.01
+  for it in range(5):
+    base = 0.2 * torch.randn(d, device=DEV, generator=gen)
+    sampled = [base + (0.5 + 0.05 * i) * torch.randn(d, device=DEV, generator=gen) for i in range(h + (1 if it == 3 else 0))]
+    a = one.run([g.clone() for g in sampled], params, origin)
+    b = seq.run([g.clone() for g in sampled], params, origin)
+    assert torch.equal(a, b), (gar, it)
+    for x, y in zip(one.buffers, seq.buffers):
+      assert torch.equal(x, y)
+    if it != 1:
+      fa, fb = one.floats(), seq.floats()
+      for key in fb:
+        assert fa[key] == fb[key] or (math.isnan(fa[key]) and math.isnan(fb[key])), (gar, it, key, fa[key], fb[key])
+    params = params - 0.05 * a
