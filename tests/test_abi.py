@@ -54,3 +54,22 @@ def test_argument_validation_without_gpu(lib):
   assert lib.bm_colwise(0, rows, 65, 10, 0, None, None) == _lib.EINVAL     # n > BM_MAX_ROWS
   assert lib.bm_workspace_bytes(0, 0, 10) == _lib.EINVAL
   assert lib.bm_workspace_bytes(_lib.WS_PAIRWISE, 25, 1000) > 0
+
+
+def test_new_entry_points_validate_arguments_without_gpu(lib):
+  """Round-2 entry points: bad arguments are refused before any HIP or RCCL call."""
+  from byzantinemomentum_amd import _lib
+  rows = (ctypes.c_void_p * 4)()
+  assert lib.bm_momentum_stats(rows, 3, rows, 4, 10, 0.9, 0.1, None, None, None, None, 1.0, 0, None, None, None) == _lib.EINVAL
+  assert lib.bm_multi_fma3(rows, rows, rows, 0, 10, 1.0, 1.0, None, None) == _lib.EINVAL
+  assert lib.bm_clip_factors(None, 3, 1.0, None, None) == _lib.EINVAL
+  assert lib.bm_sharded_workspace_bytes(0, 10) == _lib.EINVAL
+  assert lib.bm_sharded_workspace_bytes(25, 1000) > 0
+  assert lib.bm_step_workspace_bytes(25, 1000) > lib.bm_sharded_workspace_bytes(25, 1000)
+  assert lib.bm_step_stats_count() == 32
+  par = _lib.StepParams(n=25, f_decl=5, f_real=5, ks=10, rule=0)  # ks < honest count
+  assert lib.bm_step_worker(None, ctypes.byref(par), rows, rows, 10, *([None] * 13)) == _lib.EINVAL
+  assert lib.bm_comm_size(None) == 1
+  assert lib.bm_allreduce_sum_f64(None, None, 4, None) == _lib.EINVAL
+  assert lib.bm_comm_init(None, 1, 0, None) == _lib.EINVAL
+  assert b"RCCL" in lib.bm_error_string(_lib.ENOCOMM) and b"RCCL" in lib.bm_error_string(_lib.ECOMM)
