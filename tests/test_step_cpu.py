@@ -126,9 +126,10 @@ def _worker(rank, world, port, d, queue):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("d", [D, 100, 40])  # 100: the second rank's shard is short (36 coordinates); 40: it is EMPTY
-def test_two_rank_sharded_step_matches_single_rank(d):
-  world = 2
+@pytest.mark.parametrize("world,d", [(2, D), (2, 100), (2, 40), (3, D), (3, 130)])
+def test_sharded_step_matches_single_rank(world, d):
+  """d = 100 / world 2: the second rank's shard is short (36 coordinates); d = 40: it is EMPTY;
+  world 3, d = 130: shards of 64, 64 and 2 coordinates."""
   ctx = mp.get_context("spawn")
   queue = ctx.Queue()
   port = _free_port()
@@ -155,8 +156,10 @@ def test_two_rank_sharded_step_matches_single_rank(d):
           g = got[key]
           assert (math.isnan(g) and math.isnan(val)) or abs(g - val) <= 1e-9 * max(abs(val), 1e-6), (cfg, it, key, g, val)
       # every rank computed the same floats (same packed exchange, same reduction order)
-      a, b = results[0][(ci, it)][1], results[1][(ci, it)][1]
-      assert all(a[k] == b[k] or (math.isnan(a[k]) and math.isnan(b[k])) for k in a)
+      a = results[0][(ci, it)][1]
+      for r in range(1, world):
+        b = results[r][(ci, it)][1]
+        assert all(a[k] == b[k] or (math.isnan(a[k]) and math.isnan(b[k])) for k in a)
 
 
 def test_empty_shard_layout():
