@@ -424,6 +424,27 @@ def step_algorithmic_bytes(d, n, f, gar):
   return 4 * d * ((h + 2 * h + 3) + gar_units + 2 + 1 + 12)
 
 
+def attack_search(bm, honests, n, f, d, evals=16):
+  """The factor search of the "identical" attacks (attacks/identical.py:67-77, the reference's default
+  factor=-16) against Multi-Krum at C3: wall-clock of the whole search, scalar form (one distance pass over
+  h+2 rows, then host only) and the reference's form (the rule on the vectors once per evaluation)."""
+  from byzantinemomentum_amd.step import AggregationStep
+  avg, _, direction = bm.stats.stack_stats_async(honests, scale=1.0, attack="empire", direction=True)
+  res = {"config": f"empire against krum, n={n}, f={f}, d={d}, {evals} evaluations, one GPU"}
+  for mode, reps in (("auto", 10), ("generic", 3)):
+    runner = AggregationStep(n, f, f, gar="krum", attack_evals=evals, line_search=mode, nb_past=0)
+    runner._search_factor(honests, avg, direction)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+      factor = runner._search_factor(honests, avg, direction)
+    torch.cuda.synchronize()
+    res["scalar_form_ms" if mode == "auto" else "per_evaluation_form_ms"] = (time.perf_counter() - t0) / reps * 1e3
+    res["factor_" + mode] = factor
+  res["speedup"] = res["per_evaluation_form_ms"] / res["scalar_form_ms"]
+  return res
+
+
 def extras_single_gpu(bm, device, timer, aliased):
   """C3, C4 (one GPU) and C5 in a few iterations each: the driver-run record then carries every
   single-GPU configuration of BASELINE.json, not only the headline one."""
@@ -438,6 +459,8 @@ def extras_single_gpu(bm, device, timer, aliased):
     ms_pair = timed_loop(lambda i: bm.gars.pairwise_sqdist(stacks[i & 1]), 12, 3, timer, name + "_dist")
     out[name] = entry(ms, 4 * d * n + 4 * d * (m + 1), config=f"n={n}, f={f}, m={m}, d={d}, one GPU",
                       distance_pass_ms=ms_pair, distance_pass_gbps=4 * d * n / ms_pair / 1e6)
+    if name == "krum_c3":
+      out["attack_search_c3_krum"] = attack_search(bm, stacks[0][:n - f], n, f, d)
     del stacks
     torch.cuda.empty_cache()
   n, f, d = 25, 5, D_WRN

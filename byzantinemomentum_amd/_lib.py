@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported before the CDLL, see above)
 _PKG_DIR = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _PKG_DIR / "libbm_gar.so"
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 MAX_ROWS = 64
 EINVAL = -100000
 ENOCOMM, ECOMM = -100001, -100002
@@ -24,7 +24,7 @@ ENOCOMM, ECOMM = -100001, -100002
 OP_MEDIAN, OP_TRMEAN, OP_PHOCAS, OP_MEAMED = 0, 1, 2, 3
 WS_PAIRWISE, WS_AKSEL, WS_STATS, WS_DOT, WS_STEP = 0, 1, 2, 3, 4
 RANK_KRUM, RANK_BULYAN = 0, 1
-ATTACK_EMPIRE, ATTACK_LITTLE = 0, 1
+ATTACK_EMPIRE, ATTACK_LITTLE, ATTACK_DIRECTION = 0, 1, 16
 
 _c_float_pp = ctypes.POINTER(ctypes.c_void_p)
 
@@ -81,10 +81,19 @@ SIGNATURES = {
   "bm_step_workspace_bytes": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int64]),
   "bm_step_worker": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_float_pp, _c_float_pp, ctypes.c_int64]
                      + [ctypes.c_void_p] * 13),
+  "bm_line_maximize": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double,
+                                      ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
+  "bm_attack_objective": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                         ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
+                                         ctypes.c_void_p]),
+  "bm_attack_line_search": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                           ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
 }
 
+SCAPE_FN = ctypes.CFUNCTYPE(ctypes.c_double, ctypes.c_double, ctypes.c_void_p)  # bm_scape_fn
 
-RULE_IDS = {"krum": 0, "bulyan": 1, "median": 2, "trmean": 3, "phocas": 4, "meamed": 5}
+
+RULE_IDS = {"krum": 0, "bulyan": 1, "median": 2, "trmean": 3, "phocas": 4, "meamed": 5, "brute": 6, "average": 7}
 
 
 class StepParams(ctypes.Structure):

@@ -1,0 +1,238 @@
+// Line-searching attacks on the host: attacks/identical.py:67-77 (the factor search of the "empire",
+// "little" and "bulyan" attacks, the DEFAULT of the reference: factor=-16) and the exploration routine
+// it calls, tools/misc.py:468-514.
+//
+// The reference evaluates the aggregation rule on n d-sized vectors once per candidate factor (16 times
+// per step).  For the rules whose output is the mean of a selected subset (Multi-Krum, Brute, Average),
+// every quantity the search needs is a function of the inner products among
+//     u_i = h_i - avg (the h honest rows around their mean)   and   att (the attack direction),
+// because the Byzantine row of candidate t is avg + t * att:
+//     |h_i - byz(t)|^2 = |u_i|^2 - 2 t <u_i, att> + t^2 |att|^2          (the rule's distance matrix)
+//     GAR(t) - avg     = (sum_{i in S} u_i + kb * t * att) / M            (S: selected honest rows,
+//                                                                          kb: selected Byzantine copies)
+// Those inner products come from ONE squared-distance pass over the h + 2 rows {h_1..h_h, avg, avg+att}
+// (bm_pairwise_sqdist), after which a candidate costs O(n^2 log n) host flops and no device work at all.
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#include "bm_common.h"
+
+extern "C" int bm_brute_select(const double* dist_nxn, int n, int f, int32_t* sel_out);
+
+namespace {
+
+// Best-effort arg-max of scape over x >= 0 under an evaluation budget (tools/misc.py:468-514): the first
+// phase walks right from `start` with a doubling step while the value improves; the second walks back and
+// forth around the best point with a step that shrinks by `ratio` per evaluation.  Comparisons are the
+// reference's strict '>' on doubles, so equal values never move the best point.
+template <class Scape>
+double line_maximize(Scape&& scape, int evals, double start, double delta, double ratio, double* trace) {
+  int done = 0;
+  auto eval = [&](double x) {
+    const double y = scape(x);
+    if (trace != nullptr) {
+      trace[2 * done] = x;
+      trace[2 * done + 1] = y;
+    }
+    ++done;
+    return y;
+  };
+  double best_x = start;
+  double best_y = eval(best_x);
+  double prop_x = best_x;
+  // expansion
+  while (done < evals) {
+    prop_x = best_x + delta;
+    const double prop_y = eval(prop_x);
+    if (prop_y > best_y) {
+      best_y = prop_y;
+      best_x = prop_x;
+      delta *= 2.0;
+    } else {
+      delta *= ratio;
+      break;
+    }
+  }
+  // contraction
+  while (done < evals) {
+    if (prop_x < best_x) {
+      prop_x += delta;
+    } else {
+      double x = prop_x - delta;
+      while (x < 0.0) x = (x + prop_x) / 2.0;
+      prop_x = x;
+    }
+    const double prop_y = eval(prop_x);
+    if (prop_y > best_y) {
+      best_y = prop_y;
+      best_x = prop_x;
+    }
+    delta *= ratio;
+  }
+  return best_x;
+}
+
+struct AttackGeometry {
+  int h, k, n;
+  std::vector<double> a;    // |u_i|^2
+  std::vector<double> w;    // <u_i, att>
+  std::vector<double> uu;   // <u_i, u_j>, h x h
+  std::vector<double> hh;   // |h_i - h_j|^2, h x h
+  double c;                 // |att|^2
+
+  AttackGeometry(const double* ext, int h_, int k_) : h(h_), k(k_), n(h_ + k_), a(h_), w(h_), uu((size_t)h_ * h_), hh((size_t)h_ * h_) {
+    const int e = h + 2;  // ext is (h+2) x (h+2): rows 0..h-1 honest, h = avg, h+1 = avg + att
+    c = ext[h * e + h + 1];
+    for (int i = 0; i < h; ++i) {
+      a[i] = ext[i * e + h];
+      w[i] = 0.5 * (a[i] + c - ext[i * e + h + 1]);
+    }
+    for (int i = 0; i < h; ++i)
+      for (int j = 0; j < h; ++j) {
+        hh[(size_t)i * h + j] = ext[i * e + j];
+        uu[(size_t)i * h + j] = (i == j) ? a[i] : 0.5 * (a[i] + a[j] - ext[i * e + j]);
+      }
+  }
+
+  // n x n squared distances of honests + [avg + t*att] * k
+  void sqdist(double t, std::vector<double>& sq) const {
+    sq.assign((size_t)n * n, 0.0);
+    for (int i = 0; i < h; ++i) {
+      for (int j = 0; j < h; ++j) sq[(size_t)i * n + j] = hh[(size_t)i * h + j];
+      double q = a[i] - 2.0 * t * w[i] + t * t * c;
+      if (q < 0.0) q = 0.0;  // rounding of a candidate that coincides with an honest row
+      for (int j = h; j < n; ++j) {
+        sq[(size_t)i * n + j] = q;
+        sq[(size_t)j * n + i] = q;
+      }
+    }
+  }
+
+  // |mean(selected rows) - avg|^2; the honest part is summed in index order so that the value depends on
+  // the selected SET only (two candidates that select the same honest rows and no Byzantine one compare
+  // equal, as they do in the reference where the rule then returns the same vector)
+  double objective(const std::vector<int>& sel_sorted, double t) const {
+    int kb = 0;
+    double quad = 0.0, lin = 0.0;
+    for (int i : sel_sorted) {
+      if (i >= h) {
+        ++kb;
+        continue;
+      }
+      lin += w[i];
+      for (int j : sel_sorted)
+        if (j < h) quad += uu[(size_t)i * h + j];
+    }
+    const double count = (double)sel_sorted.size();
+    return (quad + 2.0 * kb * t * lin + (double)kb * kb * t * t * c) / (count * count);
+  }
+};
+
+// Multi-Krum ranking on the host with the semantics of krum_rank_kernel (pairwise.hip) / krum.py:44-62:
+// distances = sqrt, non-finite -> +inf; score = ascending fp64 sum of the n-f-1 smallest of the row;
+// stable order of the scores (ties to the lower index).
+void krum_order(const std::vector<double>& sq, int n, int f, std::vector<int>& order) {
+  std::vector<double> score(n), row;
+  int take = n - f - 1;
+  take = std::max(0, std::min(take, n - 1));
+  for (int i = 0; i < n; ++i) {
+    row.clear();
+    for (int j = 0; j < n; ++j) {
+      if (j == i) continue;
+      double v = std::sqrt(sq[(size_t)i * n + j]);
+      if (!std::isfinite(v)) v = INFINITY;
+      row.push_back(v);
+    }
+    std::sort(row.begin(), row.end());
+    double s = 0.0;
+    for (int t = 0; t < take; ++t) s += row[t];
+    score[i] = s;
+  }
+  order.resize(n);
+  for (int i = 0; i < n; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return score[x] < score[y]; });
+}
+
+int select(const AttackGeometry& g, int f, int rule, int m, double t, std::vector<int>& sel) {
+  const int n = g.n;
+  std::vector<double> sq;
+  if (rule == BM_RULE_AVERAGE) {
+    sel.resize(n);
+    for (int i = 0; i < n; ++i) sel[i] = i;
+    return 0;
+  }
+  g.sqdist(t, sq);
+  if (rule == BM_RULE_KRUM) {
+    std::vector<int> order;
+    krum_order(sq, n, f, order);
+    sel.assign(order.begin(), order.begin() + m);
+    return 0;
+  }
+  // brute.py:44-68 works on the distances themselves
+  for (double& v : sq) v = std::sqrt(v);
+  std::vector<int32_t> out(n - f);
+  const int rc = bm_brute_select(sq.data(), n, f, out.data());
+  if (rc != 0) return rc;
+  sel.assign(out.begin(), out.end());
+  return 0;
+}
+
+bool valid(const double* ext, int h, int k, int f, int rule, int& m) {
+  const int n = h + k;
+  if (ext == nullptr || h < 1 || k < 0 || n > BM_MAX_ROWS || f < 0) return false;
+  if (rule == BM_RULE_KRUM) {
+    if (m <= 0) m = n - f - 2;
+    return m >= 1 && m <= n;
+  }
+  if (rule == BM_RULE_BRUTE) return n - f >= 1;
+  return rule == BM_RULE_AVERAGE;
+}
+
+}  // namespace
+
+extern "C" int bm_line_maximize(bm_scape_fn scape, void* ctx, int evals, double start, double delta,
+                                double ratio, double* best_x_out, double* trace_out) {
+  if (scape == nullptr || best_x_out == nullptr || evals < 1 || !(start >= 0.0) || !(delta > 0.0) ||
+      !(ratio > 0.5 && ratio < 1.0))
+    return BM_EINVAL;
+  *best_x_out = line_maximize([&](double x) { return scape(x, ctx); }, evals, start, delta, ratio, trace_out);
+  return 0;
+}
+
+extern "C" int bm_attack_objective(const double* ext, int h, int k, int f, int rule, int m, double t,
+                                   double* y_out, int32_t* sel_out, int32_t* count_out) {
+  if (!valid(ext, h, k, f, rule, m) || y_out == nullptr) return BM_EINVAL;
+  const AttackGeometry g(ext, h, k);
+  std::vector<int> sel;
+  const int rc = select(g, f, rule, m, t, sel);
+  if (rc != 0) return rc;
+  if (sel_out != nullptr)
+    for (size_t i = 0; i < sel.size(); ++i) sel_out[i] = sel[i];
+  if (count_out != nullptr) *count_out = (int32_t)sel.size();
+  std::sort(sel.begin(), sel.end());
+  *y_out = g.objective(sel, t);
+  return 0;
+}
+
+extern "C" int bm_attack_line_search(const double* ext, int h, int k, int f, int rule, int m, int evals,
+                                     int negative, double* factor_out, double* trace_out) {
+  if (!valid(ext, h, k, f, rule, m) || factor_out == nullptr || evals < 1) return BM_EINVAL;
+  const AttackGeometry g(ext, h, k);
+  std::vector<int> sel;
+  int status = 0;
+  *factor_out = line_maximize(
+      [&](double x) {
+        const double t = negative ? -x : x;  // identical.py:70-71
+        const int rc = select(g, f, rule, m, t, sel);
+        if (rc != 0) {
+          status = rc;
+          return (double)NAN;
+        }
+        std::sort(sel.begin(), sel.end());
+        return g.objective(sel, t);
+      },
+      evals, 0.0, 1.0, 0.8, trace_out);
+  return status;
+}

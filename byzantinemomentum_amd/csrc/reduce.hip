@@ -104,9 +104,10 @@ __global__ __launch_bounds__(kRedBlock) void stack_stats_kernel(RowTable rows, i
 #pragma unroll
       for (int c = 0; c < VEC; ++c) {
         // empire: grad_att = grad_avg.neg();            little: grad_att = grad_stck.var(dim=0).sqrt_()
-        const float dir = (attack_kind == BM_ATTACK_LITTLE) ? __builtin_sqrtf(colq[c] / (fk - 1.0f)) : -avg[c];
+        const float dir = ((attack_kind & 15) == BM_ATTACK_LITTLE) ? __builtin_sqrtf(colq[c] / (fk - 1.0f)) : -avg[c];
         const float att = dir * scale;  // grad_att.mul_(factor)
-        sc[c] = avg[c] + att;           // byz_grad = grad_avg.add_(grad_att)
+        // byz_grad = grad_avg.add_(grad_att); BM_ATTACK_DIRECTION: grad_att alone
+        sc[c] = (attack_kind & BM_ATTACK_DIRECTION) ? att : avg[c] + att;
       }
       store_result_policy<VEC>(scaled_out + v * VEC, sc, nt_result);
     }
@@ -363,7 +364,7 @@ extern "C" int bm_stack_stats(const float* const* rows, int k, int64_t d, float*
   // d == 0 is legal (an empty trailing shard): the finish kernel then writes zeros, so that every rank
   // of a sharded job reaches its collective
   if (rows == nullptr || out3 == nullptr || ws == nullptr || k < 1 || k > BM_MAX_ROWS || d < 0 ||
-      (attack_kind != BM_ATTACK_EMPIRE && attack_kind != BM_ATTACK_LITTLE))
+      ((attack_kind & ~BM_ATTACK_DIRECTION) != BM_ATTACK_EMPIRE && (attack_kind & ~BM_ATTACK_DIRECTION) != BM_ATTACK_LITTLE))
     return BM_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   RowTable tab{};

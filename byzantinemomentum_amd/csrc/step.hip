@@ -136,8 +136,9 @@ __global__ __launch_bounds__(kStepBlock) void momentum_stats_kernel(
         }
       dvh += qh;
       // empire: grad_att = grad_avg.neg();  little: grad_att = grad_stck.var(dim=0).sqrt_()
-      const float dir = (attack_kind == BM_ATTACK_LITTLE) ? __builtin_sqrtf(qh / (fh - 1.0f)) : -t;
-      bz[c] = t + dir * scale;  // grad_att.mul_(factor); byz_grad = grad_avg.add_(grad_att)
+      const float dir = ((attack_kind & 15) == BM_ATTACK_LITTLE) ? __builtin_sqrtf(qh / (fh - 1.0f)) : -t;
+      const float att = dir * scale;  // grad_att.mul_(factor)
+      bz[c] = (attack_kind & BM_ATTACK_DIRECTION) ? att : t + att;  // byz_grad = grad_avg.add_(grad_att)
     }
     if (s_avg_out != nullptr) store_result_policy<VEC>(s_avg_out + v * VEC, sa, nt_result);
     if (h_avg_out != nullptr) store_result_policy<VEC>(h_avg_out + v * VEC, ha, nt_result);
@@ -263,8 +264,9 @@ __global__ __launch_bounds__(kStepBlock, 4) void momentum_stats_stream_kernel(
       float colq = __builtin_fmaf(eh, __builtin_fmaf(fh, eh, -2.0f * th[c]), qh[c]);
       colq = colq < 0.0f ? 0.0f : colq;  // rounding of a column whose rows coincide; NaN stays NaN
       dvh += colq;
-      const float dir = (attack_kind == BM_ATTACK_LITTLE) ? __builtin_sqrtf(colq / (fh - 1.0f)) : -t;
-      r_bz[c] = t + dir * scale;
+      const float dir = ((attack_kind & 15) == BM_ATTACK_LITTLE) ? __builtin_sqrtf(colq / (fh - 1.0f)) : -t;
+      const float att = dir * scale;
+      r_bz[c] = (attack_kind & BM_ATTACK_DIRECTION) ? att : t + att;
     }
     if (s_avg_out != nullptr) store_result_policy<VEC>(s_avg_out + v * VEC, r_sa, nt_result);
     if (h_avg_out != nullptr) store_result_policy<VEC>(h_avg_out + v * VEC, r_ha, nt_result);
@@ -450,7 +452,7 @@ extern "C" int bm_momentum_stats(const float* const* sampled, int ks, float* con
                                  void* ws, void* stream) {
   using namespace bm;
   if (sampled == nullptr || buffers == nullptr || out6 == nullptr || ws == nullptr || h < 1 || ks < h ||
-      ks > BM_MAX_ROWS || d < 0 || (attack_kind != BM_ATTACK_EMPIRE && attack_kind != BM_ATTACK_LITTLE))
+      ks > BM_MAX_ROWS || d < 0 || ((attack_kind & ~BM_ATTACK_DIRECTION) != BM_ATTACK_EMPIRE && (attack_kind & ~BM_ATTACK_DIRECTION) != BM_ATTACK_LITTLE))
     return BM_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   StepTable tab{};

@@ -1,0 +1,74 @@
+"""The factor search of the "identical" attacks (attacks/identical.py:67-77, tools/misc.py:468-514).
+
+Host logic of libbm_gar.so (csrc/linesearch.cpp), no device work here:
+  line_maximize          the exploration routine, around any Python callable;
+  attack_objective       one evaluation of |GAR(honests + [avg + t*att]*k) - avg|^2 from scalars only,
+  attack_line_search     the whole search from scalars only
+for the rules whose output is the mean of a selected subset (krum, brute, average).  The scalars are
+the (h+2) x (h+2) squared distances among the h honest rows, their average and average + att: ONE
+distance pass instead of `evals` evaluations of the rule on d-sized vectors.
+"""
+
+import ctypes
+
+import torch
+
+from . import _lib
+
+ANALYTIC_RULES = ("krum", "brute", "average")
+
+
+def line_maximize(scape, evals=16, start=0., delta=1., ratio=0.8):
+  """tools.line_maximize (tools/misc.py:468-514): returns (best x, [(x, y) in evaluation order])."""
+  lib = _lib.load()
+  failure = []
+
+  def call(x, _ctx):
+    try:
+      return float(scape(x))
+    except BaseException as err:  # an exception cannot cross the C frame: finish the search on NaNs, then re-raise
+      failure.append(err)
+      return float("nan")
+
+  best = ctypes.c_double()
+  trace = (ctypes.c_double * (2 * evals))()
+  callback = _lib.SCAPE_FN(call)
+  rc = lib.bm_line_maximize(ctypes.cast(callback, ctypes.c_void_p), None, evals, start, delta, ratio,
+                            ctypes.cast(ctypes.pointer(best), ctypes.c_void_p), ctypes.cast(trace, ctypes.c_void_p))
+  if failure:
+    raise failure[0]
+  _lib.check(rc, "bm_line_maximize")
+  return best.value, [(trace[2 * i], trace[2 * i + 1]) for i in range(evals)]
+
+
+def _ext_pointer(ext, h):
+  if not (isinstance(ext, torch.Tensor) and ext.dtype == torch.float64 and ext.device.type == "cpu"
+          and ext.is_contiguous() and tuple(ext.shape) == (h + 2, h + 2)):
+    raise ValueError(f"ext must be a contiguous float64 CPU tensor of shape ({h + 2}, {h + 2})")
+  return ctypes.c_void_p(ext.data_ptr())
+
+
+def attack_objective(ext, h, k, f, rule, t, m=None):
+  """(objective, indices the rule averages; >= h: Byzantine copies) at attack factor t."""
+  lib = _lib.load()
+  y = ctypes.c_double()
+  sel = (ctypes.c_int32 * _lib.MAX_ROWS)()
+  count = ctypes.c_int32()
+  _lib.check(lib.bm_attack_objective(_ext_pointer(ext, h), h, k, f, _lib.RULE_IDS[rule], m or 0, float(t),
+                                     ctypes.cast(ctypes.pointer(y), ctypes.c_void_p),
+                                     ctypes.cast(sel, ctypes.c_void_p),
+                                     ctypes.cast(ctypes.pointer(count), ctypes.c_void_p)), "bm_attack_objective")
+  return y.value, list(sel[:count.value])
+
+
+def attack_line_search(ext, h, k, f, rule, evals=16, negative=False, m=None):
+  """(factor, [(x, y) in evaluation order]) of the search at identical.py:67-77 for `rule`."""
+  if rule not in ANALYTIC_RULES:
+    raise ValueError(f"no scalar form of the search for rule {rule!r}")
+  lib = _lib.load()
+  factor = ctypes.c_double()
+  trace = (ctypes.c_double * (2 * evals))()
+  _lib.check(lib.bm_attack_line_search(_ext_pointer(ext, h), h, k, f, _lib.RULE_IDS[rule], m or 0, evals,
+                                       1 if negative else 0, ctypes.cast(ctypes.pointer(factor), ctypes.c_void_p),
+                                       ctypes.cast(trace, ctypes.c_void_p)), "bm_attack_line_search")
+  return factor.value, [(trace[2 * i], trace[2 * i + 1]) for i in range(evals)]

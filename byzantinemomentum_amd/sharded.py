@@ -136,11 +136,11 @@ class HipBackend:
 
   # -- step statistics and momentum -------------------------------------------- #
 
-  def stack_stats(self, samples, scale=None, attack="empire", want_avg=True):
-    return self.stats.stack_stats_async(samples, scale=scale, attack=attack, want_avg=want_avg)
+  def stack_stats(self, samples, scale=None, attack="empire", want_avg=True, direction=False):
+    return self.stats.stack_stats_async(samples, scale=scale, attack=attack, want_avg=want_avg, direction=direction)
 
-  def momentum_stats(self, sampled, buffers, mu, omd, factors, scale, attack):
-    return self.stats.momentum_stats(sampled, buffers, mu, omd, factors, scale, attack)
+  def momentum_stats(self, sampled, buffers, mu, omd, factors, scale, attack, direction=False):
+    return self.stats.momentum_stats(sampled, buffers, mu, omd, factors, scale, attack, direction)
 
   def multi_fma3(self, outs, ps, qs, a, b, p_scale=None):
     return self.stats.multi_fma3(outs, ps, qs, a, b, p_scale)

@@ -21,12 +21,19 @@ __all__ = ["compute_avg_dev_max", "stack_stats_async", "study_dots", "multi_axpb
 _ptr = gars._ptr
 
 
-def stack_stats_async(samples, scale=None, attack="empire", want_avg=True):
+def _attack_id(attack, direction):
+  kind = _lib.ATTACK_LITTLE if attack == "little" else _lib.ATTACK_EMPIRE
+  return kind | (_lib.ATTACK_DIRECTION if direction else 0)
+
+
+def stack_stats_async(samples, scale=None, attack="empire", want_avg=True, direction=False):
   """avg vector + device tensor [sum avg^2, sum_i ||s_i-avg||^2, max|avg|] (fp64), no sync.
 
   With `scale`, also returns the Byzantine vector of an "identical" attack computed in the same pass
   (third element of the tuple): attack="empire" -> avg + scale*(-avg); attack="little" ->
   avg + scale*sqrt(unbiased column variance) (attacks/identical.py:63-86,129-141).
+  direction=True: the third element is scale * (attack direction) alone, without the average
+  (`grad_att` of identical.py:65, what the factor search combines with the average).
   """
   k, d, device = gars._validate(samples)
   lib = _lib.load()
@@ -38,7 +45,7 @@ def stack_stats_async(samples, scale=None, attack="empire", want_avg=True):
     _lib.check(lib.bm_stack_stats(_lib.pointer_table(samples), k, d, _ptr(avg) if avg is not None else None,
                                   _ptr(scaled) if scaled is not None else None,
                                   ctypes.c_float(scale if scale is not None else 0.0),
-                                  _lib.ATTACK_LITTLE if attack == "little" else _lib.ATTACK_EMPIRE, _ptr(out3),
+                                  _attack_id(attack, direction), _ptr(out3),
                                   _ptr(ws), gars._stream(device)), "bm_stack_stats")
   if scale is not None:
     return avg, out3, scaled
@@ -104,7 +111,8 @@ def multi_axpby(ys, xs, a, b):
                "bm_multi_axpby")
 
 
-def momentum_stats(sampled, buffers, mu, one_minus_damp, clip_factors_dev=None, attack_scale=None, attack="empire"):
+def momentum_stats(sampled, buffers, mu, one_minus_damp, clip_factors_dev=None, attack_scale=None, attack="empire",
+                   direction=False):
   """First pass of a step in one kernel (attack.py:791-804,846-847 and attacks/identical.py:63-86):
   worker momentum in place on `buffers` (which then ARE the honest gradients), statistics of the
   sampled stack and of the honest stack, and the Byzantine vector of an "identical" attack.
@@ -130,7 +138,7 @@ def momentum_stats(sampled, buffers, mu, one_minus_damp, clip_factors_dev=None, 
       ctypes.c_float(one_minus_damp), _ptr(clip_factors_dev) if clip_factors_dev is not None else None,
       _ptr(s_avg), _ptr(h_avg), _ptr(byz) if byz is not None else None,
       ctypes.c_float(attack_scale if attack_scale is not None else 0.0),
-      _lib.ATTACK_LITTLE if attack == "little" else _lib.ATTACK_EMPIRE, _ptr(out6), _ptr(ws),
+      _attack_id(attack, direction), _ptr(out6), _ptr(ws),
       gars._stream(device)), "bm_momentum_stats")
   return s_avg, h_avg, byz, out6
 

@@ -6,6 +6,8 @@ Given the sampled honest gradients of a step it performs, without leaving the GP
                                    server: hon_i  = (1-damp)*g_i + mu*M                attack.py:805-808
                                    update / none: hon_i = g_i                          attack.py:809-810
   2. the "empire" / "little" attack  byz = avg_h + factor*dir, repeated f_real times   attacks/identical.py:63-86,129-141
+                                   factor fixed, or searched within `attack_evals` evaluations of
+                                   |GAR(honests + [avg_h + t*dir]*f) - avg_h|^2         attacks/identical.py:67-77
   3. the aggregation rule          defense = GAR(honests + [byz]*f, f)                 attack.py:821
   4. the momentum of the update    server: M <- defense; update: M <- mu*M + (1-damp)*defense   attack.py:832-839
   5. the study statistics          sampled / honest / attack stacks, defense norm and max, six cosines,
@@ -19,7 +21,9 @@ step (row norms if clipping, the n x n squared distances if the rule needs them,
 vector of every statistic), never a d-sized one.  With one rank no collective is issued.
 The model update itself (optimizer step) belongs to the caller: `update_gradient()` returns what
 attack.py hands to `model.update`.  Everything is asynchronous on the current stream until
-`floats()` fetches the scalars (one sync).
+`floats()` fetches the scalars (one sync) — except for the factor search, sequential by nature: one
+synchronisation per evaluation, or ONE for the whole search when the rule is krum, brute or average
+(linesearch.py: every evaluation is then a function of (h+2)^2 scalars of one distance pass).
 """
 
 import collections
@@ -37,18 +41,28 @@ MAX_PAST = 4096  # past sampled averages kept for the curvature term (each is on
 class AggregationStep:
   def __init__(self, nb_workers, nb_decl_byz, nb_real_byz, gar="krum", gar_args=None, momentum=0.99,
                dampening=0.99, momentum_at="worker", attack="empire", attack_factor=1.1, nb_past=25,
-               gradient_clip=None, aggregator=None, single_call=True):
+               gradient_clip=None, aggregator=None, single_call=True, attack_evals=None, attack_negative=False,
+               line_search="auto"):
     """aggregator: a sharded.ShardedAggregator (default: one over the default process group, or a
     single-rank one when torch.distributed is not initialised).
     single_call: with the HIP backend, worker-side momentum and a rule the C entry point knows
     (krum, bulyan, median, trmean, phocas, meamed), run() is ONE call into libbm_gar.so (bm_step_worker),
-    collectives included; False keeps the kernel-by-kernel Python sequence (same kernels, same results)."""
+    collectives included; False keeps the kernel-by-kernel Python sequence (same kernels, same results).
+    attack_evals: None = the fixed `attack_factor`; a positive integer E = the reference's `factor:-E` (its
+    default is -16): the factor is searched each step with tools.line_maximize's exploration
+    (identical.py:67-77), `attack_negative` being the attack's `negative` argument during the search.
+    line_search: "auto" evaluates the search from scalars when the rule allows it (krum, brute, average),
+    "generic" always runs the rule on the device once per evaluation like the reference does."""
     if gar not in _RULES:
       raise ValueError(f"unknown aggregation rule {gar!r}")
     if momentum_at not in ("worker", "server", "update"):
       raise ValueError(f"momentum_at must be 'worker', 'server' or 'update', got {momentum_at!r}")
     if attack not in ("empire", "little"):
       raise ValueError(f"unknown attack {attack!r} (empire: factor, little: factor, use a negative one for negative:True)")
+    if attack_evals is not None and (not isinstance(attack_evals, int) or attack_evals < 1):
+      raise ValueError(f"attack_evals must be a positive number of evaluations, got {attack_evals!r}")
+    if line_search not in ("auto", "generic"):
+      raise ValueError(f"line_search must be 'auto' or 'generic', got {line_search!r}")
     if not 0 <= nb_past <= MAX_PAST:
       raise ValueError(f"nb_past must be within 0..{MAX_PAST}")
     if aggregator is None:
@@ -68,6 +82,11 @@ class AggregationStep:
     self.attack = attack
     self.factor = attack_factor
     self.clip = gradient_clip
+    self.attack_evals = attack_evals
+    self.attack_negative = bool(attack_negative)
+    self.line_search = line_search
+    self.last_factor = attack_factor  # the factor of the last step (the searched one with attack_evals)
+    self.last_search = None           # [(x, objective)] of the last search, in evaluation order
     self.buffers = None        # worker placement: one momentum buffer per honest worker (attack.py:676)
     self.server_momentum = None  # server / update placements: grad_momentum_server (attack.py:678)
     self.pasts = collections.deque(maxlen=max(nb_past, 1))  # past sampled averages, newest first (attack.py:868)
@@ -81,7 +100,8 @@ class AggregationStep:
     self._update = None
     self._prev_stats = None    # single-call form: the previous step's reduced statistics (slot 0 = ||avg_s||^2)
     extra_args = set(self.gar_args) - {"m"}
-    self.single_call = bool(single_call and momentum_at == "worker" and hasattr(self.ops, "step_worker")
+    self.single_call = bool(single_call and attack_evals is None and momentum_at == "worker"
+                            and hasattr(self.ops, "step_worker")
                             and gar in ("krum", "bulyan", "median", "trmean", "phocas", "meamed") and not extra_args
                             and (not self.agg.collective or self.agg.native is not None))
 
@@ -94,6 +114,34 @@ class AggregationStep:
     if self.gar == "average":
       return agg.average(gradients)
     return getattr(agg, self.gar)(gradients, f, **self.gar_args)
+
+  def _search_factor(self, honests, h_avg, direction):
+    """attacks/identical.py:67-77: the factor maximising |GAR(honests + [avg + t*dir]*f_real) - avg|^2 under
+    the evaluation budget.  Like the reference, `negative` flips the sign of the candidates DURING the
+    search only; the factor returned (and then applied) is the positive abscissa the search settled on."""
+    from . import linesearch
+    ops, agg, h, k = self.ops, self.agg, self.h, self.f_real
+    if self.line_search == "auto" and self.gar in linesearch.ANALYTIC_RULES and h + 2 <= 64 and \
+       not (set(self.gar_args) - {"m"}):
+      unit = torch.empty_like(h_avg)
+      ops.multi_fma3([unit], [h_avg], [direction], 1.0, 1.0)   # avg + dir: the candidate of factor 1
+      ext = agg.global_sqdist(list(honests) + [h_avg, unit]).cpu().contiguous()  # the search's only synchronisation
+      factor, self.last_search = linesearch.attack_line_search(
+        ext, h, k, self.f_decl, self.gar, evals=self.attack_evals, negative=self.attack_negative,
+        m=self.gar_args.get("m"))
+      return factor
+
+    def scape(x):
+      t = -x if self.attack_negative else x
+      cand = torch.empty_like(h_avg)
+      ops.multi_fma3([cand], [h_avg], [direction], 1.0, t)
+      out = self._aggregate(list(honests) + [cand] * k)
+      sq = ops.pairwise_sqdist([out, h_avg])[0, 1].reshape(1)  # aggregated.sub_(grad_avg); dot with itself
+      agg.all_reduce_sum(sq)
+      return sq.item()
+
+    factor, self.last_search = linesearch.line_maximize(scape, evals=self.attack_evals)
+    return factor
 
   def nesterov_lookahead(self, params, lr, worker=None):
     """params <- params - mu*lr*momentum in place (attack.py:760-767): the parameter shift before
@@ -126,7 +174,11 @@ class AggregationStep:
     if self.momentum_at == "worker":
       if self.buffers is None:
         self.buffers = [torch.zeros_like(g) for g in sampled[:h]]
-      s_avg, h_avg, byz, out6 = ops.momentum_stats(sampled, self.buffers, self.mu, omd, factors, self.factor, self.attack)
+      if self.attack_evals is None:
+        s_avg, h_avg, byz, out6 = ops.momentum_stats(sampled, self.buffers, self.mu, omd, factors, self.factor, self.attack)
+      else:  # the attack direction alone; the Byzantine vector follows the factor search
+        s_avg, h_avg, byz, out6 = ops.momentum_stats(sampled, self.buffers, self.mu, omd, factors, 1.0, self.attack,
+                                                     direction=True)
       honests = self.buffers
       s_out3, h_out3 = out6[:3], out6[3:]
     else:
@@ -142,8 +194,16 @@ class AggregationStep:
         ops.multi_fma3(honests, sampled[:h], [zero] * h, omd, self.mu)
       else:
         honests = sampled[:h]
-      h_avg, h_out3, byz = ops.stack_stats(honests, scale=self.factor, attack=self.attack)
+      if self.attack_evals is None:
+        h_avg, h_out3, byz = ops.stack_stats(honests, scale=self.factor, attack=self.attack)
+      else:
+        h_avg, h_out3, byz = ops.stack_stats(honests, scale=1.0, attack=self.attack, direction=True)
       s_avg, s_out3 = ops.stack_stats(sampled)
+    if self.attack_evals is not None and self.f_real > 0:
+      direction = byz
+      self.last_factor = self._search_factor(honests, h_avg, direction)
+      byz = torch.empty_like(h_avg)  # grad_att.mul_(factor); byz_grad = grad_avg.add_(grad_att)  (identical.py:82-84)
+      ops.multi_fma3([byz], [h_avg], [direction], 1.0, self.last_factor)
     attacks = [byz] * self.f_real
     # 3. aggregation
     defense = self._aggregate(honests + attacks)

@@ -113,7 +113,10 @@ int bm_aksel_pass1(const float* const* rows, int n, int64_t d, float* median_out
  *   BM_ATTACK_EMPIRE  avg + scale * (-avg)                         attacks/identical.py:129-134
  *   BM_ATTACK_LITTLE  avg + scale * sqrt(var_unbiased over rows)   attacks/identical.py:136-141
  *                     (pass a negative scale for the reference's `negative:True`) */
-enum bm_attack_kind { BM_ATTACK_EMPIRE = 0, BM_ATTACK_LITTLE = 1 };
+enum bm_attack_kind { BM_ATTACK_EMPIRE = 0, BM_ATTACK_LITTLE = 1,
+                      /* OR-ed in: scaled_out = scale * direction only, without the average (what the factor
+                       * search of attacks/identical.py:67-77 keeps as `grad_att`)                             */
+                      BM_ATTACK_DIRECTION = 16 };
 int bm_stack_stats(const float* const* rows, int k, int64_t d, float* avg_out,
                    float* scaled_out, float scale, int attack_kind, double* out3, void* ws,
                    void* stream);
@@ -216,7 +219,8 @@ int bm_sharded_bulyan(bm_comm* comm, const float* const* rows, int n, int64_t d_
  * past_oldest non-NULL only when the caller's ring of nb_past vectors is full (its last entry).
  */
 enum bm_step_rule { BM_RULE_KRUM = 0, BM_RULE_BULYAN = 1, BM_RULE_MEDIAN = 2, BM_RULE_TRMEAN = 3,
-                    BM_RULE_PHOCAS = 4, BM_RULE_MEAMED = 5 };
+                    BM_RULE_PHOCAS = 4, BM_RULE_MEAMED = 5,
+                    BM_RULE_BRUTE = 6, BM_RULE_AVERAGE = 7 /* bm_attack_* only, not bm_step_worker */ };
 typedef struct bm_step_params {
   int32_t n, f_decl, f_real;  /* workers, declared and real Byzantine ones; honest = n - f_real      */
   int32_t ks;                 /* sampled gradients (>= honest)                                        */
@@ -236,6 +240,29 @@ int bm_step_worker(bm_comm* comm, const bm_step_params* p, const float* const* s
                    int64_t d, float* defense_out, float* sampled_avg_out, float* honest_avg_out, float* byz_out,
                    float* attack_avg_out, const float* past_newest, float* curv, const float* past_oldest,
                    const float* params, const float* origin, double* stats_out, void* ws, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The factor search of the "identical" attacks (attacks/identical.py:67-77, the reference's default
+ * factor=-16) — HOST functions, no stream.
+ *
+ * bm_line_maximize: tools/misc.py:468-514, best-effort arg-max over x >= 0 of scape(x, ctx) within
+ * `evals` evaluations (reference defaults: start 0, delta 1, ratio 0.8).  trace_out: NULL or 2*evals
+ * doubles receiving the (x, y) pairs in evaluation order.
+ *
+ * bm_attack_objective / bm_attack_line_search: for a rule whose output is the mean of a selected subset
+ * (BM_RULE_KRUM with m, BM_RULE_BRUTE, BM_RULE_AVERAGE), the objective |GAR(honests + [avg + t*att]*k, f)
+ * - avg|^2 of identical.py:72-76 evaluated from scalars only.  ext: HOST row-major (h+2) x (h+2) squared
+ * distances (bm_pairwise_sqdist) among the h honest rows, their average and average + att.
+ * sel_out (may be NULL): the rows the rule averages, indices >= h being Byzantine copies; count_out
+ * their number.  bm_attack_line_search runs the whole search (negative: identical.py:70-71) and returns
+ * the factor the attack then uses.  No d-sized vector is touched: 16 evaluations cost microseconds. */
+typedef double (*bm_scape_fn)(double x, void* ctx);
+int bm_line_maximize(bm_scape_fn scape, void* ctx, int evals, double start, double delta, double ratio,
+                     double* best_x_out, double* trace_out);
+int bm_attack_objective(const double* ext, int h, int k, int f, int rule, int m, double t, double* y_out,
+                        int32_t* sel_out, int32_t* count_out);
+int bm_attack_line_search(const double* ext, int h, int k, int f, int rule, int m, int evals, int negative,
+                          double* factor_out, double* trace_out);
 
 #ifdef __cplusplus
 }

@@ -358,6 +358,79 @@ def worker_momentum(buffers, grads, mu, dampening):
 
 
 # ---------------------------------------------------------------------------- #
+# The "identical" attacks with their factor search (attacks/identical.py:45-86, tools/misc.py:468-514)
+
+def line_maximize(scape, evals=16, start=0., delta=1., ratio=0.8):
+  """Restatement of tools.line_maximize (tools/misc.py:468-514) as an explicit two-state machine.
+  Returns (best x, [(x, y) in evaluation order]).  Expanding: candidates best+delta, delta doubling while
+  the value strictly improves; the first failure shrinks delta by `ratio` and switches to contracting:
+  the candidate moves towards (and past) the best point by a delta that shrinks after every evaluation,
+  bounced back into x >= 0 by halving the overshoot."""
+  trace = []
+
+  def value(x):
+    y = scape(x)
+    trace.append((x, y))
+    return y
+
+  best = (start, value(start))
+  cand = None
+  expanding = True
+  for _ in range(evals - 1):
+    if expanding:
+      cand = best[0] + delta
+    elif cand < best[0]:
+      cand = cand + delta
+    else:
+      x = cand - delta
+      while x < 0:
+        x = (x + cand) / 2
+      cand = x
+    y = value(cand)
+    improved = y > best[1]
+    if improved:
+      best = (cand, y)
+    if expanding:
+      if improved:
+        delta *= 2
+      else:
+        delta *= ratio
+        expanding = False
+    else:
+      delta *= ratio
+  return best[0], trace
+
+
+def identical_attack(honests, f_real, f_decl, defense, kind="empire", factor=-16, negative=False, precision="f32"):
+  """attacks/identical.py:45-86 for kind "empire" (:129-134) / "little" (:136-141).  defense(gradients, f) ->
+  aggregated vector.  Returns (list of f_real aliases of the Byzantine vector, factor used, search trace or None).
+  precision "f64": the search's objective is taken in float64 (the vectors stay the reference's fp32 ones)."""
+  if f_real == 0:
+    return [], None, None
+  stck = torch.stack(honests)
+  avg = stck.mean(dim=0)
+  att = avg.neg() if kind == "empire" else stck.var(dim=0).sqrt_()
+  trace = None
+  if factor < 0:
+    def scape(x):
+      if negative:
+        x = -x
+      cand = avg + x * att
+      out = defense(list(honests) + [cand] * f_real, f_decl)
+      if precision == "f32":
+        out = out.sub(avg)
+        return out.dot(out).item()
+      diff = out.double() - avg.double()
+      return diff.dot(diff).item()
+    factor, trace = line_maximize(scape, evals=math.ceil(-factor))
+  elif negative:
+    factor = -factor
+  att.mul_(factor)
+  byz = avg.add(att)
+  return [byz] * f_real, factor, trace
+
+
+# ---------------------------------------------------------------------------- #
 # Synthetic gradient stacks (SURVEY.md §8d)
 
 def make_stack(kind, n, f, d, seed, device="cpu", dtype=torch.float32):

@@ -95,13 +95,13 @@ class OracleBackend:
                         dtype=torch.float64)
 
   @staticmethod
-  def _byz(samples, avg, scale, attack):
+  def _byz(samples, avg, scale, attack, direction=False):
     if attack == "empire":
       att = avg.neg()
     else:
       att = torch.stack(samples).var(dim=0).sqrt_() if avg.numel() else avg.clone()
     att.mul_(scale)
-    return avg.add(att)
+    return att if direction else avg.add(att)
 
   @staticmethod
   def _seq_mean(samples):
@@ -110,14 +110,14 @@ class OracleBackend:
       avg.add_(t)
     return avg.div_(len(samples))
 
-  def stack_stats(self, samples, scale=None, attack="empire", want_avg=True):
+  def stack_stats(self, samples, scale=None, attack="empire", want_avg=True, direction=False):
     avg = self._seq_mean(samples)
     out3 = self._out3(samples, avg)
     if scale is not None:
-      return avg, out3, self._byz(samples, avg, scale, attack)
+      return avg, out3, self._byz(samples, avg, scale, attack, direction)
     return avg, out3
 
-  def momentum_stats(self, sampled, buffers, mu, omd, factors, scale, attack):
+  def momentum_stats(self, sampled, buffers, mu, omd, factors, scale, attack, direction=False):
     ks, h = len(sampled), len(buffers)
     clipped = [g * factors[i] if factors is not None else g for i, g in enumerate(sampled)]
     for buf, g in zip(buffers, clipped[:h]):
@@ -125,7 +125,7 @@ class OracleBackend:
     s_avg = self._seq_mean(clipped)
     h_avg = self._seq_mean(list(buffers))
     out6 = torch.cat([self._out3(clipped, s_avg), self._out3(list(buffers), h_avg)])
-    byz = self._byz(list(buffers), h_avg, scale, attack) if scale is not None else None
+    byz = self._byz(list(buffers), h_avg, scale, attack, direction) if scale is not None else None
     return s_avg, h_avg, byz, out6
 
   def multi_fma3(self, outs, ps, qs, a, b, p_scale=None):

@@ -20,10 +20,12 @@ RULES = {"krum": O.krum, "bulyan": O.bulyan, "trmean": O.trmean, "phocas": O.pho
 
 class ReferenceLoop:
   def __init__(self, n, f_decl, f_real, gar, momentum_at="worker", mu=0.9, damp=0.9, attack="empire", factor=1.1,
-               clip=None, nb_past=3, gar_args=None, precision="f64"):
+               clip=None, nb_past=3, gar_args=None, precision="f64", evals=None, negative=False):
     """precision: arithmetic of the norm-type floats ("f64" ground truth; "f32" = the reference's own fp32
     operations, bit-faithful: what tests/test_step_reference_vs_reference.py pins against the real loop body)."""
     self.precision = precision
+    self.evals, self.negative = evals, negative  # evals = E: the attack's `factor:-E` (search), identical.py:67-77
+    self.last_factor, self.last_search = None, None
     self.n, self.f_decl, self.f_real, self.gar = n, f_decl, f_real, gar
     self.h = n - f_real
     self.momentum_at, self.mu, self.damp = momentum_at, mu, damp
@@ -54,19 +56,24 @@ class ReferenceLoop:
     else:
       honests = sampled[:h]
     # attacks/identical.py:63-86,129-141
-    stck = torch.stack(honests)
-    avg = stck.mean(dim=0)
-    att = avg.neg() if self.attack == "empire" else stck.var(dim=0).sqrt_()
-    att.mul_(self.factor)
-    byz = avg.add(att)
-    attacks = [byz] * self.f_real
-    grads = list(honests) + attacks
-    if self.gar == "median":
-      defense = O.median(grads)
-    elif self.gar == "average":
-      defense = O.average(grads)
+    def rule(grads, f):
+      if self.gar == "median":
+        return O.median(grads)
+      if self.gar == "average":
+        return O.average(grads)
+      return RULES[self.gar](grads, f, **self.gar_args)
+    if self.evals is None:
+      stck = torch.stack(honests)
+      avg = stck.mean(dim=0)
+      att = avg.neg() if self.attack == "empire" else stck.var(dim=0).sqrt_()
+      att.mul_(self.factor)
+      byz = avg.add(att)
+      attacks = [byz] * self.f_real
     else:
-      defense = RULES[self.gar](grads, self.f_decl, **self.gar_args)
+      attacks, self.last_factor, self.last_search = O.identical_attack(
+        honests, self.f_real, self.f_decl, rule, self.attack, -self.evals, self.negative, self.precision)
+    grads = list(honests) + attacks
+    defense = rule(grads, self.f_decl)
     if params is None:
       l2 = math.nan
     elif self.precision == "f32":

@@ -411,6 +411,78 @@ def test_step_all_placements_against_reference_loop(bm, cfg):
     params = params - 0.05 * want_upd
 
 
+# The factor search of the attacks (attacks/identical.py:67-77; the reference's default is factor=-16):
+# scalar form (one distance pass over h+2 rows, then host only) and per-evaluation form
+SEARCH_CONFIGS = [
+  dict(gar="krum", momentum_at="worker", clip=None, attack="empire", evals=16),
+  dict(gar="krum", momentum_at="worker", clip=None, attack="little", evals=16, line_search="generic"),
+  dict(gar="krum", momentum_at="server", clip=100.0, attack="little", evals=9, negative=True),
+  dict(gar="brute", momentum_at="update", clip=None, attack="little", evals=8),
+  dict(gar="average", momentum_at="worker", clip=None, attack="empire", evals=5, negative=True),
+  dict(gar="median", momentum_at="update", clip=None, attack="empire", evals=16),
+  dict(gar="bulyan", momentum_at="server", clip=None, attack="little", evals=6),
+  dict(gar="trmean", momentum_at="worker", clip=None, attack="little", evals=7),
+]
+
+
+@pytest.mark.parametrize("cfg", SEARCH_CONFIGS, ids=lambda c: f"{c['gar']}-{c['momentum_at']}-{c['attack']}-search{c['evals']}"
+                                                              f"{'neg' if c.get('negative') else ''}-{c.get('line_search', 'auto')}")
+def test_step_with_factor_search_against_reference_loop(bm, cfg):
+  from byzantinemomentum_amd.step import AggregationStep
+  from tests.step_reference import ReferenceLoop, assert_floats_close
+  n, f, d = 11, 2, 30011
+  h = n - f
+  step = AggregationStep(n, f, f, gar=cfg["gar"], momentum=0.9, dampening=0.9, momentum_at=cfg["momentum_at"],
+                         attack=cfg["attack"], nb_past=3, gradient_clip=cfg["clip"], attack_evals=cfg["evals"],
+                         attack_negative=cfg.get("negative", False), line_search=cfg.get("line_search", "auto"))
+  assert not step.single_call
+  ref = ReferenceLoop(n, f, f, cfg["gar"], cfg["momentum_at"], 0.9, 0.9, cfg["attack"], 1.1, cfg["clip"], 3,
+                      evals=cfg["evals"], negative=cfg.get("negative", False))
+  gen = torch.Generator().manual_seed(321)
+  origin = torch.randn(d, generator=gen)
+  params = origin.clone()
+  for it in range(3):
+    base = 0.2 * torch.randn(d, generator=gen)
+    sampled = [base + (0.5 + 0.1 * i) * torch.randn(d, generator=gen) for i in range(h)]
+    want_def, want_upd, want = ref.step(sampled, params, origin)
+    got_def = step.run([g.to(DEV) for g in sampled], params.to(DEV), origin.to(DEV))
+    got_search, want_search = step.last_search, ref.last_search
+    assert len(got_search) == len(want_search) == cfg["evals"]
+    # an objective that is zero up to rounding (the rule returned the honest mean): the scalar form gets it from a
+    # cancellation among h^2 inner products, so the absolute floor is relative to the spread of the honest rows
+    floor = 1e-8 * sum(v * v for v in [want["honest_norm_dev"]]) * h
+    # the same candidates in the same order, the same objective at each: the same decisions, the same factor
+    for (x, y), (xo, yo) in zip(got_search, want_search):
+      assert x == xo and abs(y - yo) <= 2e-5 * abs(yo) + floor, (cfg, it, x, y, yo)
+    assert step.last_factor == ref.last_factor, (cfg, it)
+    scale = float(torch.stack(sampled).abs().max()) * max(1.0, abs(ref.last_factor))
+    assert float((got_def.cpu() - want_def).abs().max()) <= 4e-6 * scale, (cfg, it)
+    assert_floats_close(step.floats(), want, tag=(cfg["gar"], it), tol=1e-5)
+    params = params - 0.05 * want_upd
+
+
+def test_attack_direction_output(bm):
+  """BM_ATTACK_DIRECTION: the attack direction alone (grad_att of identical.py:65) from bm_stack_stats and both
+  forms of bm_momentum_stats, bit-identical to byz - avg being rebuilt the reference's way."""
+  gen = torch.Generator().manual_seed(17)
+  for h, d in ((7, 4099), (20, 30011), (39, 5003)):
+    rows = [torch.randn(d, generator=gen) for _ in range(h)]
+    for attack in ("empire", "little"):
+      dev = [g.to(DEV) for g in rows]
+      avg, _, direction = bm.stats.stack_stats_async(dev, scale=1.0, attack=attack, direction=True)
+      _, _, byz = bm.stats.stack_stats_async(dev, scale=1.0, attack=attack)
+      assert same_bits(byz, avg.cpu() + direction.cpu())
+      stck = torch.stack(rows)
+      want = stck.mean(dim=0).neg() if attack == "empire" else stck.var(dim=0).sqrt_()
+      assert float((direction.cpu() - want).abs().max()) <= 4e-6 * float(want.abs().max())
+      bufs = [torch.zeros(d, device=DEV) for _ in range(h)]
+      _, h_avg, direction2, _ = bm.stats.momentum_stats(dev, bufs, 0.0, 1.0, None, 1.0, attack, direction=True)
+      assert float((direction2.cpu() - want).abs().max()) <= 4e-6 * float(want.abs().max())
+      bufs = [torch.zeros(d, device=DEV) for _ in range(h)]
+      _, h_avg2, byz2, _ = bm.stats.momentum_stats(dev, bufs, 0.0, 1.0, None, 1.0, attack)
+      assert same_bits(byz2, h_avg2.cpu() + direction2.cpu())
+
+
 def test_momentum_stats_kernel_tiers(bm):
   """bm_momentum_stats for row counts in every register tier (<= 8, 12, 20, 40, 64), odd lengths,
   ks > h, clipping factors, both attacks; bit-exact momentum, averages and Byzantine vector."""
@@ -452,7 +524,7 @@ def test_momentum_stats_other_form():
   other = "1" if os.environ.get("BM_STEP_STREAM", "0") != "1" else "0"
   env = dict(os.environ, BM_STEP_STREAM=other, PYTHONPATH=ROOT)
   out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity_r2.py"), "-q", "-x",
-                        "-m", "gpu", "-k", "test_momentum_stats_kernel_tiers or test_step_all_placements"],
+                        "-m", "gpu", "-k", "test_momentum_stats_kernel_tiers or test_step_all_placements or test_attack_direction_output"],
                        capture_output=True, text=True, env=env, cwd=ROOT, timeout=1200)
   assert out.returncode == 0, (out.stdout[-3000:], out.stderr[-2000:])
 

@@ -36,6 +36,46 @@ CONFIGS = [
 ]
 
 
+# the factor search of the attacks (identical.py:67-77): evals = E is the reference's `factor:-E`
+SEARCH_CONFIGS = [
+  dict(gar="krum", momentum_at="worker", clip=None, attack="empire", factor=1.1, evals=16),
+  dict(gar="krum", momentum_at="worker", clip=None, attack="little", factor=1.1, evals=16, line_search="generic"),
+  dict(gar="krum", momentum_at="server", clip=30.0, attack="little", factor=1.1, evals=9, negative=True),
+  dict(gar="brute", momentum_at="update", clip=None, attack="little", factor=1.1, evals=8),
+  dict(gar="average", momentum_at="worker", clip=None, attack="empire", factor=1.1, evals=5, negative=True),
+  dict(gar="median", momentum_at="update", clip=None, attack="empire", factor=1.1, evals=16),
+  dict(gar="bulyan", momentum_at="server", clip=None, attack="little", factor=1.1, evals=6),
+  dict(gar="trmean", momentum_at="worker", clip=None, attack="empire", factor=1.1, evals=1),
+]
+
+
+def config_id(c):
+  tag = f"{c['gar']}-{c['momentum_at']}-clip{c['clip']}-{c['attack']}"
+  if "evals" in c:
+    tag += f"-search{c['evals']}{'neg' if c.get('negative') else ''}-{c.get('line_search', 'auto')}"
+  return tag
+
+
+def reference_for(cfg, n=N, f=F):
+  return ReferenceLoop(n, f, f, cfg["gar"], cfg["momentum_at"], 0.9, 0.9, cfg["attack"], cfg["factor"], cfg["clip"], 3,
+                       evals=cfg.get("evals"), negative=cfg.get("negative", False))
+
+
+def assert_same_search(step, ref, tag):
+  """Same factor, or a tie: the objective values the two searches hold at their factors agree within 1e-5
+  (a comparison between two candidates that close is decided by rounding in the reference as well)."""
+  got, want = step.last_search, ref.last_search
+  assert len(got) == len(want), tag
+  floor = 1e-9 * max(y for _, y in want)  # an objective that is zero up to rounding (the rule returned the honest mean)
+  if step.last_factor == ref.last_factor:
+    for (x, y), (xo, yo) in zip(got, want):
+      assert x == xo and abs(y - yo) <= 1e-5 * abs(yo) + floor, (tag, x, y, yo)
+    return
+  best_got = max(y for _, y in got)
+  best_want = max(y for _, y in want)
+  assert abs(best_got - best_want) <= 1e-5 * max(abs(best_want), 1e-9), (tag, step.last_factor, ref.last_factor)
+
+
 def make_step(cfg, aggregator=None, n=N, f=F):
   from byzantinemomentum_amd.sharded import ShardedAggregator
   from byzantinemomentum_amd.step import AggregationStep
@@ -43,16 +83,17 @@ def make_step(cfg, aggregator=None, n=N, f=F):
   agg = aggregator or ShardedAggregator(backend=OracleBackend())
   return AggregationStep(n, f, f, gar=cfg["gar"], momentum=0.9, dampening=0.9, momentum_at=cfg["momentum_at"],
                          attack=cfg["attack"], attack_factor=cfg["factor"], nb_past=3, gradient_clip=cfg["clip"],
-                         aggregator=agg)
+                         aggregator=agg, attack_evals=cfg.get("evals"), attack_negative=cfg.get("negative", False),
+                         line_search=cfg.get("line_search", "auto"))
 
 
-@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: f"{c['gar']}-{c['momentum_at']}-clip{c['clip']}-{c['attack']}")
+@pytest.mark.parametrize("cfg", CONFIGS + SEARCH_CONFIGS, ids=config_id)
 def test_step_matches_reference_loop(cfg):
   assert not dist.is_initialized()
   h = N - F
   n = N
   step = make_step(cfg)
-  ref = ReferenceLoop(n, F, F, cfg["gar"], cfg["momentum_at"], 0.9, 0.9, cfg["attack"], cfg["factor"], cfg["clip"], 3)
+  ref = reference_for(cfg)
   gen = torch.Generator().manual_seed(5)
   origin = torch.randn(D, generator=gen)
   params = origin.clone()
@@ -60,6 +101,10 @@ def test_step_matches_reference_loop(cfg):
     sampled = sampled_for_step(it, h, extra=(1 if it == 2 else 0))  # one step with a gradient sampled only for the study
     want_def, want_upd, want = ref.step(sampled, params, origin)
     got_def = step.run([g.clone() for g in sampled], params, origin)
+    if "evals" in cfg:
+      assert_same_search(step, ref, (config_id(cfg), it))
+      if step.last_factor != ref.last_factor:
+        pytest.skip("the two searches settled on tied candidates")  # (never hit with these seeds)
     if it == 1:
       step.run  # noqa: B018  (floats() is skipped on this step: the past deque must still advance)
     else:
@@ -83,6 +128,10 @@ def test_step_rejects_bad_arguments():
     AggregationStep(11, 2, 2, momentum_at="client", aggregator=agg)
   with pytest.raises(ValueError):
     AggregationStep(11, 2, 2, nb_past=MAX_PAST + 1, aggregator=agg)
+  with pytest.raises(ValueError):
+    AggregationStep(11, 2, 2, attack_evals=0, aggregator=agg)
+  with pytest.raises(ValueError):
+    AggregationStep(11, 2, 2, attack_evals=4, line_search="fast", aggregator=agg)
   step = AggregationStep(11, 2, 2, aggregator=agg)
   with pytest.raises(ValueError):
     step.run([torch.zeros(8)] * 3)
@@ -99,6 +148,9 @@ def _free_port():
     return s.getsockname()[1]
 
 
+SHARDED_CONFIGS = CONFIGS[:6] + [SEARCH_CONFIGS[0], SEARCH_CONFIGS[5]]  # + the search, scalar and per-evaluation forms
+
+
 def _worker(rank, world, port, d, queue):
   os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
   dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -107,7 +159,7 @@ def _worker(rank, world, port, d, queue):
     from tests.sharded_backend import OracleBackend
     lo, hi = shard_bounds(d, world, rank)
     out = {}
-    for ci, cfg in enumerate(CONFIGS[:6]):
+    for ci, cfg in enumerate(SHARDED_CONFIGS):
       agg = ShardedAggregator(backend=OracleBackend())
       assert agg.world_size == world and agg.collective
       step = make_step(cfg, agg)
@@ -140,7 +192,7 @@ def test_sharded_step_matches_single_rank(world, d):
   for p in procs:
     p.join(timeout=60)
     assert p.exitcode == 0
-  for ci, cfg in enumerate(CONFIGS[:6]):
+  for ci, cfg in enumerate(SHARDED_CONFIGS):
     single = make_step(cfg)
     gen = torch.Generator().manual_seed(5)
     origin = torch.randn(d, generator=gen)

@@ -53,9 +53,12 @@ def real_loop_body(ref, state, sampled, cfg, params, origin):
     grad_honests = grad_sampleds[:h]
   defense = aggregators.gars[cfg["gar"]]
   attack = attacks.attacks[cfg["attack"]]
-  extra = {"negative": True} if cfg["factor"] < 0 else {}
+  if "evals" in cfg:  # the attack's own default form: factor = -E searches the factor within E evaluations
+    factor, extra = -cfg["evals"], {"negative": cfg.get("negative", False)}
+  else:
+    factor, extra = abs(cfg["factor"]), ({"negative": True} if cfg["factor"] < 0 else {})
   grad_attacks = attack.unchecked(grad_honests=grad_honests, f_decl=F, f_real=F, model=None, defense=defense,
-                                  factor=abs(cfg["factor"]), **extra)      # attack.py:819
+                                  factor=factor, **extra)                 # attack.py:819
   grad_defense = defense.unchecked(gradients=(grad_honests + grad_attacks), f=F, model=None)   # attack.py:821
   l2_origin = params.sub(origin).norm().item()                           # attack.py:830
   if cfg["momentum_at"] == "server":                                      # attack.py:832-839
@@ -100,10 +103,15 @@ CONFIGS = [
   dict(gar="median", momentum_at="update", clip=26.0, attack="empire", factor=1.1),
   dict(gar="trmean", momentum_at="worker", clip=None, attack="little", factor=-1.5),
   dict(gar="aksel", momentum_at="server", clip=None, attack="empire", factor=1.1),
+  dict(gar="krum", momentum_at="worker", clip=None, attack="empire", factor=1.1, evals=16),
+  dict(gar="krum", momentum_at="server", clip=None, attack="little", factor=1.1, evals=9, negative=True),
+  dict(gar="median", momentum_at="update", clip=None, attack="little", factor=1.1, evals=16),
+  dict(gar="brute", momentum_at="worker", clip=24.0, attack="empire", factor=1.1, evals=5),
 ]
 
 
-@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: f"{c['gar']}-{c['momentum_at']}-clip{c['clip']}-{c['attack']}")
+@pytest.mark.parametrize("cfg", CONFIGS, ids=lambda c: f"{c['gar']}-{c['momentum_at']}-clip{c['clip']}-{c['attack']}"
+                                                      + (f"-search{c['evals']}" if "evals" in c else ""))
 def test_reference_loop_restatement_is_bit_faithful(ref, cfg):
   h = N - F
   gen = torch.Generator().manual_seed(11)
@@ -112,7 +120,7 @@ def test_reference_loop_restatement_is_bit_faithful(ref, cfg):
   state = {"workers": [torch.zeros(D) for _ in range(h)], "server": torch.zeros(D),
            "pasts": collections.deque(maxlen=3)}
   mine = ReferenceLoop(N, F, F, cfg["gar"], cfg["momentum_at"], 0.9, 0.9, cfg["attack"], cfg["factor"], cfg["clip"], 3,
-                       precision="f32")
+                       precision="f32", evals=cfg.get("evals"), negative=cfg.get("negative", False))
   for it in range(4):
     base = 0.2 * torch.randn(D, generator=gen)
     sampled = [base + (0.5 + 0.1 * i) * torch.randn(D, generator=gen) for i in range(h)]
