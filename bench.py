@@ -260,6 +260,23 @@ def main():
   lo, hi = shard_bounds(d_total, world, rank)
   d = hi - lo  # this rank's coordinates
   agg = ShardedAggregator(force_collectives=distributed)
+  if distributed and agg.native is not None:
+    # the library's own RCCL communicator must work on EVERY rank, or every rank leaves it together (a rank
+    # falling back alone would issue different collectives): one tiny all-reduce through it, then a vote
+    ok = 1.0
+    try:
+      probe = torch.ones(4, dtype=torch.float64, device=device)
+      bm._lib.check(bm._lib.load().bm_allreduce_sum_f64(agg.native.handle, probe.data_ptr(), 4,
+                                                         torch.cuda.current_stream().cuda_stream), "bm_allreduce_sum_f64")
+      torch.cuda.synchronize()
+      ok = 1.0 if float(probe[0].item()) == float(world) else 0.0
+    except Exception as err:  # noqa: BLE001
+      print(f"[bench rank {rank}] native communicator failed its probe: {err}", file=sys.stderr)
+      ok = 0.0
+    vote = torch.tensor([ok], dtype=torch.float64, device=device)
+    dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+    if vote.item() < 1.0:
+      agg = ShardedAggregator(force_collectives=distributed, native_comm=False)
   timer = KernelTimer()
   per_gar = {}
   extra = {}
@@ -398,7 +415,10 @@ def main():
       "dtype": "f32", "data": "synthetic",
       "config": {"workload": workload_name, "n_workers": n, "f": f, "d_total": d_total, "d_per_gpu": d,
                  "byzantine_rows": "aliased" if args.aliased_byz else "distinct buffers",
-                 "parallelism": f"dim-shard x{world}" if world > 1 else "single GPU"},
+                 "parallelism": f"dim-shard x{world}" if world > 1 else "single GPU",
+                 "collectives": ("none" if not distributed else
+                                 "libbm_gar's own RCCL communicator, one C call per aggregation" if agg.native is not None
+                                 else "torch.distributed (RCCL)")},
       "roofline": {"bound": "hbm", "kernel": dominant, "achieved": dk["gbps"], "peak": HBM_PEAK_GBPS * world,
                    "unit": "GB/s", "frac": dk["gbps"] / (HBM_PEAK_GBPS * world), "traffic": traffic,
                    "traffic_source": None if traffic is None else

@@ -461,6 +461,38 @@ def test_step_with_factor_search_against_reference_loop(bm, cfg):
     params = params - 0.05 * want_upd
 
 
+@pytest.mark.parametrize("kind,attack", [("hetero", "empire"), ("tight", "little")])
+def test_factor_search_full_size_c3_both_forms_and_fp64(bm, kind, attack):
+  """The search against Multi-Krum at C3 (n=51, f=12, d=11 173 962): the scalar form (one distance pass) and the
+  per-evaluation form (the HIP rule on the vectors, sixteen times) visit the same candidates with the same
+  objective and settle on the same factor; the objective of the final factor is checked against a float64
+  evaluation on the GPU of what identical.py:72-76 computes."""
+  from byzantinemomentum_amd.step import AggregationStep
+  n, f, d = 51, 12, D_RESNET18
+  rows, h = gpu_stack(kind, n, f, d, seed=31)
+  honests = rows[:h]
+  avg, _, direction = bm.stats.stack_stats_async(honests, scale=1.0, attack=attack, direction=True)
+  found = {}
+  for mode in ("auto", "generic"):
+    runner = AggregationStep(n, f, f, gar="krum", attack=attack, attack_evals=16, line_search=mode, nb_past=0)
+    found[mode] = (runner._search_factor(honests, avg, direction), runner.last_search)
+  (fa, ta), (fg, tg) = found["auto"], found["generic"]
+  top = max(y for _, y in tg)
+  for (x, y), (xo, yo) in zip(ta, tg):
+    assert x == xo and abs(y - yo) <= 1e-5 * abs(yo) + 1e-9 * top, (x, y, yo)
+  assert fa == fg
+  # float64 on the GPU: candidate vector as the reference rounds it, Multi-Krum of the 51 rows, distance to avg
+  cand = avg + fa * direction
+  grads = honests + [cand] * f
+  sel = bm.gars.krum_selection(grads, f)
+  acc = torch.zeros(d, dtype=torch.float64, device=DEV)
+  for i in sel:
+    acc += grads[i].double()
+  want = float((acc / len(sel) - avg.double()).pow(2).sum())
+  got = dict(ta)[fa]
+  assert abs(got - want) <= 1e-5 * want, (got, want)
+
+
 def test_attack_direction_output(bm):
   """BM_ATTACK_DIRECTION: the attack direction alone (grad_att of identical.py:65) from bm_stack_stats and both
   forms of bm_momentum_stats, bit-identical to byz - avg being rebuilt the reference's way."""
