@@ -23,6 +23,7 @@ namespace bm {
 constexpr int kStatSums = 26;   // s2 sd h2 hd d2 a2 ad l2 | gram 4x4 | ex0 ex1
 constexpr int kStatMaxes = 4;   // smax hmax dmax amax
 constexpr int kStatSlots = 32;  // kStatSums + kStatMaxes, padded
+static_assert(kStatSums + kStatMaxes <= kStatSlots, "statistics vector layout");
 
 // scratch scalars of one call, all fp64 on the device
 struct StepScalars {
