@@ -29,18 +29,30 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(RowTable rows,
   constexpr int THETA = N - 2 * F - 2;
   constexpr int BETA = THETA - 2 * F;
   static_assert(BETA >= 1, "bulyan needs n >= 4f+3");
-  __shared__ const float* ranked_lds[MMAX];
-  if (threadIdx.x < MMAX) ranked_lds[threadIdx.x] = rows.p[order[threadIdx.x]];
-  __syncthreads();
-  // the m_max ranked row pointers move to SGPRs (wave-uniform): loads then use the saddr form with
-  // one 32-bit byte offset per lane, like the column kernels
+  // The m_max ranked row pointers live in SGPRs (loads then use the saddr form with one 32-bit byte offset
+  // per lane, like the column kernels).  Up to 25 of them are fetched with scalar loads only: `order` is
+  // uniform, and the row table — the first kernel argument, passed by value — is indexed in the kernarg
+  // segment itself.  A workgroup handles one column group per lane, so this prologue runs once per 256
+  // results: through LDS, a barrier and readfirstlane it costs 5 % of the kernel at n = 25 (163.5 -> 155.4 us,
+  // profiles/r02_g_bulyan_pass2_prologue.txt).  Above 25 pointers the scalar form runs out of SGPRs (16-60
+  // spilled, n = 51: 365 -> 390 us), so the larger instances keep the LDS form.
   const float* ranked[MMAX];
+  if constexpr (MMAX <= 25) {
+    typedef const float* __attribute__((address_space(4))) const* KargTable;
+    const KargTable karg = (KargTable)__builtin_amdgcn_kernarg_segment_ptr();
 #pragma unroll
-  for (int t = 0; t < MMAX; ++t) {
-    const uint64_t p = reinterpret_cast<uint64_t>(ranked_lds[t]);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p);
-    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
-    ranked[t] = reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
+    for (int t = 0; t < MMAX; ++t) ranked[t] = (const float*)karg[__builtin_amdgcn_readfirstlane(order[t])];
+  } else {
+    __shared__ const float* ranked_lds[MMAX];
+    if (threadIdx.x < MMAX) ranked_lds[threadIdx.x] = rows.p[order[threadIdx.x]];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < MMAX; ++t) {
+      const uint64_t p = reinterpret_cast<uint64_t>(ranked_lds[t]);
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p);
+      const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+      ranked[t] = reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
+    }
   }
   const float kNaN = __builtin_nanf("");
   const uint32_t nv = (uint32_t)nvec;  // nvec * VEC * 4 < 2^32: the host splits longer gradients
