@@ -301,7 +301,7 @@ def main():
         bm.median(st)
         bm.trmean(st, f)
     workload_name = f"C2 colwise: median + trmean(f={f}), n={n}, total d={d_total}"
-    dominant_kernel = "colwise_kernel"
+    dominant_kernel = "colwise_"  # colwise_kernel (plain form) or colwise_burst_kernel
   elif workload == "step":
     from byzantinemomentum_amd.step import AggregationStep
     n, f = 25, 5

@@ -235,6 +235,7 @@ namespace bm {
 struct Tuning {
   int force_vec;       // BM_FORCE_VEC: 0 auto, 1 or 2 force a narrower column vector
   int col_max_blocks;  // BM_COL_MAX_BLOCKS: grid cap of the column kernels
+  int col_burst;       // BM_COL_BURST: burst form of median/trmean from this many iterations per CU on (0 = never)
   int pair_blocks;     // BM_PAIR_BLOCKS: persistent grid of the pairwise-distance kernel
   int pair_strips;     // BM_PAIR_STRIPS: force a tile shape, strips*100+slots (e.g. 208), 0 = automatic
   int pair_ablate;     // BM_PAIR_ABLATE: 1 = no compute, 2 = no staging (experiments)

@@ -373,7 +373,7 @@ extern "C" int64_t bm_workspace_bytes(int kind, int n, int64_t d) {
     case BM_WS_DOT:
       return (int64_t)1025 * 42 * (int64_t)sizeof(double);
     case BM_WS_STEP:
-      return (int64_t)2049 * 6 * (int64_t)sizeof(double);
+      return (int64_t)16385 * 6 * (int64_t)sizeof(double);  // kStepMaxBlocks + 1 sets of 6 partials (step.hip)
     default:
       return BM_EINVAL;
   }

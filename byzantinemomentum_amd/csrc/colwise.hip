@@ -20,6 +20,21 @@
 
 namespace bm {
 
+constexpr int kBurstMaxRows = 25;  // 4 waves per SIMD (1024 lanes per CU) leave 128 VGPRs: trmean at n = 25 just fits, n = 26 spills
+
+// Compute units of the current device (the burst form launches one workgroup per CU).
+static int compute_units() {
+  static int cached[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  if (cached[dev] == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    cached[dev] = cus;
+  }
+  return cached[dev];
+}
+
 template <int N, int OP, int VEC>
 static int launch_colwise_vec(const RowTable& rows_all, int64_t d_all, int f, float* out_all,
                               hipStream_t stream) {
@@ -32,6 +47,17 @@ static int launch_colwise_vec(const RowTable& rows_all, int64_t d_all, int f, fl
     for (int i = 0; i < N; ++i) rows.p[i] += lo;
     const int64_t nvec = d / VEC;
     const int tail = (int)(d - nvec * VEC);
+    if constexpr (VEC == 4 && N <= kBurstMaxRows && (OP == BM_OP_MEDIAN || OP == BM_OP_TRMEAN)) {
+      // burst form: one workgroup per CU; worth it once every CU has several iterations to stage
+      const int cus = compute_units();
+      const int64_t burst_iters = nvec / ((int64_t)cus * kBurstThreads);
+      if (tuning().col_burst > 0 && burst_iters >= tuning().col_burst) {
+        hipLaunchKernelGGL((colwise_burst_kernel<N, OP, VEC>), dim3(cus), dim3(kBurstThreads), 0, stream, rows, nvec,
+                           tail, f, inv_keep, out_all + lo);
+        BM_LAUNCH_CHECK();
+        continue;
+      }
+    }
     const int grid = stream_grid(nvec, kColBlock, tuning().col_max_blocks);
     if constexpr (N == 25 && VEC == 4 && (OP == BM_OP_MEDIAN || OP == BM_OP_TRMEAN)) {
       if (tuning().col_ablate == 1) {  // experiment only: the read-only rate of the same kernel

@@ -121,6 +121,82 @@ __global__ __launch_bounds__(kColBlock) void colwise_kernel(RowTable rows, int64
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Burst form (median / trmean, VEC = 4, N <= 26, long gradients): the same loads and the same rule, but
+// the results leave the CU in bursts that coincide across the chip.
+//
+// A result stream that trickles out between the reads of 256 CUs costs 10-14 % of the kernel for 3.8 % of
+// its bytes (scripts/probes/rows_sweep_probe.hip).  Here ONE workgroup of 1024 lanes per CU (it declares
+// all 160 KB of LDS, so exactly one fits) walks the columns interleaved with the other CUs — iteration `it`
+// of workgroup b covers column groups (it * gridDim + b) * 1024 + lane, so at any time the chip reads one
+// contiguous window of every row — stages the results of 10 iterations in LDS, meets at a barrier and
+// writes them back to back.  Every CU started at the same time and has
+// the same work, so the bursts line up across the chip without any global synchronisation.
+// scripts/probes/two_phase_probe.hip on a bare 25-row stream: 194.3 us plain, 180.8 us in this form
+// (175.6 us with no store at all); without the barrier 197.7 us, with contiguous instead of interleaved
+// ownership 199.0 us, with bursts of 5 / 2 / 1 iterations 191.3 / 190.3 / 191.0 us.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kBurstThreads = 1024;
+constexpr int kBurstLdsBytes = 160 * 1024;
+
+template <int N, int OP, int VEC>
+__global__ __launch_bounds__(kBurstThreads) void colwise_burst_kernel(RowTable rows, int64_t nvec, int tail, int f,
+                                                                      float inv_keep, float* __restrict__ out) {
+  static_assert(OP == BM_OP_MEDIAN || OP == BM_OP_TRMEAN, "the closest-to-centre rules need the LDS for themselves");
+  using V = typename VecLoad<VEC>::T;
+  constexpr int kSlots = kBurstLdsBytes / (kBurstThreads * VEC * (int)sizeof(float));
+  __shared__ V stage[kSlots * kBurstThreads];
+  const uint32_t nv = (uint32_t)nvec, tid = threadIdx.x;
+  const uint32_t span = gridDim.x * kBurstThreads;  // column groups per iteration of the whole grid
+  const uint32_t iters = (nv + span - 1) / span;
+  const uint32_t first = blockIdx.x * kBurstThreads + tid;
+  for (uint32_t p0 = 0; p0 < iters; p0 += kSlots) {
+    const uint32_t p1 = (p0 + kSlots < iters) ? p0 + kSlots : iters;
+    for (uint32_t it = p0; it < p1; ++it) {
+      const uint32_t v = it * span + first;
+      if (v < nv) {
+        const uint32_t off = v * (uint32_t)(VEC * sizeof(float));
+        float x[VEC][N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+          float t[VEC];
+          load_stream_off<VEC>(rows.p[i], off, t);
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) x[c][i] = t[c];
+        }
+        float r[VEC];
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) r[c] = column_rule<N, OP>(x[c], f, inv_keep, nullptr);
+        V packed;
+        if constexpr (VEC == 1) {
+          packed = r[0];
+        } else {
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) packed[c] = r[c];
+        }
+        stage[(it - p0) * kBurstThreads + tid] = packed;
+      }
+    }
+    __syncthreads();  // not for the data (a lane reads back its own slots): it is what makes the stores a burst
+    for (uint32_t it = p0; it < p1; ++it) {
+      const uint32_t v = it * span + first;
+      if (v < nv) {
+        const uint32_t off = v * (uint32_t)(VEC * sizeof(float));
+        const V packed = stage[(it - p0) * kBurstThreads + tid];
+        __builtin_nontemporal_store(packed, reinterpret_cast<V*>(reinterpret_cast<char*>(out) + off));
+      }
+    }
+  }
+  // the d % VEC trailing columns: one lane each, in the last workgroup
+  if (VEC > 1 && blockIdx.x == gridDim.x - 1 && (int)tid < tail) {
+    const int64_t j = nvec * VEC + tid;
+    float x[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) x[i] = rows.p[i][j];
+    out[j] = column_rule<N, OP>(x, f, inv_keep, nullptr);
+  }
+}
+
 // Measured alternative, not kept: an LDS-DMA variant (per-wave private [N][1 KiB] LDS slot filled by
 // global_load_lds_dwordx4, read back with ds_read_b128, next chunk's DMA in flight during the
 // network, no barrier) ran at 229 / 244 us against 194 / 195 us for this kernel at n = 25,

@@ -19,7 +19,7 @@
 namespace bm {
 
 constexpr int kStepBlock = 256;
-constexpr int kStepMaxBlocks = 2048;
+constexpr int kStepMaxBlocks = 16384;  // per-workgroup partials: bm_workspace_bytes(BM_WS_STEP) holds kStepMaxBlocks + 1 sets
 
 struct StepTable {
   const float* g[BM_MAX_ROWS];  // sampled gradients (ks)
@@ -292,12 +292,14 @@ __global__ __launch_bounds__(kStepBlock, 4) void momentum_stats_stream_kernel(
 }
 
 // Fixed-order reduction of [nparts][6] partials: slots 0,1,3,4 are sums, 2 and 5 NaN-propagating maxima.
-__global__ __launch_bounds__(64) void step_finish_kernel(const double* __restrict__ partial, int nparts,
-                                                         double* __restrict__ out6) {
-  const int lane = threadIdx.x;
+constexpr int kFinishThreads = 256;
+__global__ __launch_bounds__(kFinishThreads) void step_finish_kernel(const double* __restrict__ partial, int nparts,
+                                                                     double* __restrict__ out6) {
+  __shared__ double red[kFinishThreads / 64][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
   bool nan2 = false, nan5 = false;
-  for (int b = lane; b < nparts; b += 64) {
+  for (int b = threadIdx.x; b < nparts; b += kFinishThreads) {
     const double* p = partial + (int64_t)b * 6;
     s[0] += p[0];
     s[1] += p[1];
@@ -319,6 +321,25 @@ __global__ __launch_bounds__(64) void step_finish_kernel(const double* __restric
     s[5] = o5 > s[5] ? o5 : s[5];
     nan2 |= (bool)__shfl_down((int)nan2, off, 64);
     nan5 |= (bool)__shfl_down((int)nan5, off, 64);
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) red[wave][k] = s[k];
+    red[wave][6] = nan2 ? 1.0 : 0.0;
+    red[wave][7] = nan5 ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kFinishThreads / 64; ++w) {  // waves in index order: the result does not depend on timing
+      s[0] += red[w][0];
+      s[1] += red[w][1];
+      s[3] += red[w][3];
+      s[4] += red[w][4];
+      s[2] = red[w][2] > s[2] ? red[w][2] : s[2];
+      s[5] = red[w][5] > s[5] ? red[w][5] : s[5];
+      nan2 |= red[w][6] != 0.0;
+      nan5 |= red[w][7] != 0.0;
+    }
   }
   if (lane == 0) {
     out6[0] = s[0];
@@ -479,7 +500,7 @@ extern "C" int bm_momentum_stats(const float* const* sampled, int ks, float* con
   int rc = 0;
   if (vec >= 2 && d / vec > 0) {
     const int64_t nvec = d / vec;
-    int cap = tuning().step_blocks > 0 ? tuning().step_blocks : kStepMaxBlocks - 1;
+    int cap = tuning().step_blocks > 0 ? tuning().step_blocks : 2047;
     if (cap > kStepMaxBlocks - 1) cap = kStepMaxBlocks - 1;
     const int grid = stream_grid(nvec, kStepBlock, cap);
     rc = (vec == 4) ? dispatch_momentum_stats<4>(tab, ks, h, nvec, mu, one_minus_damp, clip_factors, sampled_avg,
@@ -497,7 +518,7 @@ extern "C" int bm_momentum_stats(const float* const* sampled, int ks, float* con
       tail.b[i] += body;
     }
     const int64_t rest = d - body;
-    const int grid = (body == 0) ? stream_grid(rest, kStepBlock, kStepMaxBlocks) : 1;
+    const int grid = (body == 0) ? stream_grid(rest, kStepBlock, 2048) : 1;
     rc = dispatch_momentum_stats<1>(tail, ks, h, rest, mu, one_minus_damp, clip_factors,
                                     sampled_avg ? sampled_avg + body : nullptr,
                                     honest_avg ? honest_avg + body : nullptr, byz_out ? byz_out + body : nullptr,
@@ -506,7 +527,7 @@ extern "C" int bm_momentum_stats(const float* const* sampled, int ks, float* con
     nparts += grid;
   }
   // d == 0: nparts == 0 and the finish kernel writes zeros — every rank of a sharded job reaches its collective
-  hipLaunchKernelGGL(step_finish_kernel, dim3(1), dim3(64), 0, s, partial, nparts, out6);
+  hipLaunchKernelGGL(step_finish_kernel, dim3(1), dim3(kFinishThreads), 0, s, partial, nparts, out6);
   BM_LAUNCH_CHECK();
   return 0;
 }

@@ -7,6 +7,9 @@ sorted-order means within 1e-6 (summation order only).
 """
 
 import math
+import os
+import subprocess
+import sys
 
 import pytest
 import torch
@@ -17,6 +20,7 @@ from tests.golden_io import CASES, HAND_CASES, Golden, same_bits
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.fixture(scope="module")
@@ -464,9 +468,12 @@ def test_influence_hooks_match_reference_semantics(bm):
   assert 0 in before and 0 not in after
 
 
-@pytest.mark.parametrize("n,f,d", [(25, 5, 300003), (7, 1, 262145), (28, 6, 270000), (4, 1, 1048577)])
+@pytest.mark.parametrize("n,f,d", [(25, 5, 300003), (7, 1, 262145), (28, 6, 270000), (4, 1, 1048577), (25, 5, 1310723),
+                                   (13, 3, 2100001), (1, 0, 1048583)])
 def test_long_columns_with_nan_and_inf(bm, n, f, d):
-  """Long columns with NaN / inf sprinkled in and a d % 4 tail (several grid-stride trips per lane)."""
+  """Long columns with NaN / inf sprinkled in and a d % 4 tail (several grid-stride trips per lane).  From
+  2^20 coordinates on, BM_COL_BURST=1 sends median / trmean through the burst form of the column kernel with a
+  full and a partial iteration (test_colwise_burst_form_at_short_lengths re-runs this test that way)."""
   gen = torch.Generator().manual_seed(n * 1000 + f)
   rows = [torch.randn(d, generator=gen) for _ in range(n)]
   rows[0][::1001] = math.nan
@@ -478,6 +485,17 @@ def test_long_columns_with_nan_and_inf(bm, n, f, d):
   fin = torch.isfinite(want)
   assert bool(((got[fin] - want[fin]).abs() <= 1e-6 * 5).all())
   assert bool((got[~fin & ~torch.isnan(want)] == want[~fin & ~torch.isnan(want)]).all())
+
+
+def test_colwise_burst_form_at_short_lengths():
+  """The burst form of median / trmean (one workgroup per CU, results staged in LDS and written in bursts) is used
+  from 8 iterations per CU on (d >= 8.4 M: the full-size tests); BM_COL_BURST=1 lowers that to one iteration so that
+  the NaN / inf / tail cases above run through it too.  The knob is read once per process: subprocess."""
+  env = dict(os.environ, BM_COL_BURST="1", PYTHONPATH=ROOT)
+  out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-x",
+                        "-m", "gpu", "-k", "test_long_columns_with_nan_and_inf or test_full_size_colwise_properties"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+  assert out.returncode == 0, (out.stdout[-3000:], out.stderr[-2000:])
 
 
 def test_fused_attack_vectors(bm):
