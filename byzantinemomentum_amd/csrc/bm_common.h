@@ -210,6 +210,19 @@ static inline int stream_grid(int64_t work_items, int block, int max_blocks) {
   return (int)g;
 }
 
+// Compute units of the current device (the burst forms launch one workgroup per CU).
+static inline int compute_units() {
+  static int cached[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  if (cached[dev] == 0) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    cached[dev] = cus;
+  }
+  return cached[dev];
+}
+
 // Deterministic block reduction (sum) of one double per thread; result valid on thread 0.
 template <int BLOCK>
 __device__ __forceinline__ double block_reduce_sum(double v, double* lds /* BLOCK/64 doubles */) {
@@ -236,6 +249,7 @@ struct Tuning {
   int force_vec;       // BM_FORCE_VEC: 0 auto, 1 or 2 force a narrower column vector
   int col_max_blocks;  // BM_COL_MAX_BLOCKS: grid cap of the column kernels
   int col_burst;       // BM_COL_BURST: burst form of median/trmean from this many iterations per CU on (0 = never)
+  int mean_burst;      // BM_MEAN_BURST: the same for bm_selected_mean (averages of 12 rows or more)
   int pair_blocks;     // BM_PAIR_BLOCKS: persistent grid of the pairwise-distance kernel
   int pair_strips;     // BM_PAIR_STRIPS: force a tile shape, strips*100+slots (e.g. 208), 0 = automatic
   int pair_ablate;     // BM_PAIR_ABLATE: 1 = no compute, 2 = no staging (experiments)

@@ -22,19 +22,6 @@ namespace bm {
 
 constexpr int kBurstMaxRows = 25;  // 4 waves per SIMD (1024 lanes per CU) leave 128 VGPRs: trmean at n = 25 just fits, n = 26 spills
 
-// Compute units of the current device (the burst form launches one workgroup per CU).
-static int compute_units() {
-  static int cached[16] = {0};
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
-  if (cached[dev] == 0) {
-    int cus = 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    cached[dev] = cus;
-  }
-  return cached[dev];
-}
-
 template <int N, int OP, int VEC>
 static int launch_colwise_vec(const RowTable& rows_all, int64_t d_all, int f, float* out_all,
                               hipStream_t stream) {

@@ -44,10 +44,69 @@ __global__ __launch_bounds__(kRedBlock) void selected_mean_kernel(RowTable rows,
   }
 }
 
+// Burst form of the same kernel for long gradients (16-byte columns): one workgroup of 1024 lanes per CU,
+// column groups interleaved across the CUs, the results of 9 iterations staged in LDS, a barrier, then written
+// back to back — the recipe of colwise_burst_kernel (colwise_kernels.h), where the why is written down.  The
+// additions per column are the same, in the same order: the result is bit-identical to the plain form.
+constexpr int kMeanBurstThreads = 1024;
+constexpr int kMeanBurstSlots = 9;  // 9 x 1024 x 16 B = 144 KB of results next to the pointer table
+__global__ __launch_bounds__(kMeanBurstThreads) void selected_mean_burst_kernel(RowTable rows,
+                                                                                const int32_t* __restrict__ idx, int m,
+                                                                                int64_t nvec, float fm,
+                                                                                float* __restrict__ out) {
+  using V = typename VecLoad<4>::T;
+  __shared__ V stage[kMeanBurstSlots * kMeanBurstThreads];
+  __shared__ const float* sel[BM_MAX_ROWS];
+  const uint32_t tid = threadIdx.x;
+  if ((int)tid < m) sel[tid] = rows.p[idx[tid]];
+  __syncthreads();
+  const uint32_t nv = (uint32_t)nvec;
+  const uint32_t span = gridDim.x * kMeanBurstThreads;
+  const uint32_t iters = (nv + span - 1) / span;
+  const uint32_t first = blockIdx.x * kMeanBurstThreads + tid;
+  for (uint32_t p0 = 0; p0 < iters; p0 += kMeanBurstSlots) {
+    const uint32_t p1 = (p0 + kMeanBurstSlots < iters) ? p0 + kMeanBurstSlots : iters;
+    for (uint32_t it = p0; it < p1; ++it) {
+      const uint32_t v = it * span + first;
+      if (v < nv) {
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 8
+        for (int k = 0; k < m; ++k) {
+          float t[4];
+          load_stream<4>(sel[k] + (int64_t)v * 4, t);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[c] += t[c];
+        }
+        V packed;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) packed[c] = acc[c] / fm;
+        stage[(it - p0) * kMeanBurstThreads + tid] = packed;
+      }
+    }
+    __syncthreads();  // what makes the stores below a burst
+    for (uint32_t it = p0; it < p1; ++it) {
+      const uint32_t v = it * span + first;
+      if (v < nv) __builtin_nontemporal_store(stage[(it - p0) * kMeanBurstThreads + tid], reinterpret_cast<V*>(out) + v);
+    }
+  }
+}
+
 template <int VEC>
 static int launch_selected_mean(const RowTable& tab, const int32_t* idx, int m, int64_t nvec,
                                 float* out, hipStream_t s) {
   if (nvec <= 0) return 0;
+  if constexpr (VEC == 4) {
+    const int cus = compute_units();
+    // measured (profiles/r02_i_selected_mean_burst.txt): m = 37 at 11.2 M 306.7 -> 284.4 us, m = 18 at 36.5 M
+    // 510.7 -> 471.9 us, m = 7 at 9 M 56.7 -> 58.0 us: from 12 rows and 8 iterations per CU on
+    if (tuning().mean_burst > 0 && m >= 12 && nvec < ((int64_t)1 << 30) &&
+        nvec / ((int64_t)cus * kMeanBurstThreads) >= tuning().mean_burst) {
+      hipLaunchKernelGGL(selected_mean_burst_kernel, dim3(cus), dim3(kMeanBurstThreads), 0, s, tab, idx, m, nvec,
+                         (float)m, out);
+      BM_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   const int grid = stream_grid(nvec, kRedBlock, 256 * 32);
   hipLaunchKernelGGL(selected_mean_kernel<VEC>, dim3(grid), dim3(kRedBlock), 0, s, tab, idx, m, nvec,
                      (float)m, tuning().result_nt, out);

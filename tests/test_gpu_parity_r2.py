@@ -493,6 +493,19 @@ def test_factor_search_full_size_c3_both_forms_and_fp64(bm, kind, attack):
   assert abs(got - want) <= 1e-5 * want, (got, want)
 
 
+def test_selected_mean_burst_form_at_short_lengths():
+  """bm_selected_mean has a burst form (one workgroup per CU, results staged in LDS) used from 8 iterations per CU
+  on; BM_MEAN_BURST=1 sends gradients of one to two million coordinates with a ragged tail through it (a full and
+  a partial iteration, d % 4 != 0), where scripts/selected_mean_probe.py compares the WHOLE result with torch's own
+  sequential adds, bit for bit.  The knob is read once per process: subprocess."""
+  env = dict(os.environ, BM_MEAN_BURST="1", PYTHONPATH=ROOT, BM_PROBE_CASES="16:13:1310723,64:37:1100003,25:18:2621443")
+  out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "selected_mean_probe.py")], capture_output=True,
+                       text=True, env=env, cwd=ROOT, timeout=600)
+  assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-2000:])
+  lines = [ln for ln in out.stdout.splitlines() if ln.startswith("BM_MEAN_BURST=1")]
+  assert len(lines) == 3 and all("bit-exact True" in ln for ln in lines), out.stdout[-2000:]
+
+
 def test_attack_direction_output(bm):
   """BM_ATTACK_DIRECTION: the attack direction alone (grad_att of identical.py:65) from bm_stack_stats and both
   forms of bm_momentum_stats, bit-identical to byz - avg being rebuilt the reference's way."""
