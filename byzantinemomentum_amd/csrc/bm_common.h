@@ -250,6 +250,7 @@ struct Tuning {
   int col_max_blocks;  // BM_COL_MAX_BLOCKS: grid cap of the column kernels
   int col_burst;       // BM_COL_BURST: burst form of median/trmean from this many iterations per CU on (0 = never)
   int mean_burst;      // BM_MEAN_BURST: the same for bm_selected_mean (averages of 12 rows or more)
+  int bul_burst;       // BM_BUL_BURST: the same for Bulyan pass 2 (n <= 25); 0 (default): off, not yet validated on hardware
   int pair_blocks;     // BM_PAIR_BLOCKS: persistent grid of the pairwise-distance kernel
   int pair_strips;     // BM_PAIR_STRIPS: force a tile shape, strips*100+slots (e.g. 208), 0 = automatic
   int pair_ablate;     // BM_PAIR_ABLATE: 1 = no compute, 2 = no staging (experiments)

@@ -1,4 +1,6 @@
-"""Time bm_bulyan_pass2 alone at C4 (n=25, f=5, d=11 173 962) or C-like sizes; run it once per value of an
+"""A/B of Bulyan pass 2 forms: `BM_BUL_BURST=0|8 python scripts/bulyan_pass2_probe.py` in ONE gpurun call — the checksums
+of the two runs must agree to the last digit before the burst form may become the default.
+Time bm_bulyan_pass2 alone at C4 (n=25, f=5, d=11 173 962) or C-like sizes; run it once per value of an
 environment knob (the library reads its knobs once per process) for A/B comparisons inside one gpurun call."""
 import os
 import sys
@@ -41,8 +43,8 @@ def main():
       us.append(a.elapsed_time(b) * 1e3 / reps)
     us.sort()
     nbytes = 4 * d * (m + 1)
-    print(f"lib={os.environ.get('BM_PROBE_LIB', 'in-tree')} n={n} f={f}: pass 2 {us[rounds // 2]:.1f} us per call "
-          f"(best round {us[0]:.1f}) = {nbytes / us[rounds // 2] / 1e3:.0f} GB/s for {m}+1 rows; checksum {float(out[:1000].sum()):.6f}")
+    print(f"lib={os.environ.get('BM_PROBE_LIB', 'in-tree')} BM_BUL_BURST={os.environ.get('BM_BUL_BURST', 'default')} n={n} f={f}: pass 2 {us[rounds // 2]:.1f} us per call "
+          f"(best round {us[0]:.1f}) = {nbytes / us[rounds // 2] / 1e3:.0f} GB/s for {m}+1 rows; checksum {float(out.double().sum()):.9f}")
     del stacks
     torch.cuda.empty_cache()
 
