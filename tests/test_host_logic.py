@@ -103,3 +103,42 @@ def test_reference_discovers_native_package():
   names = out.stdout.strip().splitlines()[-1].split(",")
   assert names == ["native-aksel", "native-average", "native-brute", "native-bulyan", "native-cge", "native-krum",
                    "native-meamed", "native-median", "native-phocas", "native-trmean"]
+
+
+def test_burst_form_index_map_covers_every_column_group_once():
+  """The burst forms (colwise_burst_kernel, selected_mean_burst_kernel, bulyan_pass2_kernel<…, BURST>) walk the
+  column groups as v = it * (grid * T) + block * T + lane, in phases of `slots` iterations whose results sit in LDS
+  slot (it - p0) * T + lane until the barrier.  Replay that arithmetic on the host: every group below nv is produced
+  exactly once, staged in a slot no other live result of the same lane occupies, and written from that slot."""
+  def replay(nv, grid, threads, slots):
+    span = grid * threads
+    iters = (nv + span - 1) // span
+    written = np.zeros(nv, dtype=np.int32)
+    for block in range(grid):
+      lanes = np.arange(threads)
+      first = block * threads + lanes
+      p0 = 0
+      while p0 < iters:
+        p1 = min(p0 + slots, iters)
+        stage = {}
+        for it in range(p0, p1):
+          v = it * span + first
+          ok = v < nv
+          slot = (it - p0) * threads + lanes
+          assert slot.max() < slots * threads
+          for s, vv in zip(slot[ok], v[ok]):
+            assert s not in stage
+            stage[int(s)] = int(vv)
+        for it in range(p0, p1):
+          v = it * span + first
+          ok = v < nv
+          slot = (it - p0) * threads + lanes
+          for s, vv in zip(slot[ok], v[ok]):
+            assert stage[int(s)] == int(vv)
+            written[vv] += 1
+        p0 += slots
+    assert (written == 1).all()
+
+  for nv, grid, threads, slots in ((1, 4, 8, 3), (95, 4, 8, 3), (96, 4, 8, 3), (97, 4, 8, 3), (1000, 4, 8, 3),
+                                   (513, 8, 16, 10), (5000, 3, 32, 9), (32 * 7 * 10, 7, 32, 10)):
+    replay(nv, grid, threads, slots)
