@@ -178,10 +178,10 @@ def _worker(rank, world, port, d, queue):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("world,d", [(2, D), (2, 100), (2, 40), (3, D), (3, 130)])
+@pytest.mark.parametrize("world,d", [(2, D), (2, 100), (2, 40), (3, D), (3, 130), (4, 300)])
 def test_sharded_step_matches_single_rank(world, d):
   """d = 100 / world 2: the second rank's shard is short (36 coordinates); d = 40: it is EMPTY;
-  world 3, d = 130: shards of 64, 64 and 2 coordinates."""
+  world 3, d = 130: shards of 64, 64 and 2 coordinates; world 4, d = 300: 128, 128, 44 and an empty one."""
   ctx = mp.get_context("spawn")
   queue = ctx.Queue()
   port = _free_port()
