@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported before the CDLL, see above)
 _PKG_DIR = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _PKG_DIR / "libbm_gar.so"
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 MAX_ROWS = 64
 EINVAL = -100000
 ENOCOMM, ECOMM = -100001, -100002
@@ -81,8 +81,9 @@ SIGNATURES = {
   "bm_step_workspace_bytes": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int64]),
   "bm_step_worker": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_float_pp, _c_float_pp, ctypes.c_int64]
                      + [ctypes.c_void_p] * 13),
-  "bm_line_maximize": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_double,
-                                      ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]),
+  "bm_search_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double]),
+  "bm_search_propose": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+  "bm_search_report": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double]),
   "bm_attack_objective": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                          ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p,
                                          ctypes.c_void_p]),
@@ -90,7 +91,11 @@ SIGNATURES = {
                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
 }
 
-SCAPE_FN = ctypes.CFUNCTYPE(ctypes.c_double, ctypes.c_double, ctypes.c_void_p)  # bm_scape_fn
+class Search(ctypes.Structure):
+  """bm_search of include/bm_gar.h: the caller-owned cursor of the factor search."""
+  _fields_ = [("best_x", ctypes.c_double), ("best_y", ctypes.c_double), ("probe", ctypes.c_double),
+              ("step", ctypes.c_double), ("ratio", ctypes.c_double), ("phase", ctypes.c_int32),
+              ("evaluations", ctypes.c_int32), ("awaiting", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 RULE_IDS = {"krum": 0, "bulyan": 1, "median": 2, "trmean": 3, "phocas": 4, "meamed": 5, "brute": 6, "average": 7}

@@ -1,6 +1,6 @@
 // Line-searching attacks on the host: attacks/identical.py:67-77 (the factor search of the "empire",
-// "little" and "bulyan" attacks, the DEFAULT of the reference: factor=-16) and the exploration routine
-// it calls, tools/misc.py:468-514.
+// "little" and "bulyan" attacks, the DEFAULT of the reference: factor=-16); the exploration it asks
+// tools/misc.py:468-514 for is offered as a caller-driven cursor (bm_search_*).
 //
 // The reference evaluates the aggregation rule on n d-sized vectors once per candidate factor (16 times
 // per step).  For the rules whose output is the mean of a selected subset (Multi-Krum, Brute, Average),
@@ -23,55 +23,58 @@ extern "C" int bm_brute_select(const double* dist_nxn, int n, int f, int32_t* se
 
 namespace {
 
-// Best-effort arg-max of scape over x >= 0 under an evaluation budget (tools/misc.py:468-514): the first
-// phase walks right from `start` with a doubling step while the value improves; the second walks back and
-// forth around the best point with a step that shrinks by `ratio` per evaluation.  Comparisons are the
-// reference's strict '>' on doubles, so equal values never move the best point.
-template <class Scape>
-double line_maximize(Scape&& scape, int evals, double start, double delta, double ratio, double* trace) {
-  int done = 0;
-  auto eval = [&](double x) {
-    const double y = scape(x);
-    if (trace != nullptr) {
-      trace[2 * done] = x;
-      trace[2 * done + 1] = y;
-    }
-    ++done;
-    return y;
-  };
-  double best_x = start;
-  double best_y = eval(best_x);
-  double prop_x = best_x;
-  // expansion
-  while (done < evals) {
-    prop_x = best_x + delta;
-    const double prop_y = eval(prop_x);
-    if (prop_y > best_y) {
-      best_y = prop_y;
-      best_x = prop_x;
-      delta *= 2.0;
-    } else {
-      delta *= ratio;
+// The exploration of tools/misc.py:468-514 as a CURSOR the caller drives: propose() names the next abscissa,
+// report() takes the value measured there.  The library never calls back into the caller (no function pointer
+// crosses the ABI), so the same object serves the per-evaluation search of the Python host mirror (one device
+// evaluation between propose and report) and the scalar search below.
+// Behaviour to reproduce (the candidates must be the reference's, evaluation for evaluation):
+//   GROW    probe = incumbent + step; a strictly better value moves the incumbent there and doubles the step,
+//           the first value that is not better multiplies the step by `ratio` and ends the phase;
+//   SHRINK  the probe walks towards the incumbent and oscillates around it (+step while left of it, else
+//           -step, folded back into x >= 0 by repeated halving of the overshoot); the step is multiplied by
+//           `ratio` after every evaluation; strictly better values move the incumbent.
+enum { kSearchFirst = 0, kSearchGrow = 1, kSearchShrink = 2 };
+
+void cursor_propose(bm_search* c) {
+  switch (c->phase) {
+    case kSearchFirst:
+      break;  // probe already holds the starting point
+    case kSearchGrow:
+      c->probe = c->best_x + c->step;
       break;
-    }
+    default:
+      if (c->probe < c->best_x) {
+        c->probe += c->step;
+      } else {
+        double x = c->probe - c->step;
+        while (x < 0.0) x = 0.5 * (x + c->probe);
+        c->probe = x;
+      }
   }
-  // contraction
-  while (done < evals) {
-    if (prop_x < best_x) {
-      prop_x += delta;
-    } else {
-      double x = prop_x - delta;
-      while (x < 0.0) x = (x + prop_x) / 2.0;
-      prop_x = x;
-    }
-    const double prop_y = eval(prop_x);
-    if (prop_y > best_y) {
-      best_y = prop_y;
-      best_x = prop_x;
-    }
-    delta *= ratio;
+}
+
+void cursor_report(bm_search* c, double y) {
+  const bool better = (c->phase == kSearchFirst) || (y > c->best_y);  // strict: equal values never move the incumbent
+  if (better) {
+    c->best_x = c->probe;
+    c->best_y = y;
   }
-  return best_x;
+  switch (c->phase) {
+    case kSearchFirst:
+      c->phase = kSearchGrow;
+      break;
+    case kSearchGrow:
+      if (better) {
+        c->step *= 2.0;
+      } else {
+        c->step *= c->ratio;
+        c->phase = kSearchShrink;
+      }
+      break;
+    default:
+      c->step *= c->ratio;
+  }
+  ++c->evaluations;
 }
 
 struct AttackGeometry {
@@ -192,12 +195,31 @@ bool valid(const double* ext, int h, int k, int f, int rule, int& m) {
 
 }  // namespace
 
-extern "C" int bm_line_maximize(bm_scape_fn scape, void* ctx, int evals, double start, double delta,
-                                double ratio, double* best_x_out, double* trace_out) {
-  if (scape == nullptr || best_x_out == nullptr || evals < 1 || !(start >= 0.0) || !(delta > 0.0) ||
-      !(ratio > 0.5 && ratio < 1.0))
-    return BM_EINVAL;
-  *best_x_out = line_maximize([&](double x) { return scape(x, ctx); }, evals, start, delta, ratio, trace_out);
+extern "C" int bm_search_begin(bm_search* c, double start, double delta, double ratio) {
+  if (c == nullptr || !(start >= 0.0) || !(delta > 0.0) || !(ratio > 0.5 && ratio < 1.0)) return BM_EINVAL;
+  c->best_x = start;
+  c->best_y = 0.0;
+  c->probe = start;
+  c->step = delta;
+  c->ratio = ratio;
+  c->phase = kSearchFirst;
+  c->evaluations = 0;
+  c->awaiting = 0;
+  return 0;
+}
+
+extern "C" int bm_search_propose(bm_search* c, double* x_out) {
+  if (c == nullptr || x_out == nullptr || c->awaiting) return BM_EINVAL;  // one report per proposal
+  cursor_propose(c);
+  c->awaiting = 1;
+  *x_out = c->probe;
+  return 0;
+}
+
+extern "C" int bm_search_report(bm_search* c, double y) {
+  if (c == nullptr || !c->awaiting) return BM_EINVAL;
+  cursor_report(c, y);
+  c->awaiting = 0;
   return 0;
 }
 
@@ -221,18 +243,23 @@ extern "C" int bm_attack_line_search(const double* ext, int h, int k, int f, int
   if (!valid(ext, h, k, f, rule, m) || factor_out == nullptr || evals < 1) return BM_EINVAL;
   const AttackGeometry g(ext, h, k);
   std::vector<int> sel;
-  int status = 0;
-  *factor_out = line_maximize(
-      [&](double x) {
-        const double t = negative ? -x : x;  // identical.py:70-71
-        const int rc = select(g, f, rule, m, t, sel);
-        if (rc != 0) {
-          status = rc;
-          return (double)NAN;
-        }
-        std::sort(sel.begin(), sel.end());
-        return g.objective(sel, t);
-      },
-      evals, 0.0, 1.0, 0.8, trace_out);
-  return status;
+  bm_search cur;
+  int rc = bm_search_begin(&cur, 0.0, 1.0, 0.8);  // the attack's call: tools.line_maximize(eval_factor, evals=evals)
+  for (int e = 0; e < evals && rc == 0; ++e) {
+    double x = 0.0;
+    rc = bm_search_propose(&cur, &x);
+    if (rc != 0) break;
+    const double t = negative ? -x : x;  // identical.py:70-71
+    rc = select(g, f, rule, m, t, sel);
+    if (rc != 0) break;
+    std::sort(sel.begin(), sel.end());
+    const double y = g.objective(sel, t);
+    if (trace_out != nullptr) {
+      trace_out[2 * e] = x;
+      trace_out[2 * e + 1] = y;
+    }
+    rc = bm_search_report(&cur, y);
+  }
+  *factor_out = cur.best_x;
+  return rc;
 }

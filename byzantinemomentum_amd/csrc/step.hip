@@ -341,7 +341,7 @@ __global__ __launch_bounds__(kFinishThreads) void step_finish_kernel(const doubl
       nan5 |= red[w][7] != 0.0;
     }
   }
-  if (lane == 0) {
+  if (threadIdx.x == 0) {  // thread 0 alone holds the totals (lane 0 of the other waves holds partial sums)
     out6[0] = s[0];
     out6[1] = s[1];
     out6[2] = nan2 ? __builtin_nan("") : s[2];

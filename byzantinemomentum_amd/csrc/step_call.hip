@@ -33,7 +33,7 @@ struct StepScalars {
   double dots[18];
   double l2[4];
   double rowsq[BM_MAX_ROWS];
-  double gram4[4 * 16];  // row norms: Gram blocks of up to four rows at a time
+  double gram4[(BM_MAX_ROWS / 4) * 16];  // row norms: one 4 x 4 Gram block per group of four rows (ks <= BM_MAX_ROWS)
   double mine[kStatSlots];
   double all[kStatSlots * BM_MAX_ROWS];  // up to 64 ranks
   float clipf[BM_MAX_ROWS];

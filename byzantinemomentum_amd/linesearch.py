@@ -1,7 +1,7 @@
 """The factor search of the "identical" attacks (attacks/identical.py:67-77, tools/misc.py:468-514).
 
 Host logic of libbm_gar.so (csrc/linesearch.cpp), no device work here:
-  line_maximize          the exploration routine, around any Python callable;
+  line_maximize          the exploration routine around any Python callable, driven through the bm_search_* cursor;
   attack_objective       one evaluation of |GAR(honests + [avg + t*att]*k) - avg|^2 from scalars only,
   attack_line_search     the whole search from scalars only
 for the rules whose output is the mean of a selected subset (krum, brute, average).  The scalars are
@@ -19,26 +19,23 @@ ANALYTIC_RULES = ("krum", "brute", "average")
 
 
 def line_maximize(scape, evals=16, start=0., delta=1., ratio=0.8):
-  """tools.line_maximize (tools/misc.py:468-514): returns (best x, [(x, y) in evaluation order])."""
+  """The exploration of tools.line_maximize (tools/misc.py:468-514) around any Python callable: returns
+  (best x, [(x, y) in evaluation order]).  The candidates come from the library's cursor (bm_search_*), the
+  evaluations are made here, between a proposal and its report — nothing calls back through the C frame, so
+  an exception of `scape` propagates as it is."""
   lib = _lib.load()
-  failure = []
-
-  def call(x, _ctx):
-    try:
-      return float(scape(x))
-    except BaseException as err:  # an exception cannot cross the C frame: finish the search on NaNs, then re-raise
-      failure.append(err)
-      return float("nan")
-
-  best = ctypes.c_double()
-  trace = (ctypes.c_double * (2 * evals))()
-  callback = _lib.SCAPE_FN(call)
-  rc = lib.bm_line_maximize(ctypes.cast(callback, ctypes.c_void_p), None, evals, start, delta, ratio,
-                            ctypes.cast(ctypes.pointer(best), ctypes.c_void_p), ctypes.cast(trace, ctypes.c_void_p))
-  if failure:
-    raise failure[0]
-  _lib.check(rc, "bm_line_maximize")
-  return best.value, [(trace[2 * i], trace[2 * i + 1]) for i in range(evals)]
+  if not isinstance(evals, int) or evals < 1:
+    _lib.check(_lib.EINVAL, "line_maximize (evals must be a positive integer)")
+  cursor = _lib.Search()
+  _lib.check(lib.bm_search_begin(ctypes.byref(cursor), start, delta, ratio), "bm_search_begin")
+  x = ctypes.c_double()
+  trace = []
+  for _ in range(evals):
+    _lib.check(lib.bm_search_propose(ctypes.byref(cursor), ctypes.byref(x)), "bm_search_propose")
+    y = float(scape(x.value))
+    trace.append((x.value, y))
+    _lib.check(lib.bm_search_report(ctypes.byref(cursor), y), "bm_search_report")
+  return cursor.best_x, trace
 
 
 def _ext_pointer(ext, h):

@@ -180,13 +180,39 @@ class ShardedAggregator:
     self.native = None
     self.single_call = isinstance(self.backend, HipBackend) and native_comm is not False
     if self.single_call and self.collective:
-      try:
-        self.native = NativeComm(group)
-      except Exception as err:  # noqa: BLE001
+      self.native, failure = self._create_native(group)
+      if self.native is None:
         if native_comm is True:
-          raise
-        warnings.warn(f"libbm_gar RCCL communicator unavailable ({err}); using torch.distributed collectives")
+          raise RuntimeError(f"libbm_gar RCCL communicator unavailable on at least one rank ({failure})")
+        warnings.warn(f"libbm_gar RCCL communicator unavailable ({failure}); using torch.distributed collectives")
         self.single_call = False
+
+  def _create_native(self, group):
+    """The library's own communicator, on EVERY rank or on none: a rank that fell back alone would issue
+    torch.distributed collectives while its peers wait inside RCCL calls of the other communicator (a hang,
+    not a degradation).  Every step of the bootstrap that can fail locally is followed by a vote (MIN over the
+    ranks of a success flag, through the torch group that is known to work); the unique id is only
+    broadcast, and bm_comm_init only entered, when every rank can go on."""
+    lib = _lib.load()
+
+    def everyone(ok):
+      flag = torch.tensor([1.0 if ok else 0.0], dtype=torch.float32,
+                          device=torch.device("cuda", torch.cuda.current_device()))
+      dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+      return flag.item() >= 1.0
+
+    if not everyone(bool(lib.bm_comm_available())):
+      return None, "RCCL could not be bound by libbm_gar.so"
+    comm, failure = None, None
+    try:
+      comm = NativeComm(group)
+    except Exception as err:  # noqa: BLE001
+      failure = err
+    if not everyone(comm is not None):
+      if comm is not None:
+        comm.close()
+      return None, failure if failure is not None else "bm_comm_init failed on another rank"
+    return comm, None
 
   # -- collectives (never called when world_size == 1) ----------------------- #
 
@@ -227,7 +253,7 @@ class ShardedAggregator:
     dist.all_gather_into_tensor(full, padded, group=self.group)
     return full[:d]
 
-  def to_dim_sharded(self, my_gradients, n, d):
+  def to_dim_sharded(self, my_gradients, n, d, dtype=torch.float32, device=None):
     """Worker-major -> dimension-major in ONE all-to-all (the step before the
     path when the honest gradients are PRODUCED in parallel, experiments/model.py:333-366 run once per
     worker).  `my_gradients`: the full-length gradients of owned_workers(n, P, rank), in that order.
@@ -243,8 +269,13 @@ class ShardedAggregator:
     lo0, hi0 = shard_bounds(d, world, 0)
     per = hi0 - lo0                       # padded shard length (multiple of 64 coordinates)
     n_max = -(-n // world)
-    like = my_gradients[0]
-    send = torch.zeros((world, n_max, per), dtype=like.dtype, device=like.device)
+    # a rank that owns no worker (n < P) still takes part in the exchange with an all-zero send buffer:
+    # dtype / device come from its gradients when it has some, else from the arguments
+    if my_gradients:
+      dtype, device = my_gradients[0].dtype, my_gradients[0].device
+    elif device is None:
+      device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    send = torch.zeros((world, n_max, per), dtype=dtype, device=device)
     for j, g in enumerate(my_gradients):
       full = g.shape[0] // per
       send[:full, j, :] = g[:full * per].view(full, per)

@@ -245,9 +245,13 @@ int bm_step_worker(bm_comm* comm, const bm_step_params* p, const float* const* s
  * The factor search of the "identical" attacks (attacks/identical.py:67-77, the reference's default
  * factor=-16) — HOST functions, no stream.
  *
- * bm_line_maximize: tools/misc.py:468-514, best-effort arg-max over x >= 0 of scape(x, ctx) within
- * `evals` evaluations (reference defaults: start 0, delta 1, ratio 0.8).  trace_out: NULL or 2*evals
- * doubles receiving the (x, y) pairs in evaluation order.
+ * bm_search_*: the exploration of tools/misc.py:468-514 (best-effort arg-max over x >= 0 within a budget of
+ * evaluations; reference defaults: start 0, delta 1, ratio 0.8) as a cursor the CALLER drives:
+ *     bm_search_begin(&c, start, delta, ratio);
+ *     repeat `evals` times: bm_search_propose(&c, &x); y = <evaluate at x>; bm_search_report(&c, y);
+ *     answer: c.best_x
+ * The evaluations are the caller's (a rule on the device, or bm_attack_objective on scalars); the library
+ * never calls back.  bm_search is plain data owned by the caller.
  *
  * bm_attack_objective / bm_attack_line_search: for a rule whose output is the mean of a selected subset
  * (BM_RULE_KRUM with m, BM_RULE_BRUTE, BM_RULE_AVERAGE), the objective |GAR(honests + [avg + t*att]*k, f)
@@ -256,9 +260,18 @@ int bm_step_worker(bm_comm* comm, const bm_step_params* p, const float* const* s
  * sel_out (may be NULL): the rows the rule averages, indices >= h being Byzantine copies; count_out
  * their number.  bm_attack_line_search runs the whole search (negative: identical.py:70-71) and returns
  * the factor the attack then uses.  No d-sized vector is touched: 16 evaluations cost microseconds. */
-typedef double (*bm_scape_fn)(double x, void* ctx);
-int bm_line_maximize(bm_scape_fn scape, void* ctx, int evals, double start, double delta, double ratio,
-                     double* best_x_out, double* trace_out);
+typedef struct bm_search {
+  double best_x, best_y;  /* incumbent: abscissa and value (valid once evaluations >= 1)           */
+  double probe;           /* last abscissa proposed                                                 */
+  double step, ratio;     /* current step; contraction factor, 0.5 < ratio < 1                      */
+  int32_t phase;          /* 0 first evaluation, 1 growing, 2 shrinking                             */
+  int32_t evaluations;    /* values reported so far                                                 */
+  int32_t awaiting;       /* 1 between bm_search_propose and bm_search_report                       */
+  int32_t reserved;
+} bm_search;
+int bm_search_begin(bm_search* c, double start, double delta, double ratio);
+int bm_search_propose(bm_search* c, double* x_out);
+int bm_search_report(bm_search* c, double y);
 int bm_attack_objective(const double* ext, int h, int k, int f, int rule, int m, double t, double* y_out,
                         int32_t* sel_out, int32_t* count_out);
 int bm_attack_line_search(const double* ext, int h, int k, int f, int rule, int m, int evals, int negative,

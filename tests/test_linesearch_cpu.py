@@ -1,5 +1,5 @@
 """The factor search of the "identical" attacks on the host (csrc/linesearch.cpp, no GPU involved):
-bm_line_maximize against the restatement of tools.line_maximize, and the scalar form of the search
+the bm_search_* cursor against the restatement of tools.line_maximize, and the scalar form of the search
 (bm_attack_objective / bm_attack_line_search) against the search run the reference's way — the rule
 evaluated on the vectors once per candidate — on float64 distances."""
 
@@ -41,8 +41,24 @@ def test_line_maximize_other_parameters_and_errors():
 
   def boom(x):
     raise KeyError("from the callback")
-  with pytest.raises(KeyError):  # an exception of the callable surfaces after the C frame has returned
+  with pytest.raises(KeyError):  # an exception of the callable propagates (the evaluations are the caller's)
     linesearch.line_maximize(boom, evals=4)
+
+
+def test_search_cursor_protocol():
+  """One report per proposal, in that order; the cursor is plain caller-owned data."""
+  import ctypes
+  lib = _lib.load()
+  cur = _lib.Search()
+  x = ctypes.c_double()
+  assert lib.bm_search_begin(ctypes.byref(cur), 0.0, 1.0, 0.8) == 0
+  assert lib.bm_search_report(ctypes.byref(cur), 1.0) == _lib.EINVAL       # nothing proposed yet
+  assert lib.bm_search_propose(ctypes.byref(cur), ctypes.byref(x)) == 0 and x.value == 0.0
+  assert lib.bm_search_propose(ctypes.byref(cur), ctypes.byref(x)) == _lib.EINVAL  # the first one is unanswered
+  assert lib.bm_search_report(ctypes.byref(cur), 3.0) == 0
+  assert (cur.evaluations, cur.best_x, cur.best_y) == (1, 0.0, 3.0)
+  assert lib.bm_search_propose(ctypes.byref(cur), ctypes.byref(x)) == 0 and x.value == 1.0
+  assert lib.bm_search_begin(None, 0.0, 1.0, 0.8) == _lib.EINVAL
 
 
 def honest_stack(seed, h, d=400):

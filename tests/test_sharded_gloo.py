@@ -109,10 +109,11 @@ def _a2a_worker(rank, world, port, n, d, queue):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("n,d", [(5, 1000), (4, 130), (3, 40)])
+@pytest.mark.parametrize("n,d", [(5, 1000), (4, 130), (3, 40), (1, 200)])
 def test_worker_major_to_dim_major_all_to_all(n, d):
   """Worker-parallel production (rank p holds workers p, p+P, ...) -> one all-to-all -> every rank holds
-  its coordinate slice of ALL workers; uneven worker counts, a short last shard and an empty one."""
+  its coordinate slice of ALL workers; uneven worker counts, a short last shard, an empty one, and a rank
+  that owns no worker at all (n < P: it still joins the exchange, with an all-zero send buffer)."""
   world = 2
   ctx = mp.get_context("spawn")
   queue = ctx.Queue()
