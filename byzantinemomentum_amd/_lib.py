@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported before the CDLL, see above)
 _PKG_DIR = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _PKG_DIR / "libbm_gar.so"
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 MAX_ROWS = 64
 EINVAL = -100000
 ENOCOMM, ECOMM = -100001, -100002
@@ -37,6 +37,8 @@ SIGNATURES = {
   "bm_workspace_bytes": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int, ctypes.c_int64]),
   "bm_pairwise_sqdist": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p,
                                         ctypes.c_void_p, ctypes.c_void_p]),
+  "bm_pairwise_sqdist_shard": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
   "bm_krum_rank": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
   "bm_selected_mean": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,

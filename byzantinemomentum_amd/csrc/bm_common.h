@@ -264,6 +264,7 @@ struct Tuning {
   int step_store;      // BM_STEP_STORE: 0 non-temporal buffer stores (default), 1 plain stores (experiments)
   int step_blocks;     // BM_STEP_BLOCKS: grid cap of bm_momentum_stats, 0 = default
   int step_vec;        // BM_STEP_VEC: 0 (default) automatic, 1/2/4 cap the vector width of bm_momentum_stats (experiments)
+  int pair_dither;     // BM_PAIR_DITHER (mode 0, two planes): seed of the coordinate dither (default 0); -1 = no dither, round to nearest (experiments)
   double pair_tau;     // BM_PAIR_TAU: accuracy gate of the Gram modes (see gram_to_sqdist_kernel); <= 0 disables
 };
 const Tuning& tuning();

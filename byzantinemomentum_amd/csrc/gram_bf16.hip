@@ -88,6 +88,39 @@ __device__ __forceinline__ void split3(const f32x4 x, u32x2& h, u32x2& m, u32x2&
   l.y = pack_bf16(s2, s3);
 }
 
+// Two-plane form: x ~ h + m with h = rne_bf16(x) and m the remainder r = x - h rounded to bf16 STOCHASTICALLY:
+// the 16 discarded bits of r are compared with 16 pseudo-random bits that depend on the COORDINATE only
+// (integer add on the bit pattern, then truncation: the magnitude is rounded up with probability
+// discarded/2^16, so E[m] = r exactly).  What is dropped, l = r - m, then has zero mean and is independent from
+// one coordinate to the next BY CONSTRUCTION, whatever the data — with round-to-nearest the dropped part
+// is a deterministic function of the value, and rows with few distinct values (constant, sign, quantised or
+// sparsified gradients) turn the first-order error 2 sum_k (x_i - x_j)_k (l_i - l_j)_k of a squared distance
+// into a systematic term of relative size up to 2^-16 |x| / |x_i - x_j| (3e-5 ... 5e-4 for a pair just above
+// the accuracy gate) instead of a random walk sqrt(d) times smaller.  All rows share the dither of a
+// coordinate, so bitwise-equal rows still give bitwise-equal planes (exact ties survive), and rows that are
+// close get the same rounding direction most of the time (their l's largely cancel in l_i - l_j).
+__device__ __forceinline__ unsigned dither_pair(unsigned coord) {
+  // two 16-bit words for coordinates coord, coord + 1 from one 32-bit mix of the (even) coordinate index
+  unsigned z = coord * 0x9E3779B1u + 0x7F4A7C15u;
+  z ^= z >> 15;
+  z *= 0x85EBCA77u;
+  z ^= z >> 13;
+  z *= 0xC2B2AE3Du;
+  z ^= z >> 16;
+  return z;
+}
+__device__ __forceinline__ void split2_dithered(const f32x4 x, const unsigned d01, const unsigned d23, u32x2& h, u32x2& m) {
+  h.x = pack_bf16(x.x, x.y);
+  h.y = pack_bf16(x.z, x.w);
+  const unsigned b0 = __builtin_bit_cast(unsigned, x.x - bf16_lo(h.x)) + (d01 & 0xffffu);
+  const unsigned b1 = __builtin_bit_cast(unsigned, x.y - bf16_hi(h.x)) + (d01 >> 16);
+  const unsigned b2 = __builtin_bit_cast(unsigned, x.z - bf16_lo(h.y)) + (d23 & 0xffffu);
+  const unsigned b3 = __builtin_bit_cast(unsigned, x.w - bf16_hi(h.y)) + (d23 >> 16);
+  // upper halves of (b1, b0) -> one packed bf16 pair: bytes {b0.2, b0.3, b1.2, b1.3}
+  m.x = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
+  m.y = __builtin_amdgcn_perm(b3, b2, 0x07060302u);
+}
+
 __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
                                                  0, 0, 0);
@@ -111,7 +144,7 @@ struct B3Shape {
 
 template <int K, int NPL, bool ALIGNED>
 __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_partial_kernel(
-    RowTable rows, int n, int64_t d, float inv_n, int centre, double* __restrict__ partial) {
+    RowTable rows, int n, int64_t d, float inv_n, int centre, unsigned dither_seed, double* __restrict__ partial) {
   using S = B3Shape<K, NPL>;
   constexpr int RB = S::RB, NP = S::NP, NSETS = S::NSETS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -187,7 +220,7 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
   const int src_b = (K >= 3) ? x : (K == 2 ? 32 + x : (n >= 3 ? 16 + x : x));
   const int src_c = (K >= 3) ? x : (K == 2 ? x : (n >= 3 ? 32 + x : x));
 
-  auto contract = [&](f32x4 (&v)[K]) {
+  auto contract = [&](f32x4 (&v)[K], int64_t chunk) {
     // -- per-coordinate centre (distances are translation invariant; any finite vector is legal) --
     f32x4 c = {0.0f, 0.0f, 0.0f, 0.0f};
     if (centre == 2) {
@@ -222,10 +255,20 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
       }
     }
     // -- split and store the planes --
+    unsigned d01 = 0, d23 = 0;
+    if constexpr (NPL == 2) {  // the dither of this lane's four coordinates, shared by all K rows
+      const unsigned coord = (unsigned)chunk * (unsigned)kB3Chunk + 4u * (unsigned)x;
+      // dither_seed == ~0u (BM_PAIR_DITHER=-1, experiments): half an ulp for everyone = round to nearest
+      d01 = dither_seed == ~0u ? 0x80008000u : dither_pair(coord + dither_seed);
+      d23 = dither_seed == ~0u ? 0x80008000u : dither_pair(coord + 2u + dither_seed);
+    }
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       u32x2 h, m, l;
-      split3(v[k] - c, h, m, l);
+      if constexpr (NPL == 2)
+        split2_dithered(v[k] - c, d01, d23, h, m);
+      else
+        split3(v[k] - c, h, m, l);
       char* dst = wbase + (wr_lane ^ (((2 * k) & 7) << 4)) + k * 4 * kB3RowBytes;
       *reinterpret_cast<u32x2*>(dst) = h;
       *reinterpret_cast<u32x2*>(dst + S::PS) = m;
@@ -291,7 +334,7 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
 #pragma unroll
     for (int b = 0; b < NSETS; ++b) {
       if (c < nchunks) {  // wave-uniform
-        contract(xs[b]);
+        contract(xs[b], c);
         const int64_t nxt = c + NSETS * nw;
         if (nxt < nchunks) issue(nxt, xs[b]);
         multiply();
@@ -337,7 +380,7 @@ static int launch_gram3_planes(const RowTable& tab, int n, int64_t d, bool align
     if (e != hipSuccess) return hip_code(e);
   }
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * kB3Waves), S::kLds, s, tab, n, d, 1.0f / (float)n, centre,
-                     partial);
+                     (unsigned)tuning().pair_dither, partial);
   BM_LAUNCH_CHECK();
   return 0;
 }
@@ -355,7 +398,7 @@ int64_t gram3_partial_doubles(int n) { return (int64_t)kB3MaxBlocks * ((int64_t)
 
 // Partial Gram matrices of the centred rows; returns the number of workgroups (= partial blocks)
 // through *blocks_out.  `partial` holds gram3_partial_doubles(n) doubles.
-int gram3_partials(const float* const* rows, int n, int64_t d, double* partial, int* blocks_out,
+int gram3_partials(const float* const* rows, int n, int64_t d, int64_t d_total, double* partial, int* blocks_out,
                    hipStream_t s) {
   RowTable tab{};
   for (int i = 0; i < n; ++i) tab.p[i] = rows[i];
@@ -368,13 +411,15 @@ int gram3_partials(const float* const* rows, int n, int64_t d, double* partial, 
   const int64_t need = (chunks + kB3Waves - 1) / kB3Waves;
   if (blocks > need) blocks = (int)(need > 0 ? need : 1);
   const int centre = tuning().pair_centre;
-  // Planes: the exact three-way split below 2^20 coordinates; above, two planes (x ~ h + m, 16
-  // significant bits, unbiased remainder <= 2^-17 |x|): the rounding noise of a Gram entry averages
-  // as 4.4e-6 * sqrt(3/d) <= 7.6e-9 relative, the order of the fp32 accumulation error itself (so that a
-  // pair just above the accuracy gate, tau = 2e-3, still has ~4e-6 relative accuracy), for a third fewer
-  // MFMAs and conversion ops.  BM_PAIR_PLANES forces 2 or 3.
+  // Planes: the exact three-way split below 2^20 coordinates; above, two planes (x ~ h + m, 16 significant
+  // bits, the remainder rounded with the coordinate dither of split2_dithered: what is dropped has zero mean and
+  // is independent across coordinates by construction), whose error on a squared distance is a random walk
+  // over the coordinates: relative 2.8 * 2^-16 * (|x| / |x_i - x_j|) / sqrt(d) <= 1e-6 for a pair just above the
+  // accuracy gate at d = 2^20, for a third fewer MFMAs and conversion ops.  The length that counts is the
+  // TOTAL one (d_total: all shards of a dim-sharded job), so that the choice does not depend on the world
+  // size.  BM_PAIR_PLANES forces 2 or 3.
   int planes = tuning().pair_planes;
-  if (planes != 2 && planes != 3) planes = (d >= ((int64_t)1 << 20)) ? 2 : 3;
+  if (planes != 2 && planes != 3) planes = (d_total >= ((int64_t)1 << 20)) ? 2 : 3;
   int rc;
   switch (K) {
 #define BM_B3_CASE(KK) \

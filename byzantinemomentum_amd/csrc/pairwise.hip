@@ -455,7 +455,8 @@ int gram_sqdist(const float* const* rows, int n, int64_t d, double* sq_nxn, doub
 int gram_finish(const double* partial, int blocks, int n, double* gram, double* sq_nxn, int* sub, double tau,
                 hipStream_t s);
 int64_t gram_partial_doubles(int n);
-int gram3_partials(const float* const* rows, int n, int64_t d, double* partial, int* blocks_out, hipStream_t s);
+int gram3_partials(const float* const* rows, int n, int64_t d, int64_t d_total, double* partial, int* blocks_out,
+                   hipStream_t s);
 int64_t gram3_partial_doubles(int n);
 
 // Workspace layout of bm_pairwise_sqdist: [row list of the gate: 512 B][Gram partials][Gram n(n+1)/2][direct partials]
@@ -514,8 +515,13 @@ static int pairwise_direct(const float* const* rows, int n, int64_t d, double* s
 
 extern "C" int bm_pairwise_sqdist(const float* const* rows, int n, int64_t d, double* sq_nxn,
                                   void* ws, void* stream) {
+  return bm_pairwise_sqdist_shard(rows, n, d, d, sq_nxn, ws, stream);
+}
+
+extern "C" int bm_pairwise_sqdist_shard(const float* const* rows, int n, int64_t d, int64_t d_total, double* sq_nxn,
+                                        void* ws, void* stream) {
   using namespace bm;
-  if (rows == nullptr || sq_nxn == nullptr || ws == nullptr || n < 1 || n > BM_MAX_ROWS || d < 0)
+  if (rows == nullptr || sq_nxn == nullptr || ws == nullptr || n < 1 || n > BM_MAX_ROWS || d < 0 || d_total < d)
     return BM_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   int* flag = static_cast<int*>(ws);  // flag[0] = rows to recompute, flag[1..] = their indices
@@ -535,7 +541,7 @@ extern "C" int bm_pairwise_sqdist(const float* const* rows, int n, int64_t d, do
     rc = gram_sqdist(rows, n, d, sq_nxn, gram_partial, gram, flag, tau, s);
   } else {
     int blocks = 0;
-    rc = gram3_partials(rows, n, d, gram_partial, &blocks, s);
+    rc = gram3_partials(rows, n, d, d_total, gram_partial, &blocks, s);
     if (rc != 0) return rc;
     double* gram = gram_partial + gram3_partial_doubles(n);
     rc = gram_finish(gram_partial, blocks, n, gram, sq_nxn, flag, tau, s);

@@ -129,7 +129,10 @@ int sharded_rank(bm_comm* comm, const float* const* rows, int n, int64_t d_local
   double* sq = reinterpret_cast<double*>(base);
   int32_t* order = reinterpret_cast<int32_t*>(base + BM_MAX_ROWS * BM_MAX_ROWS * 8);
   void* pair_ws = base + kShardHeader;
-  int rc = bm_pairwise_sqdist(rows, n, d_local, sq, pair_ws, stream);
+  // the precision plan of the distance pass follows the length of the WHOLE vector (all shards): shards are equal
+  // up to the 64-coordinate rounding of shard_bounds, d_local * ranks is the total to within that
+  const int64_t d_total = d_local * (int64_t)bm_comm_size(comm);
+  int rc = bm_pairwise_sqdist_shard(rows, n, d_local, d_total, sq, pair_ws, stream);
   if (rc != 0) return rc;
   rc = bm_allreduce_sum_f64(comm, sq, (int64_t)n * n, stream);
   if (rc != 0) return rc;

@@ -120,15 +120,16 @@ def meamed(gradients, f, **kwargs):
 # ---------------------------------------------------------------------------- #
 # Distance-based rules
 
-def pairwise_sqdist(gradients):
-  """n x n fp64 matrix of squared L2 distances, on the device, no host sync."""
+def pairwise_sqdist(gradients, d_total=None):
+  """n x n fp64 matrix of squared L2 distances, on the device, no host sync.  d_total: length of the whole
+  vectors when `gradients` are one shard of a dimension-partitioned stack (the precision plan follows it)."""
   n, d, device = _validate(gradients)
   lib = _lib.load()
   sq = torch.empty((n, n), dtype=torch.float64, device=device)  # result: a fresh tensor per call
   ws = _workspace(device, _lib.WS_PAIRWISE, n, d, "ws_pair")
   with torch.cuda.device(device):
-    _lib.check(lib.bm_pairwise_sqdist(_lib.pointer_table(gradients), n, d, _ptr(sq), _ptr(ws),
-                                      _stream(device)), "bm_pairwise_sqdist")
+    _lib.check(lib.bm_pairwise_sqdist_shard(_lib.pointer_table(gradients), n, d, d if d_total is None else int(d_total),
+                                            _ptr(sq), _ptr(ws), _stream(device)), "bm_pairwise_sqdist_shard")
   return sq
 
 

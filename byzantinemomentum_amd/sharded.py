@@ -91,8 +91,8 @@ class HipBackend:
 
   # -- aggregation rules ------------------------------------------------------ #
 
-  def pairwise_sqdist(self, gradients):
-    return self.gars.pairwise_sqdist(gradients)
+  def pairwise_sqdist(self, gradients, d_total=None):
+    return self.gars.pairwise_sqdist(gradients, d_total)
 
   def rank(self, sq, n, f, m, mode):
     order, _ = self.gars.rank_from_sqdist(sq, n, f, m, mode)
@@ -303,7 +303,8 @@ class ShardedAggregator:
   def global_sqdist(self, local):
     """All-reduced n x n squared-distance matrix (every rank gets the same bits: the sum runs over
     the same P partial matrices in the collective's fixed order)."""
-    sq = self.backend.pairwise_sqdist(local)  # a fresh tensor, reduced in place
+    # the precision plan follows the length of the whole vectors (as bm_sharded_* does: d_local x ranks)
+    sq = self.backend.pairwise_sqdist(local, d_total=local[0].numel() * self.world_size)  # fresh, reduced in place
     self._all_reduce(sq)
     return sq
 

@@ -71,6 +71,13 @@ int64_t bm_workspace_bytes(int kind, int n, int64_t d);
 int bm_pairwise_sqdist(const float* const* rows, int n, int64_t d,
                        double* sq_nxn, void* ws, void* stream);
 
+/* The same over ONE SHARD of a dimension-partitioned stack: d coordinates here, d_total >= d over
+ * all shards.  The partial matrices of the shards add up to the matrix of the whole rows; the precision
+ * plan of the pass (how each fp32 value is split for the matrix cores) follows d_total, so a job gives the
+ * same plan whatever its world size.  bm_pairwise_sqdist(rows, n, d, ...) is this with d_total = d. */
+int bm_pairwise_sqdist_shard(const float* const* rows, int n, int64_t d, int64_t d_total,
+                             double* sq_nxn, void* ws, void* stream);
+
 /* Score + stable rank on the device (one workgroup), from the squared distances.
  * mode BM_RANK_KRUM  : score_i = sum of the (n-f-1) smallest distances of row i
  *                      (aggregators/krum.py:50-62)

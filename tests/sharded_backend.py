@@ -10,7 +10,7 @@ from oracle import gar_oracle as O
 
 
 class OracleBackend:
-  def pairwise_sqdist(self, gradients):
+  def pairwise_sqdist(self, gradients, d_total=None):
     n = len(gradients)
     sq = torch.zeros(n, n, dtype=torch.float64)
     g64 = [g.double() for g in gradients]

@@ -64,14 +64,8 @@ def test_golden_colwise(bm, name):
   assert same_bits(bm.median(dev), g.tensor("median"))  # bit-exact, NaN columns included
   if g.has("trmean"):
     assert close(bm.trmean(dev, g.f), g.tensor("trmean"), 1e-6)
-    st = torch.stack(g.gradients)
-    for rule, centre in (("phocas", O.trmean(g.gradients, g.f)), ("meamed", O.median(g.gradients))):
-      got = bm.gars.__dict__[rule](dev, g.f).cpu()
-      want = g.tensor(rule)
-      _, amb = O.closest_window(torch.nan_to_num(st, nan=math.inf), g.n - g.f, centre)
-      scale = float(st[torch.isfinite(st)].abs().max())
-      per_col = ((got.double() - want.double()).abs() <= 2e-6 * scale) | (torch.isnan(got) & torch.isnan(want))
-      assert bool((per_col | amb | torch.isnan(centre)).all()), rule
+  # phocas / meamed on the same fixtures: tests/test_gpu_parity_r2.py::test_closest_rules_without_exemptions
+  # (no column is exempt: an exact deviation tie must give a legal window)
 
 
 @pytest.mark.parametrize("name", CASES)

@@ -1,0 +1,277 @@
+"""Round-3 GPU parity: what the round-2 review found unpinned.
+
+* the STEADY STATE of the study block (attack.py:861-868): the deque of past sampled averages full and its
+  oldest entry leaving, over nb_past + 5 iterations, for the single-call step (bm_step_worker), the
+  kernel-by-kernel sequence and the other momentum placements, against the independent loop of
+  tests/step_reference.py; and at C5 size against fp64 torch reductions of the deque itself;
+* STRUCTURED stacks through the default distance path (krum.py:41-63): rows with few distinct values (constant
+  + small noise, sign, int8-quantised, top-1 % sparsified with exact zeros) at the lengths where the two-plane
+  split of gram_bf16.hip is in use, every squared distance within 1e-5 of fp64 direct differences;
+* Aksel (aksel.py:35-64) and CGE (cge.py:28-57) at C2 size against fp64 torch on the same GPU.
+Needs an MI355X: `pytest -m gpu`.
+"""
+
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import gar_oracle as O
+from tests.golden_io import same_bits
+from tests.test_gpu_parity_r2 import DEV, D_RESNET18, D_WRN, sqdist_f64_on_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bm():
+  import byzantinemomentum_amd
+  byzantinemomentum_amd._lib.load()
+  return byzantinemomentum_amd
+
+
+# ---------------------------------------------------------------------------- #
+# Steady state of the curvature recurrence
+
+STEADY = [
+  dict(gar="krum", momentum_at="worker", single_call=True, clip=None, nb_past=3),
+  dict(gar="krum", momentum_at="worker", single_call=False, clip=None, nb_past=3),
+  dict(gar="median", momentum_at="worker", single_call=True, clip=100.0, nb_past=2),
+  dict(gar="bulyan", momentum_at="worker", single_call=True, clip=None, nb_past=1),
+  dict(gar="trmean", momentum_at="server", single_call=False, clip=None, nb_past=3),
+  dict(gar="median", momentum_at="update", single_call=False, clip=95.0, nb_past=4),
+]
+
+
+@pytest.mark.parametrize("cfg", STEADY, ids=lambda c: f"{c['gar']}-{c['momentum_at']}-{'one' if c['single_call'] else 'seq'}"
+                                                      f"-past{c['nb_past']}-clip{c['clip']}")
+def test_step_steady_state_against_reference_loop(bm, cfg):
+  """nb_past + 5 iterations: the deque is full from iteration nb_past on, and from nb_past + 1 on the
+  curvature seen by floats() depends on the entry that LEFT being removed with the right weight
+  (step.py `oldest_weight`, step_call.hip).  The sampled averages share a persistent component, so every
+  term of mu * sum_i mu^i <s, past_i> is large and of the same sign: a wrong weight on one of them is a
+  relative error of order 1/nb_past, not something a tolerance hides."""
+  from byzantinemomentum_amd.step import AggregationStep
+  from tests.step_reference import ReferenceLoop, assert_floats_close
+  n, f, d, mu = 11, 2, 30011, 0.9
+  h = n - f
+  P = cfg["nb_past"]
+  step = AggregationStep(n, f, f, gar=cfg["gar"], momentum=mu, dampening=0.9, momentum_at=cfg["momentum_at"],
+                         attack="empire", attack_factor=1.1, nb_past=P, gradient_clip=cfg["clip"],
+                         single_call=cfg["single_call"])
+  assert step.single_call == cfg["single_call"]
+  ref = ReferenceLoop(n, f, f, cfg["gar"], cfg["momentum_at"], mu, 0.9, "empire", 1.1, cfg["clip"], P)
+  gen = torch.Generator().manual_seed(2025)
+  origin = torch.randn(d, generator=gen)
+  params = origin.clone()
+  drift = 0.3 * torch.randn(d, generator=gen)   # persistent across steps: <s_t, s_u> ~ 0.09 d for every t, u
+  curvs = []
+  for it in range(P + 5):
+    base = drift + 0.1 * torch.randn(d, generator=gen)
+    sampled = [base + (0.5 + 0.1 * i) * torch.randn(d, generator=gen) for i in range(h)]
+    want_def, want_upd, want = ref.step(sampled, params, origin)
+    got_def = step.run([g.to(DEV) for g in sampled], params.to(DEV), origin.to(DEV))
+    scale = float(torch.stack(sampled).abs().max())
+    assert float((got_def.cpu() - want_def).abs().max()) <= 4e-6 * scale, (cfg, it)
+    assert float((step.update_gradient().cpu() - want_upd).abs().max()) <= 4e-6 * scale, (cfg, it)
+    if it != P:  # one skipped read in the middle: the recurrence must advance whether or not floats() is called
+      got = step.floats()
+      assert_floats_close(got, want, tag=(cfg, it), tol=1e-5)
+      if it >= 1:
+        assert abs(got["curv_sampled"] - want["curv_sampled"]) <= 1e-5 * abs(want["curv_sampled"]), (cfg, it)
+        curvs.append(want["curv_sampled"])
+    params = params - 0.05 * want_upd
+  # the test is meaningful: the curvature is dominated by the persistent component (~ mu * sum mu^i * 0.09 d)
+  full = mu * sum(mu ** i for i in range(P)) * 0.09 * d
+  assert curvs[-1] > 0.5 * full, (curvs[-1], full)
+
+
+def test_full_size_c5_steady_state_curvature(bm):
+  """BASELINE config 5 on one GPU (d = 36 546 980, n = 25, f = 5, worker momentum, the single-call step) with
+  nb_past = 3 for 7 steps: cosin_sampled and curv_sampled against fp64 dot products with the deque of past
+  sampled averages kept by the TEST (attack.py:861-868, computed term by term, no recurrence), momentum buffers
+  against torch's own mul_/add_."""
+  from byzantinemomentum_amd.step import AggregationStep
+  n, f, d, mu, damp, P = 25, 5, D_WRN, 0.99, 0.99, 3
+  h = n - f
+  gen = torch.Generator(device=DEV).manual_seed(78)
+  drift = 0.1 * torch.randn(d, device=DEV, generator=gen)
+  step = AggregationStep(n, f, f, gar="median", momentum=mu, dampening=damp, attack_factor=1.1, nb_past=P)
+  assert step.single_call
+  ref_bufs = [torch.zeros(d, device=DEV) for _ in range(h)]
+  pasts = []  # newest first
+  sigmas = torch.linspace(0.5, 1.5, h).tolist()
+  for it in range(P + 4):
+    sampled = [drift + s * torch.randn(d, device=DEV, generator=gen) for s in sigmas]
+    step.run(sampled)
+    got = step.floats()
+    for b, g in zip(ref_bufs, sampled):
+      b.mul_(mu).add_(g, alpha=1.0 - damp)
+    if it in (0, P + 3):
+      for a, b in zip(step.buffers, ref_bufs):
+        assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+    s_avg = sampled[0].clone()
+    for r in sampled[1:]:
+      s_avg.add_(r)
+    s_avg.div_(h)
+    s64 = s_avg.double()
+    if pasts:
+      want_cos = float(torch.dot(s64, pasts[0])) / math.sqrt(float(s64.pow(2).sum())) / \
+          math.sqrt(float(pasts[0].pow(2).sum()))
+      assert abs(got["cosin_sampled"] - want_cos) <= 1e-5, (it, got["cosin_sampled"], want_cos)
+      want_curv = mu * sum(mu ** i * float(torch.dot(s64, p)) for i, p in enumerate(pasts))
+      assert abs(got["curv_sampled"] - want_curv) <= 1e-5 * abs(want_curv), (it, got["curv_sampled"], want_curv)
+    else:
+      assert math.isnan(got["cosin_sampled"]) and math.isnan(got["curv_sampled"])
+    pasts.insert(0, s64)
+    del pasts[P:]
+    del sampled, s_avg
+
+
+# ---------------------------------------------------------------------------- #
+# Structured stacks through the default distance path
+
+def structured_stack(kind, n, f, d, seed):
+  """Honest rows of few distinct values / low entropy, f aliased Byzantine rows (= -0.1 mean of the honest ones,
+  the "empire" vector).  Generated on the GPU; the fp32 values ARE the inputs (quantisation happens before)."""
+  gen = torch.Generator(device=DEV).manual_seed(seed)
+  h = n - f
+  randn = lambda: torch.randn(d, device=DEV, generator=gen)  # noqa: E731
+  wts = torch.linspace(0.5, 2.0, h).tolist()
+  if kind == "const+noise":          # w_i * 1 + 1e-3 randn
+    honest = [w + 1e-3 * randn() for w in wts]
+  elif kind == "const_close_pair":   # two rows 7 % apart (a pair just above the accuracy gate), the rest spread out
+    wts[1] = wts[0] * 1.07
+    honest = [w + 1e-4 * randn() for w in wts]
+  elif kind == "const":              # exactly constant rows
+    honest = [torch.full((d,), w, device=DEV) for w in wts]
+  elif kind == "sign":               # 1-bit gradients: +-s_i
+    honest = [(0.0123 * w) * torch.sign(randn()) for w in wts]
+  elif kind == "int8":               # symmetric 8-bit quantisation of mu + sigma_i randn
+    mu = 0.1 * randn()
+    honest = []
+    for w in wts:
+      g = mu + w * randn()
+      scale = float(g.abs().max()) / 127.0
+      honest.append(torch.round(g / scale) * scale)
+  elif kind == "top1%":              # keep the largest 1 % of the entries, exact zeros elsewhere
+    mu = 0.1 * randn()
+    honest = []
+    for w in wts:
+      g = mu + w * randn()
+      k = d - d // 100
+      thr = float(torch.kthvalue(g.abs(), k).values)
+      honest.append(torch.where(g.abs() >= thr, g, torch.zeros_like(g)))
+  elif kind == "ternary":            # {-s, 0, +s}
+    honest = []
+    for w in wts:
+      g = randn()
+      honest.append((0.01 * w) * (torch.sign(g) * (g.abs() > 0.7)))
+  else:
+    raise ValueError(kind)
+  acc = torch.zeros(d, dtype=torch.float32, device=DEV)
+  for g in honest:
+    acc += g
+  byz = acc.div_(h).mul_(-0.1)
+  return honest + [byz] * f, h
+
+
+STRUCTURED = ["const+noise", "const_close_pair", "const", "sign", "int8", "top1%", "ternary"]
+
+
+@pytest.mark.parametrize("d", [(1 << 20) + 192, 2500003, D_RESNET18], ids=lambda d: f"d{d}")
+@pytest.mark.parametrize("kind", STRUCTURED)
+def test_structured_stacks_default_distance_path(bm, kind, d):
+  """Every squared distance within 1e-5 (relative to itself) of fp64 direct differences on the same GPU, and
+  the Multi-Krum / Bulyan selections equal to the oracle's ranking logic on those fp64 distances wherever the
+  fp64 scores themselves separate the sets by more than the tolerance."""
+  n, f = (25, 5) if d != 2500003 else (51, 12)
+  rows, h = structured_stack(kind, n, f, d, seed=99)
+  want = sqdist_f64_on_gpu(rows)
+  sq = bm.gars.pairwise_sqdist(rows).cpu().numpy()
+  assert np.array_equal(sq, sq.T) and not sq.diagonal().any()
+  pos = want > 0
+  assert not sq[~pos].any(), "bitwise-equal rows must give an exact zero"
+  rel = np.abs(sq - want)[pos] / want[pos]
+  assert rel.max() <= 1e-5, f"{kind}, d={d}: worst relative error of a squared distance {rel.max():.2e}"
+  for a in range(h + 1, n):  # aliased Byzantine rows: bitwise-equal rows of the matrix
+    assert np.array_equal(sq[h, :h], sq[a, :h])
+  m = n - f - 2
+  scores = O.krum_scores(np.sqrt(want), f)
+  order = O._stable_order(scores)
+  srt = sorted(scores)
+  if srt[m] - srt[m - 1] > 1e-5 * srt[m]:
+    assert sorted(bm.gars.krum_selection(rows, f)) == sorted(order[:m]), kind
+  theta = n - 2 * f - 2
+  if theta >= 1:
+    bscores = [O._sum_smallest([math.sqrt(want[i, j]) for j in range(n) if j != i], m) for i in range(n)]
+    border = O._stable_order(bscores)
+    bsrt = sorted(bscores)
+    if bsrt[m] - bsrt[m - 1] > 1e-5 * bsrt[m]:
+      assert sorted(bm.gars.bulyan_ranking(rows, f)[:m]) == sorted(border[:m]), kind
+
+
+def test_structured_stack_sharded_plan_follows_total_length(bm):
+  """A shard of 2^17 coordinates of a 2^20-coordinate job takes the precision plan of the whole job
+  (bm_pairwise_sqdist_shard): the partial matrices of the 8 shards add up to the unsharded matrix within the
+  fp64 rounding of the sum, on a stack where the two plans differ measurably (constant rows)."""
+  n, f, d, P = 13, 3, 1 << 20, 8
+  rows, h = structured_stack("const+noise", n, f, d, seed=5)
+  whole = bm.gars.pairwise_sqdist(rows).cpu().numpy()
+  per = d // P
+  acc = np.zeros((n, n))
+  for p in range(P):
+    acc += bm.gars.pairwise_sqdist([r[p * per:(p + 1) * per] for r in rows], d_total=d).cpu().numpy()
+  want = sqdist_f64_on_gpu(rows)
+  pos = want > 0
+  assert (np.abs(acc - want)[pos] / want[pos]).max() <= 1e-5
+  assert (np.abs(acc - whole)[pos] / want[pos]).max() <= 1e-6
+
+
+# ---------------------------------------------------------------------------- #
+# Aksel and CGE at C2 size
+
+def test_full_size_aksel_and_cge_against_fp64(bm):
+  n, f, d = 25, 5, D_RESNET18
+  gen = torch.Generator(device=DEV).manual_seed(404)
+  mu = 0.1 * torch.randn(d, device=DEV, generator=gen)
+  h = n - f
+  honest = [mu + s * torch.randn(d, device=DEV, generator=gen) for s in torch.linspace(0.5, 1.5, h).tolist()]
+  acc = torch.zeros(d, device=DEV)
+  for g in honest:
+    acc += g
+  rows = honest + [acc.div_(h).mul_(-0.1)] * f
+  # Aksel (aksel.py:35-48): squared distances to the coordinate-wise (lower) median, fp64 on the same GPU
+  med = torch.stack(rows).median(dim=0).values
+  sq64 = [float((r.double() - med.double()).pow(2).sum()) for r in rows]
+  got_sq = bm.gars.aksel_sqdist(rows)[:n].cpu().tolist()
+  for a, b in zip(got_sq, sq64):
+    assert abs(a - b) <= 1e-5 * b
+  for a in range(h + 1, n):
+    assert got_sq[a] == got_sq[h]  # aliased rows: exact ties
+  order = O._stable_order(sq64)
+  for mode, count in (("mid", (n + 1) // 2), ("n-f", n - f)):
+    sel = bm.gars.aksel_selection(rows, f, mode)
+    srt = sorted(sq64)
+    assert srt[count] - srt[count - 1] > 1e-5 * srt[count]
+    assert sorted(sel) == sorted(order[:count]), mode
+    ref = torch.zeros(d, device=DEV)
+    for i in sel:   # torch's own sequential fp32 sum in the order the rule used (aksel.py:64)
+      ref = ref + rows[i]
+    assert same_bits(bm.aksel(rows, f, mode), ref.cpu().div_(count)), mode
+  # CGE (cge.py:28-57): rows by increasing norm, mean of the n - f smallest
+  norms = [math.sqrt(float(r.double().pow(2).sum())) for r in rows]
+  corder = O._stable_order(norms)
+  keep = n - f
+  sel = bm.gars.cge_selection(rows, f)[:keep].cpu().tolist()
+  srt = sorted(norms)
+  assert srt[keep] - srt[keep - 1] > 1e-5 * srt[keep]
+  assert sorted(sel) == sorted(corder[:keep])
+  byz = [i for i in sel if i >= h]
+  assert byz == sorted(byz)  # tied rows in index order (stable)
+  ref = rows[sel[0]].clone()
+  for i in sel[1:]:
+    ref.add_(rows[i])
+  assert same_bits(bm.cge(rows, f), ref.cpu().div_(keep))
