@@ -16,13 +16,14 @@ import torch  # noqa: F401  (must be imported before the CDLL, see above)
 _PKG_DIR = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _PKG_DIR / "libbm_gar.so"
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_ROWS = 64
 EINVAL = -100000
 ENOCOMM, ECOMM = -100001, -100002
 
 OP_MEDIAN, OP_TRMEAN, OP_PHOCAS, OP_MEAMED = 0, 1, 2, 3
-WS_PAIRWISE, WS_AKSEL, WS_STATS, WS_DOT, WS_STEP = 0, 1, 2, 3, 4
+WS_PAIRWISE, WS_AKSEL, WS_STATS, WS_DOT, WS_STEP, WS_STUDY = 0, 1, 2, 3, 4, 5
+STUDY_SLOTS = 32
 RANK_KRUM, RANK_BULYAN = 0, 1
 ATTACK_EMPIRE, ATTACK_LITTLE, ATTACK_DIRECTION = 0, 1, 16
 
@@ -52,6 +53,10 @@ SIGNATURES = {
                                     ctypes.c_void_p]),
   "bm_multi_dot": (ctypes.c_int, [_c_float_pp, ctypes.c_int, _c_float_pp, ctypes.c_int, ctypes.c_int64,
                                   ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+  "bm_study_stats": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                    ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                    ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
   "bm_stable_argsort": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
   "bm_multi_axpby": (ctypes.c_int, [_c_float_pp, _c_float_pp, ctypes.c_int, ctypes.c_int64,
                                     ctypes.c_float, ctypes.c_float, ctypes.c_void_p]),

@@ -261,9 +261,7 @@ struct Tuning {
   int step_stream;     // BM_STEP_STREAM: 0 (default) register-resident form of bm_momentum_stats up to 20 rows, streaming above; 1 = streaming form at every size
   int result_nt;       // BM_RESULT_NT: 1 (default) non-temporal stores for result vectors, 0 = default cache policy (experiments)
   int col_ablate;      // BM_COL_ABLATE: 1 = median/trmean at n=25 without the output store (experiment)
-  int step_store;      // BM_STEP_STORE: 0 non-temporal buffer stores (default), 1 plain stores (experiments)
-  int step_blocks;     // BM_STEP_BLOCKS: grid cap of bm_momentum_stats, 0 = default
-  int step_vec;        // BM_STEP_VEC: 0 (default) automatic, 1/2/4 cap the vector width of bm_momentum_stats (experiments)
+  int step_burst;      // BM_STEP_BURST: iterations per CU from which bm_momentum_stats takes its burst form (default 8; 0 = never)
   int pair_dither;     // BM_PAIR_DITHER (mode 0, two planes): seed of the coordinate dither (default 0); -1 = no dither, round to nearest (experiments)
   double pair_tau;     // BM_PAIR_TAU: accuracy gate of the Gram modes (see gram_to_sqdist_kernel); <= 0 disables
 };

@@ -408,6 +408,10 @@ extern "C" int bm_aksel_pass1(const float* const* rows, int n, int64_t d, float*
                         sq_out, static_cast<double*>(ws), static_cast<hipStream_t>(stream));
 }
 
+namespace bm {
+int64_t study_workspace_bytes();  // study.hip
+}
+
 extern "C" int64_t bm_workspace_bytes(int kind, int n, int64_t d) {
   using namespace bm;
   if (n < 1 || n > BM_MAX_ROWS) return BM_EINVAL;
@@ -422,6 +426,8 @@ extern "C" int64_t bm_workspace_bytes(int kind, int n, int64_t d) {
       return (int64_t)1025 * 42 * (int64_t)sizeof(double);
     case BM_WS_STEP:
       return (int64_t)16385 * 6 * (int64_t)sizeof(double);  // kStepMaxBlocks + 1 sets of 6 partials (step.hip)
+    case BM_WS_STUDY:
+      return study_workspace_bytes();
     default:
       return BM_EINVAL;
   }

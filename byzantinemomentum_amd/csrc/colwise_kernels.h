@@ -6,6 +6,40 @@ namespace bm {
 
 constexpr int kColBlock = 256;
 
+// Sum of the sorted ranks F .. N-F-1 in ascending order from 0, every register index static.
+template <int N, int F>
+__device__ __forceinline__ float trimmed_sum_static(const float (&x)[N]) {
+  float t = 0.0f;
+#pragma unroll
+  for (int i = F; i < N - F; ++i) t += x[i];
+  return t;
+}
+
+// The same for a wave-uniform run-time f: a scalar branch to the unrolled sum of that f.  (Written as
+// `if (i >= f && i < N - f) t += x[i]` the compiler hoists the 2N rank predicates out of the column loop and
+// keeps them in SGPRs: 22 of them spilled to VGPR lanes in the n = 25 burst kernel, which sits at its 128-VGPR
+// limit.)  f outside 0 .. (N-1)/2 is refused by the host.
+template <int N>
+__device__ __forceinline__ float trimmed_sum(const float (&x)[N], int f) {
+  float t = 0.0f;
+  switch (f) {
+#define BM_TRIM_CASE(F)                                             \
+  case F:                                                           \
+    if constexpr (2 * (F) < N) t = trimmed_sum_static<N, (F)>(x);   \
+    break;
+    BM_TRIM_CASE(0) BM_TRIM_CASE(1) BM_TRIM_CASE(2) BM_TRIM_CASE(3) BM_TRIM_CASE(4) BM_TRIM_CASE(5) BM_TRIM_CASE(6)
+    BM_TRIM_CASE(7) BM_TRIM_CASE(8) BM_TRIM_CASE(9) BM_TRIM_CASE(10) BM_TRIM_CASE(11) BM_TRIM_CASE(12)
+    BM_TRIM_CASE(13) BM_TRIM_CASE(14) BM_TRIM_CASE(15) BM_TRIM_CASE(16) BM_TRIM_CASE(17) BM_TRIM_CASE(18)
+    BM_TRIM_CASE(19) BM_TRIM_CASE(20) BM_TRIM_CASE(21) BM_TRIM_CASE(22) BM_TRIM_CASE(23) BM_TRIM_CASE(24)
+    BM_TRIM_CASE(25) BM_TRIM_CASE(26) BM_TRIM_CASE(27) BM_TRIM_CASE(28) BM_TRIM_CASE(29) BM_TRIM_CASE(30)
+    BM_TRIM_CASE(31)
+#undef BM_TRIM_CASE
+    default:
+      break;
+  }
+  return t;
+}
+
 // Per-column rule on N register-resident values.  `lds` points at this lane's slot of a
 // [N][kColBlock] scratch array (only used by the closest-to-centre rules).
 template <int N, int OP>
@@ -36,11 +70,7 @@ __device__ __forceinline__ float column_rule(float (&x)[N], int f, float inv_kee
     sort_network<N>(x);
     // trimmed mean: ranks f .. N-f-1, summed in ascending order
     float tsum = 0.0f;
-    if constexpr (OP == BM_OP_TRMEAN || OP == BM_OP_PHOCAS) {
-#pragma unroll
-      for (int i = 0; i < N; ++i)
-        if (i >= f && i < N - f) tsum += x[i];  // f is wave-uniform
-    }
+    if constexpr (OP == BM_OP_TRMEAN || OP == BM_OP_PHOCAS) tsum = trimmed_sum<N>(x, f);
     if constexpr (OP == BM_OP_TRMEAN) {
       const float r = div_small_int(tsum, (float)(N - 2 * f), inv_keep);
       return (nan_count > f) ? kNaN : r;

@@ -43,6 +43,7 @@
 //     krum.py:62 stable sort);
 //   * fp32 chains cover 32 coordinates, per-wave fp32 sums ~100 chunks, everything wider is fp64
 //     (workgroup, grid, GPUs) in a fixed order: deterministic, no atomics.
+#include <type_traits>
 #include "bm_common.h"
 
 namespace bm {
@@ -136,7 +137,8 @@ struct B3Shape {
   static constexpr int PS = N4 * kB3RowBytes;           // plane stride
   static constexpr int WS = NPL * PS;                   // wave region
   static constexpr int NSETS = (K <= 8 && (NPL == 2 || K * NPL <= 21)) ? 2 : 1;  // register sets of loads in flight
-  static constexpr int MINW = (K <= 8) ? 3 : 2;         // workgroups per CU aimed at
+  // workgroups per CU aimed at (K = 8 with the fp64 running sums of the two-plane form does not fit 168 VGPRs)
+  static constexpr int MINW = (K <= 7 || (K == 8 && NPL == 3)) ? 3 : 2;
   static constexpr int kPtrBytes = BM_MAX_ROWS * 8;
   static constexpr int kRedBytes = kB3Waves * 256 * 8;
   static constexpr int kLds = kPtrBytes + (kB3Waves * WS > kRedBytes ? kB3Waves * WS : kRedBytes);
@@ -176,9 +178,17 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
   const bool last_ok = (16 * (RB - 1) + li) < S::N4;
   const int rd_last0 = last_ok ? rd0 + (RB - 1) * 16 * kB3RowBytes : (lg << 4);
 
-  f32x4 outer[NP];
+  // Per-wave running sums of the chunk results.  Two planes (long vectors: a wave folds 85-280 chunks) keep them
+  // in fp64: an fp32 running sum of NEARLY EQUAL terms (rows with few distinct values: constant, quantised)
+  // rounds the same way at every step, the error grows like 2^-25 * chunks instead of averaging out (measured
+  // 3e-7 on G at d = 11.2 M with constant rows, i.e. 1.5e-4 on a squared distance that cancels 200-fold).  The
+  // three-plane form (d < 2^20: at most 8 chunks per wave) keeps fp32.
+  using Acc = typename std::conditional<NPL == 2, double, float>::type;
+  Acc outer[NP][4];
 #pragma unroll
-  for (int p = 0; p < NP; ++p) outer[p] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) outer[p][v] = (Acc)0;
 
   const int64_t nchunks = (d + kB3Chunk - 1) / kB3Chunk;
   const int64_t gw = (int64_t)blockIdx.x * kB3Waves + wave;
@@ -279,6 +289,11 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
   // Fragments of both 32-coordinate steps are read first; every block pair then runs its MFMAs of
   // both steps into the same three accumulators, which are folded into the per-wave fp32 sums once
   // per chunk (64 coordinates).
+  auto fold = [](Acc (&acc)[4], const f32x4 a0, const f32x4 a1, const f32x4 a2) {
+    const f32x4 t = a0 + (a1 + a2);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[v] += (Acc)t[v];
+  };
   auto multiply = [&]() {
     u32x4 fh[2][RB], fm[2][RB], fl[2][RB];
 #pragma unroll
@@ -316,13 +331,13 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
           s1 = mfma_bf16(fh[1][I], fl[1][J], s1);
           s2 = mfma_bf16(fl[1][I], fh[1][J], s2);
         }
-        if (p > 0) outer[p - 1] += q0 + (q1 + q2);
+        if (p > 0) fold(outer[p - 1], q0, q1, q2);
         q0 = s0;
         q1 = s1;
         q2 = s2;
         ++p;
       }
-    outer[NP - 1] += q0 + (q1 + q2);
+    fold(outer[NP - 1], q0, q1, q2);
   };
 
   // ---- main loop: loads of the next chunk(s) stay in flight under the MFMAs of this one ----

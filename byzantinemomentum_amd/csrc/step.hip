@@ -48,110 +48,139 @@ __device__ __forceinline__ float block_reduce_absmax(float m, float* lds) {
   return r;
 }
 
-// T = compile-time bound on max(ks, h); rows beyond ks / h are predicated off (wave-uniform).
-template <int T, int VEC, bool PLAIN_STORE = false>
-__global__ __launch_bounds__(kStepBlock) void momentum_stats_kernel(
-    StepTable tab, int ks, int h, int64_t nvec, float mu, float omd, const float* __restrict__ clipf,
+// Register-resident form (max(ks, h) <= T <= 20): the ks + h values of a column group stay in VGPRs, so the deviations
+// are two-pass (no cancellation) without re-reading anything.
+//   EXACT  ks == h == T: no row predicate is left in the code (the C5 shape: 20 sampled gradients, 20 buffers)
+//   CLIP   clipping factors present
+//   BURST  one workgroup of kStepBurstBlock lanes per CU, column groups interleaved across the CUs, and a workgroup
+//          barrier between the loads + arithmetic and the 23 stores of an iteration: the chip alternates between
+//          reading and writing instead of trickling writes between reads (scripts/probes/momentum_burst_probe.hip:
+//          1 740 -> 1 685 us on the bare stream of this shape; the results wait in registers, they do not fit the LDS)
+// Addressing: 32-bit byte offsets (the host cuts d into pieces below 2^32 bytes) on wave-uniform row pointers
+// (saddr form, no 64-bit VALU arithmetic).  The 2T row pointers are NOT kept in SGPRs across the loop (80 of them
+// at T = 20: round 2's kernel spilled 322 SGPRs to VGPR lanes): each use fetches its pointer from the kernarg
+// segment with a scalar load behind an opaque copy of the segment address, so nothing is hoisted.
+typedef const float* __attribute__((address_space(4))) const* KargRowPtrs;
+constexpr int kStepBurstBlock = 512;
+
+template <int T, int VEC, bool EXACT, bool CLIP, bool BURST>
+__global__ __launch_bounds__(BURST ? kStepBurstBlock : kStepBlock) void momentum_stats_kernel(
+    StepTable tab, int ks_rt, int h_rt, uint32_t nvec, float mu, float omd, const float* __restrict__ clipf,
     float* __restrict__ s_avg_out, float* __restrict__ h_avg_out, float* __restrict__ byz_out, float scale,
-    int attack_kind, int nt_result, double* __restrict__ partial) {
-  __shared__ double red[kStepBlock / 64];
-  __shared__ float mred[kStepBlock / 64];
-  const float fks = (float)ks, fh = (float)h;
+    int attack_kind, double* __restrict__ partial) {
+  constexpr int BLOCK = BURST ? kStepBurstBlock : kStepBlock;
+  __shared__ double red[BLOCK / 64];
+  __shared__ float mred[BLOCK / 64];
+  const float fks = (float)(EXACT ? T : ks_rt), fh = (float)(EXACT ? T : h_rt);
   float n2s = 0.0f, dvs = 0.0f, mxs = 0.0f, n2h = 0.0f, dvh = 0.0f, mxh = 0.0f;
   bool nan_s = false, nan_h = false;
-  // per-row clipping factors (attack.py:791-794): wave-uniform scalars
-  float cf[T];
-#pragma unroll
-  for (int i = 0; i < T; ++i) cf[i] = (clipf != nullptr && i < ks) ? clipf[i] : 1.0f;
-  const int64_t stride = (int64_t)gridDim.x * kStepBlock;
-  for (int64_t v = (int64_t)blockIdx.x * kStepBlock + threadIdx.x; v < nvec; v += stride) {
+  // the row tables are the first kernel argument: g[i] at byte 8 i, b[i] at byte 8 (BM_MAX_ROWS + i)
+  uint64_t kbase = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)tab;
+  const uint32_t span = gridDim.x * BLOCK;
+  const uint32_t iters = (nvec + span - 1) / span;
+  const uint32_t first = blockIdx.x * BLOCK + threadIdx.x;
+  for (uint32_t it = 0; it < iters; ++it) {
+    const uint32_t v = it * span + first;
+    const bool live = v < nvec;
+    const uint32_t off = v * (uint32_t)(VEC * sizeof(float));
     float g[T][VEC], b[T][VEC];
-#pragma unroll
-    for (int i = 0; i < T; ++i) {
-      if (i < ks) load_stream<VEC>(tab.g[i] + v * VEC, g[i]);
-      if (i < h) load_stream<VEC>(tab.b[i] + v * VEC, b[i]);
-    }
-    // clip, then momentum: gmtm.mul_(mu).add_(grad, alpha=1-damp) = fma(1-damp, grad, round(mu*gmtm))
-#pragma unroll
-    for (int i = 0; i < T; ++i) {
-      if (i < ks && clipf != nullptr) {
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) g[i][c] *= cf[i];
-      }
-      if (i < h) {
-#pragma unroll
-        for (int c = 0; c < VEC; ++c) b[i][c] = __builtin_fmaf(omd, g[i][c], mu * b[i][c]);
-        if constexpr (PLAIN_STORE) {
-          using TV = typename VecLoad<VEC>::T;
-          TV ov;
-          if constexpr (VEC == 1) {
-            ov = b[i][0];
-          } else {
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) ov[c] = b[i][c];
-          }
-          *reinterpret_cast<TV*>(tab.b[i] + v * VEC) = ov;
-        } else {
-          store_stream<VEC>(tab.b[i] + v * VEC, b[i]);
-        }
-      }
-    }
     float sa[VEC], ha[VEC], bz[VEC];
-#pragma unroll
-    for (int c = 0; c < VEC; ++c) {
-      // sampled stack: sequential mean, ||avg||^2, max|avg|, sum_i ||s_i - avg||^2 (tools/pytorch.py:105-125)
-      float s = g[0][c];
-#pragma unroll
-      for (int i = 1; i < T; ++i)
-        if (i < ks) s += g[i][c];
-      s = s / fks;
-      sa[c] = s;
-      n2s = __builtin_fmaf(s, s, n2s);
-      mxs = fmaxf(mxs, __builtin_fabsf(s));
-      nan_s |= (s != s);
-      float q = 0.0f;
-#pragma unroll
-      for (int i = 0; i < T; ++i)
-        if (i < ks) {
-          const float df = g[i][c] - s;
-          q = __builtin_fmaf(df, df, q);
-        }
-      dvs += q;
-      // honest stack = the updated momentum buffers
-      float t = b[0][c];
-#pragma unroll
-      for (int i = 1; i < T; ++i)
-        if (i < h) t += b[i][c];
-      t = t / fh;
-      ha[c] = t;
-      n2h = __builtin_fmaf(t, t, n2h);
-      mxh = fmaxf(mxh, __builtin_fabsf(t));
-      nan_h |= (t != t);
-      float qh = 0.0f;
-#pragma unroll
-      for (int i = 0; i < T; ++i)
-        if (i < h) {
-          const float df = b[i][c] - t;
-          qh = __builtin_fmaf(df, df, qh);
-        }
-      dvh += qh;
-      // empire: grad_att = grad_avg.neg();  little: grad_att = grad_stck.var(dim=0).sqrt_()
-      const float dir = ((attack_kind & 15) == BM_ATTACK_LITTLE) ? __builtin_sqrtf(qh / (fh - 1.0f)) : -t;
-      const float att = dir * scale;  // grad_att.mul_(factor)
-      bz[c] = (attack_kind & BM_ATTACK_DIRECTION) ? att : t + att;  // byz_grad = grad_avg.add_(grad_att)
+    asm volatile("" : "+s"(kbase));  // (outside the divergent region: the segment address stays wave-uniform)
+    // row counts: compile-time when EXACT, else per-iteration opaque copies (the 2T predicates are recomputed where
+    // they are used instead of living in SGPR pairs across the loop)
+    int ks = T, h = T;
+    if constexpr (!EXACT) {
+      ks = ks_rt;
+      h = h_rt;
+      asm volatile("" : "+s"(ks), "+s"(h));
     }
-    if (s_avg_out != nullptr) store_result_policy<VEC>(s_avg_out + v * VEC, sa, nt_result);
-    if (h_avg_out != nullptr) store_result_policy<VEC>(h_avg_out + v * VEC, ha, nt_result);
-    if (byz_out != nullptr) store_result_policy<VEC>(byz_out + v * VEC, bz, nt_result);
+    if (live) {
+      KargRowPtrs karg = (KargRowPtrs)kbase;
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
+        if (i < ks) load_stream_off<VEC>(karg[i], off, g[i]);
+        if (i < h) load_stream_off<VEC>(karg[BM_MAX_ROWS + i], off, b[i]);
+      }
+      // clip, then momentum: gmtm.mul_(mu).add_(grad, alpha=1-damp) = fma(1-damp, grad, round(mu*gmtm))
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
+        if constexpr (CLIP) {
+          if (i < ks) {
+            const float cf = clipf[i];  // wave-uniform scalar load (attack.py:791-794)
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) g[i][c] *= cf;
+          }
+        }
+        if (i < h) {
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) b[i][c] = __builtin_fmaf(omd, g[i][c], mu * b[i][c]);
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) {
+        // sampled stack: sequential mean, ||avg||^2, max|avg|, sum_i ||s_i - avg||^2 (tools/pytorch.py:105-125)
+        float s = g[0][c];
+#pragma unroll
+        for (int i = 1; i < T; ++i)
+          if (i < ks) s += g[i][c];
+        s = s / fks;
+        sa[c] = s;
+        n2s = __builtin_fmaf(s, s, n2s);
+        mxs = fmaxf(mxs, __builtin_fabsf(s));
+        nan_s |= (s != s);
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < T; ++i)
+          if (i < ks) {
+            const float df = g[i][c] - s;
+            q = __builtin_fmaf(df, df, q);
+          }
+        dvs += q;
+        // honest stack = the updated momentum buffers
+        float t = b[0][c];
+#pragma unroll
+        for (int i = 1; i < T; ++i)
+          if (i < h) t += b[i][c];
+        t = t / fh;
+        ha[c] = t;
+        n2h = __builtin_fmaf(t, t, n2h);
+        mxh = fmaxf(mxh, __builtin_fabsf(t));
+        nan_h |= (t != t);
+        float qh = 0.0f;
+#pragma unroll
+        for (int i = 0; i < T; ++i)
+          if (i < h) {
+            const float df = b[i][c] - t;
+            qh = __builtin_fmaf(df, df, qh);
+          }
+        dvh += qh;
+        // empire: grad_att = grad_avg.neg();  little: grad_att = grad_stck.var(dim=0).sqrt_()
+        const float dir = ((attack_kind & 15) == BM_ATTACK_LITTLE) ? __builtin_sqrtf(qh / (fh - 1.0f)) : -t;
+        const float att = dir * scale;  // grad_att.mul_(factor)
+        bz[c] = (attack_kind & BM_ATTACK_DIRECTION) ? att : t + att;  // byz_grad = grad_avg.add_(grad_att)
+      }
+    }
+    if constexpr (BURST) __syncthreads();  // not for the data: it is what turns the stores of a CU into one burst
+    asm volatile("" : "+s"(kbase));
+    if (live) {
+      KargRowPtrs karg = (KargRowPtrs)kbase;
+#pragma unroll
+      for (int i = 0; i < T; ++i)
+        if (i < h) store_stream_off<VEC>(const_cast<float*>(karg[BM_MAX_ROWS + i]), off, b[i]);
+      if (s_avg_out != nullptr) store_stream_off<VEC>(s_avg_out, off, sa);
+      if (h_avg_out != nullptr) store_stream_off<VEC>(h_avg_out, off, ha);
+      if (byz_out != nullptr) store_stream_off<VEC>(byz_out, off, bz);
+    }
   }
   if (nan_s) mxs = __builtin_nanf("");  // torch's abs().max() propagates NaN; fmaxf does not
   if (nan_h) mxh = __builtin_nanf("");
-  const double r0 = block_reduce_sum<kStepBlock>((double)n2s, red);
-  const double r1 = block_reduce_sum<kStepBlock>((double)dvs, red);
-  const double r3 = block_reduce_sum<kStepBlock>((double)n2h, red);
-  const double r4 = block_reduce_sum<kStepBlock>((double)dvh, red);
-  const float r2 = block_reduce_absmax<kStepBlock>(mxs, mred);
-  const float r5 = block_reduce_absmax<kStepBlock>(mxh, mred);
+  const double r0 = block_reduce_sum<BLOCK>((double)n2s, red);
+  const double r1 = block_reduce_sum<BLOCK>((double)dvs, red);
+  const double r3 = block_reduce_sum<BLOCK>((double)n2h, red);
+  const double r4 = block_reduce_sum<BLOCK>((double)dvh, red);
+  const float r2 = block_reduce_absmax<BLOCK>(mxs, mred);
+  const float r5 = block_reduce_absmax<BLOCK>(mxh, mred);
   if (threadIdx.x == 0) {
     double* p = partial + (int64_t)blockIdx.x * 6;
     p[0] = r0;
@@ -172,43 +201,53 @@ __global__ __launch_bounds__(kStepBlock) void momentum_stats_kernel(
 //   sum_i (x_i - a)^2 = sum_i d_i^2 - 2 (a - p) sum_i d_i + k (a - p)^2,   d_i = x_i - p,
 // with a the (rounded, sequential) mean.  The pivot's own deviation (a - p)^2 is part of the result, hence
 // sum d_i^2 <= (k + 1) * result: the subtraction cancels at most a factor k + 1, never catastrophically.
-template <int T, int VEC>
+template <int T, int VEC, bool CLIP>
 __global__ __launch_bounds__(kStepBlock, 4) void momentum_stats_stream_kernel(
-    StepTable tab, int ks, int h, int64_t nvec, float mu, float omd, const float* __restrict__ clipf,
+    StepTable tab, int ks, int h, uint32_t nvec, float mu, float omd, const float* __restrict__ clipf,
     float* __restrict__ s_avg_out, float* __restrict__ h_avg_out, float* __restrict__ byz_out, float scale,
-    int attack_kind, int nt_result, double* __restrict__ partial) {
+    int attack_kind, double* __restrict__ partial) {
   __shared__ double red[kStepBlock / 64];
   __shared__ float mred[kStepBlock / 64];
   const float fks = (float)ks, fh = (float)h;
   float n2s = 0.0f, dvs = 0.0f, mxs = 0.0f, n2h = 0.0f, dvh = 0.0f, mxh = 0.0f;
   bool nan_s = false, nan_h = false;
-  float cf[T];
-#pragma unroll
-  for (int i = 0; i < T; ++i) cf[i] = (clipf != nullptr && i < ks) ? clipf[i] : 1.0f;
-  const int64_t stride = (int64_t)gridDim.x * kStepBlock;
+  // row pointers and clipping factors are fetched where they are used (scalar loads from the kernarg segment /
+  // the factor array, see momentum_stats_kernel): kept in SGPRs across the loop they were 278-1142 spilled SGPRs
+  uint64_t kbase = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)tab;
+  const uint32_t stride = gridDim.x * kStepBlock;
   constexpr int kBatch = 4;
-  for (int64_t v = (int64_t)blockIdx.x * kStepBlock + threadIdx.x; v < nvec; v += stride) {
+  for (uint32_t v = blockIdx.x * kStepBlock + threadIdx.x; v < nvec; v += stride) {
+    const uint32_t off = v * (uint32_t)(VEC * sizeof(float));
+    // per-iteration copies the compiler cannot see through: the 2T row predicates are recomputed where they are used
+    // instead of living in SGPR pairs across the loop
+    int ksl = ks, hl = h;
+    asm volatile("" : "+s"(ksl), "+s"(hl));
     float ps[VEC], ss[VEC], qs[VEC], ts[VEC];  // sampled: pivot, sequential sum, sum d^2, sum d
     float ph[VEC], sh[VEC], qh[VEC], th[VEC];  // honest
 #pragma unroll
     for (int base = 0; base < T; base += kBatch) {
-      if (base < ks) {  // wave-uniform
+      if (base < ksl) {  // wave-uniform
         float g[kBatch][VEC], b[kBatch][VEC];
+        asm volatile("" : "+s"(kbase));
+        KargRowPtrs karg = (KargRowPtrs)kbase;
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
           const int i = base + j;
-          load_stream<VEC>(tab.g[i] + v * VEC, g[j]);  // entries >= ks repeat the last row (host-side padding)
-          if (base < h) load_stream<VEC>(tab.b[i] + v * VEC, b[j]);
+          load_stream_off<VEC>(karg[i], off, g[j]);  // entries >= ks repeat the last row (host-side padding)
+          if (base < hl) load_stream_off<VEC>(karg[BM_MAX_ROWS + i], off, b[j]);
         }
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
           const int i = base + j;
           // branch-free arithmetic (rows that do not exist are masked with wave-uniform selects): a load
           // whose only use sits behind a branch would be sunk into it and lose its place in the batch
-          const bool on_s = i < ks, on_h = i < h;
+          const bool on_s = i < ksl, on_h = i < hl;
+          float cfi = 1.0f;
+          if constexpr (CLIP) cfi = clipf[i < ksl ? i : ksl - 1];  // wave-uniform scalar load
 #pragma unroll
           for (int c = 0; c < VEC; ++c) {
-            const float gv = g[j][c] * cf[i < T ? i : T - 1];
+            const float gv = CLIP ? g[j][c] * cfi : g[j][c];
             if (i == 0) {
               ps[c] = gv;
               ss[c] = gv;
@@ -222,10 +261,10 @@ __global__ __launch_bounds__(kStepBlock, 4) void momentum_stats_stream_kernel(
             }
             g[j][c] = gv;
           }
-          if (base < h) {  // wave-uniform, the loads of b sit in the same region
+          if (base < hl) {  // wave-uniform, the loads of b sit in the same region
 #pragma unroll
             for (int c = 0; c < VEC; ++c) b[j][c] = __builtin_fmaf(omd, g[j][c], mu * b[j][c]);
-            if (on_h) store_stream<VEC>(tab.b[i] + v * VEC, b[j]);
+            if (on_h) store_stream_off<VEC>(const_cast<float*>(karg[BM_MAX_ROWS + i]), off, b[j]);
 #pragma unroll
             for (int c = 0; c < VEC; ++c) {
               const float bv = b[j][c];
@@ -268,9 +307,9 @@ __global__ __launch_bounds__(kStepBlock, 4) void momentum_stats_stream_kernel(
       const float att = dir * scale;
       r_bz[c] = (attack_kind & BM_ATTACK_DIRECTION) ? att : t + att;
     }
-    if (s_avg_out != nullptr) store_result_policy<VEC>(s_avg_out + v * VEC, r_sa, nt_result);
-    if (h_avg_out != nullptr) store_result_policy<VEC>(h_avg_out + v * VEC, r_ha, nt_result);
-    if (byz_out != nullptr) store_result_policy<VEC>(byz_out + v * VEC, r_bz, nt_result);
+    if (s_avg_out != nullptr) store_stream_off<VEC>(s_avg_out, off, r_sa);
+    if (h_avg_out != nullptr) store_stream_off<VEC>(h_avg_out, off, r_ha);
+    if (byz_out != nullptr) store_stream_off<VEC>(byz_out, off, r_bz);
   }
   if (nan_s) mxs = __builtin_nanf("");
   if (nan_h) mxh = __builtin_nanf("");
@@ -351,48 +390,73 @@ __global__ __launch_bounds__(kFinishThreads) void step_finish_kernel(const doubl
   }
 }
 
+template <int T, int VEC, bool EXACT, bool CLIP>
+static int launch_momentum_stats_form(const StepTable& tab, int ks, int h, int64_t nvec, float mu, float omd,
+                                      const float* clipf, float* s_avg, float* h_avg, float* byz, float scale,
+                                      int kind, double* partial, int* grid_io, hipStream_t s) {
+  // burst form: one workgroup per CU, once every CU has BM_STEP_BURST (default 8) iterations to alternate over
+  const int cus = compute_units();
+  const int64_t burst_iters = nvec / ((int64_t)cus * kStepBurstBlock);
+  if (tuning().step_burst > 0 && burst_iters >= tuning().step_burst && cus < *grid_io) {
+    *grid_io = cus;
+    hipLaunchKernelGGL((momentum_stats_kernel<T, VEC, EXACT, CLIP, true>), dim3(cus), dim3(kStepBurstBlock), 0, s, tab,
+                       ks, h, (uint32_t)nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial);
+  } else {
+    hipLaunchKernelGGL((momentum_stats_kernel<T, VEC, EXACT, CLIP, false>), dim3(*grid_io), dim3(kStepBlock), 0, s, tab,
+                       ks, h, (uint32_t)nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial);
+  }
+  BM_LAUNCH_CHECK();
+  return 0;
+}
+
+// *grid_io: in = the grid of the plain form, out = the number of workgroups launched (= partial sets written)
 template <int T, int VEC>
 static int launch_momentum_stats(const StepTable& tab, int ks, int h, int64_t nvec, float mu, float omd,
                                  const float* clipf, float* s_avg, float* h_avg, float* byz, float scale, int kind,
-                                 double* partial, int grid, hipStream_t s) {
-  if (tuning().step_store == 1)
-    hipLaunchKernelGGL((momentum_stats_kernel<T, VEC, true>), dim3(grid), dim3(kStepBlock), 0, s, tab, ks, h, nvec, mu,
-                       omd, clipf, s_avg, h_avg, byz, scale, kind, tuning().result_nt, partial);
-  else
-    hipLaunchKernelGGL((momentum_stats_kernel<T, VEC>), dim3(grid), dim3(kStepBlock), 0, s, tab, ks, h, nvec, mu, omd,
-                       clipf, s_avg, h_avg, byz, scale, kind, tuning().result_nt, partial);
-  BM_LAUNCH_CHECK();
-  return 0;
+                                 double* partial, int* grid_io, hipStream_t s) {
+#define BM_STEP_FORM(EX, CL) \
+  launch_momentum_stats_form<T, VEC, EX, CL>(tab, ks, h, nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial, grid_io, s)
+  const bool exact = (ks == T && h == T);
+  if constexpr (T > 12) {  // with row predicates the 2 x 20 x VEC values no longer fit: the dispatcher sends those shapes elsewhere
+    if (!exact) return BM_EINVAL;
+    return clipf != nullptr ? BM_STEP_FORM(true, true) : BM_STEP_FORM(true, false);
+  } else {
+    if (clipf != nullptr) return exact ? BM_STEP_FORM(true, true) : BM_STEP_FORM(false, true);
+    return exact ? BM_STEP_FORM(true, false) : BM_STEP_FORM(false, false);
+  }
+#undef BM_STEP_FORM
 }
 
 template <int T, int VEC>
 static int launch_momentum_stats_stream(const StepTable& tab, int ks, int h, int64_t nvec, float mu, float omd,
                                         const float* clipf, float* s_avg, float* h_avg, float* byz, float scale,
-                                        int kind, double* partial, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((momentum_stats_stream_kernel<T, VEC>), dim3(grid), dim3(kStepBlock), 0, s, tab, ks, h, nvec,
-                     mu, omd, clipf, s_avg, h_avg, byz, scale, kind, tuning().result_nt, partial);
+                                        int kind, double* partial, int* grid_io, hipStream_t s) {
+  if (clipf != nullptr)
+    hipLaunchKernelGGL((momentum_stats_stream_kernel<T, VEC, true>), dim3(*grid_io), dim3(kStepBlock), 0, s, tab, ks, h,
+                       (uint32_t)nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial);
+  else
+    hipLaunchKernelGGL((momentum_stats_stream_kernel<T, VEC, false>), dim3(*grid_io), dim3(kStepBlock), 0, s, tab, ks, h,
+                       (uint32_t)nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial);
   BM_LAUNCH_CHECK();
   return 0;
 }
 
-// Tiers by max(ks, h): the register-resident form holds 2 * T * VEC values per lane (T <= 20), the
-// streaming form takes over above.
+// Forms by (ks, h): the register-resident kernel holds 2 * T * VEC values per lane; without row predicates (ks == h == T,
+// T = 8, 12, 20) it fits two waves per SIMD up to T = 20, with them up to T = 12; every other shape takes the streaming
+// form, whose footprint does not depend on the number of rows.
 template <int VEC>
 static int dispatch_momentum_stats(const StepTable& tab, int ks, int h, int64_t nvec, float mu, float omd,
                                    const float* clipf, float* s_avg, float* h_avg, float* byz, float scale, int kind,
-                                   double* partial, int grid, hipStream_t s) {
+                                   double* partial, int* grid_io, hipStream_t s) {
   const int t = ks > h ? ks : h;
-#define BM_STEP_ARGS tab, ks, h, nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial, grid, s
-  // BM_STEP_STREAM: 0 (default) register-resident form up to 20 rows, 1 = streaming form at every size,
-
-  const int form = tuning().step_stream;
-  if (form != 1) {
+#define BM_STEP_ARGS tab, ks, h, nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial, grid_io, s
+  // BM_STEP_STREAM=1: the streaming form at every size (tests, experiments)
+  if (tuning().step_stream != 1) {
     if (t <= 8) return launch_momentum_stats<8, VEC>(BM_STEP_ARGS);
     if (t <= 12) return launch_momentum_stats<12, VEC>(BM_STEP_ARGS);
-    if (t <= 20) return launch_momentum_stats<20, VEC>(BM_STEP_ARGS);
-  } else {
-    if (t <= 20) return launch_momentum_stats_stream<20, VEC>(BM_STEP_ARGS);
+    if (ks == 20 && h == 20) return launch_momentum_stats<20, VEC>(BM_STEP_ARGS);
   }
+  if (t <= 20) return launch_momentum_stats_stream<20, VEC>(BM_STEP_ARGS);
   if (t <= 40) return launch_momentum_stats_stream<40, VEC>(BM_STEP_ARGS);
   return launch_momentum_stats_stream<64, VEC>(BM_STEP_ARGS);
 #undef BM_STEP_ARGS
@@ -491,40 +555,50 @@ extern "C" int bm_momentum_stats(const float* const* sampled, int ks, float* con
   for (int i = ks; i < BM_MAX_ROWS; ++i) tab.g[i] = sampled[ks - 1];
   for (int i = h; i < BM_MAX_ROWS; ++i) tab.b[i] = buffers[h - 1];
   double* partial = static_cast<double*>(ws);
-  int vec = vec_of(bits);
-  const int t = ks > h ? ks : h;
-  if (tuning().step_vec > 0 && vec > tuning().step_vec) vec = tuning().step_vec;
-  (void)t;  // above 20 rows the streaming form keeps VEC at any row count
+  const int vec = vec_of(bits);
+  // pieces of at most 2^29 coordinates: byte offsets fit 32 bits inside the register-resident kernel
+  const int64_t pieces = d > 0 ? (d + kMaxColsPerLaunch - 1) / kMaxColsPerLaunch : 0;
+  int cap = pieces > 1 ? (int)((kStepMaxBlocks - 1) / pieces) - 1 : 2047;
+  if (cap > 2047) cap = 2047;
+  if (cap < 1) return BM_EINVAL;  // d >= 2^42: not a gradient
   int nparts = 0;
-  int64_t body = 0;
   int rc = 0;
-  if (vec >= 2 && d / vec > 0) {
-    const int64_t nvec = d / vec;
-    int cap = tuning().step_blocks > 0 ? tuning().step_blocks : 2047;
-    if (cap > kStepMaxBlocks - 1) cap = kStepMaxBlocks - 1;
-    const int grid = stream_grid(nvec, kStepBlock, cap);
-    rc = (vec == 4) ? dispatch_momentum_stats<4>(tab, ks, h, nvec, mu, one_minus_damp, clip_factors, sampled_avg,
-                                                  honest_avg, byz_out, scale, attack_kind, partial, grid, s)
-                    : dispatch_momentum_stats<2>(tab, ks, h, nvec, mu, one_minus_damp, clip_factors, sampled_avg,
-                                                  honest_avg, byz_out, scale, attack_kind, partial, grid, s);
-    if (rc != 0) return rc;
-    nparts = grid;
-    body = nvec * vec;
-  }
-  if (body < d) {
-    StepTable tail = tab;
+  for (int64_t lo = 0; lo < d; lo += kMaxColsPerLaunch) {
+    const int64_t dp = (d - lo < kMaxColsPerLaunch) ? (d - lo) : kMaxColsPerLaunch;
+    StepTable piece = tab;
     for (int i = 0; i < BM_MAX_ROWS; ++i) {
-      tail.g[i] += body;
-      tail.b[i] += body;
+      piece.g[i] += lo;
+      piece.b[i] += lo;
     }
-    const int64_t rest = d - body;
-    const int grid = (body == 0) ? stream_grid(rest, kStepBlock, 2048) : 1;
-    rc = dispatch_momentum_stats<1>(tail, ks, h, rest, mu, one_minus_damp, clip_factors,
-                                    sampled_avg ? sampled_avg + body : nullptr,
-                                    honest_avg ? honest_avg + body : nullptr, byz_out ? byz_out + body : nullptr,
-                                    scale, attack_kind, partial + (int64_t)nparts * 6, grid, s);
-    if (rc != 0) return rc;
-    nparts += grid;
+    float* sa = sampled_avg ? sampled_avg + lo : nullptr;
+    float* ha = honest_avg ? honest_avg + lo : nullptr;
+    float* bz = byz_out ? byz_out + lo : nullptr;
+    int64_t body = 0;
+    if (vec >= 2 && dp / vec > 0) {
+      const int64_t nvec = dp / vec;
+      int grid = stream_grid(nvec, kStepBlock, cap);
+      rc = (vec == 4) ? dispatch_momentum_stats<4>(piece, ks, h, nvec, mu, one_minus_damp, clip_factors, sa, ha, bz,
+                                                    scale, attack_kind, partial + (int64_t)nparts * 6, &grid, s)
+                      : dispatch_momentum_stats<2>(piece, ks, h, nvec, mu, one_minus_damp, clip_factors, sa, ha, bz,
+                                                    scale, attack_kind, partial + (int64_t)nparts * 6, &grid, s);
+      if (rc != 0) return rc;
+      nparts += grid;
+      body = nvec * vec;
+    }
+    if (body < dp) {
+      StepTable tail = piece;
+      for (int i = 0; i < BM_MAX_ROWS; ++i) {
+        tail.g[i] += body;
+        tail.b[i] += body;
+      }
+      const int64_t rest = dp - body;
+      int grid = (body == 0) ? stream_grid(rest, kStepBlock, cap) : 1;
+      rc = dispatch_momentum_stats<1>(tail, ks, h, rest, mu, one_minus_damp, clip_factors, sa ? sa + body : nullptr,
+                                      ha ? ha + body : nullptr, bz ? bz + body : nullptr, scale, attack_kind,
+                                      partial + (int64_t)nparts * 6, &grid, s);
+      if (rc != 0) return rc;
+      nparts += grid;
+    }
   }
   // d == 0: nparts == 0 and the finish kernel writes zeros — every rank of a sharded job reaches its collective
   hipLaunchKernelGGL(step_finish_kernel, dim3(1), dim3(kFinishThreads), 0, s, partial, nparts, out6);

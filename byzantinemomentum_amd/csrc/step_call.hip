@@ -11,10 +11,10 @@
 //   [clip]   row squared norms of the sampled gradients -> all-reduce -> clipping factors   attack.py:791-794
 //   pass 1   bm_momentum_stats: momentum in place, sampled / honest statistics, Byzantine vector   :800-804,846-847
 //   rule     bm_sharded_krum / bm_sharded_bulyan (distances -> all-reduce -> rank -> mean / pass 2) or bm_colwise   :821
-//   stats    attack stack, defense vector                                                     :848,851-852
-//   dots     Gram of (sampled avg, honest avg, defense, attack avg) + <s, newest past>, <s, C>   :854-866
-//   C        curvature combination C <- s + mu * (C - mu^(P-1) * oldest)                       (see step.py)
-//   l2       ||params - origin||^2                                                            :830
+//   study    bm_study_stats, ONE pass: statistics of the attack stack and of the defense vector (:848,851-852),
+//            Gram of (sampled avg, honest avg, defense, attack avg) + <s, newest past>, <s, C> (:854-866),
+//            ||params - origin||^2 (:830), and the curvature combination C <- s + mu * (C - mu^(P-1) * oldest)
+//            for the next step (see step.py)
 //   pack     every scalar into one vector -> all-gather -> fixed-order sums / maxima -> stats_out
 #include "bm_common.h"
 
@@ -28,10 +28,7 @@ static_assert(kStatSums + kStatMaxes <= kStatSlots, "statistics vector layout");
 // scratch scalars of one call, all fp64 on the device
 struct StepScalars {
   double out6[6];
-  double a3[3];
-  double d3[3];
-  double dots[18];
-  double l2[4];
+  double study[BM_STUDY_SLOTS];  // bm_study_stats
   double rowsq[BM_MAX_ROWS];
   double gram4[(BM_MAX_ROWS / 4) * 16];  // row norms: one 4 x 4 Gram block per group of four rows (ks <= BM_MAX_ROWS)
   double mine[kStatSlots];
@@ -44,28 +41,29 @@ __global__ void step_diag_kernel(const double* __restrict__ gram, int nc, double
   if (i < nc) rowsq[i] = gram[i * nc + i];
 }
 
-__global__ void step_pack_kernel(StepScalars* sc, int has_attack, int nc, int has_past, int has_l2) {
+__global__ void step_pack_kernel(StepScalars* sc, int has_attack, int has_past, int has_l2) {
   if (threadIdx.x != 0) return;
   double* m = sc->mine;
+  const double* st = sc->study;
   for (int i = 0; i < kStatSlots; ++i) m[i] = 0.0;
   m[0] = sc->out6[0];
   m[1] = sc->out6[1];
   m[2] = sc->out6[3];
   m[3] = sc->out6[4];
-  m[4] = sc->d3[0];
-  m[5] = has_attack ? sc->a3[0] : 0.0;
-  m[6] = has_attack ? sc->a3[1] : 0.0;
-  m[7] = has_l2 ? sc->l2[1] : 0.0;
-  for (int a = 0; a < nc; ++a)
-    for (int b = 0; b < nc; ++b) m[8 + a * 4 + b] = sc->dots[a * nc + b];
+  m[4] = st[2 * 4 + 2];  // |defense|^2
+  m[5] = has_attack ? st[18] : 0.0;
+  m[6] = has_attack ? st[19] : 0.0;
+  m[7] = has_l2 ? st[22] : 0.0;
+  for (int a = 0; a < 4; ++a)
+    for (int b = 0; b < 4; ++b) m[8 + a * 4 + b] = (has_attack || (a < 3 && b < 3)) ? st[a * 4 + b] : 0.0;
   if (has_past) {
-    m[24] = sc->dots[nc * nc];
-    m[25] = sc->dots[nc * nc + 1];
+    m[24] = st[16];
+    m[25] = st[17];
   }
   m[kStatSums + 0] = sc->out6[2];
   m[kStatSums + 1] = sc->out6[5];
-  m[kStatSums + 2] = sc->d3[2];
-  m[kStatSums + 3] = has_attack ? sc->a3[2] : 0.0;
+  m[kStatSums + 2] = st[21];
+  m[kStatSums + 3] = has_attack ? st[20] : 0.0;
 }
 
 // stats_out[slot] = sum over ranks in rank order (slots < kStatSums) or NaN-propagating maximum
@@ -87,7 +85,7 @@ __global__ void step_reduce_kernel(const double* __restrict__ all, int nranks, d
 }
 
 struct StepLayout {
-  int64_t scalars, ws_step, ws_stats, ws_dot, ws_rule, ws_pair2, total;
+  int64_t scalars, ws_step, ws_study, ws_dot, ws_rule, total;
 };
 
 static StepLayout step_layout(int n, int64_t d) {
@@ -98,14 +96,12 @@ static StepLayout step_layout(int n, int64_t d) {
   off += up((int64_t)sizeof(StepScalars));
   l.ws_step = off;
   off += up(bm_workspace_bytes(BM_WS_STEP, 1, d));
-  l.ws_stats = off;
-  off += up(bm_workspace_bytes(BM_WS_STATS, 1, d));
+  l.ws_study = off;
+  off += up(bm_workspace_bytes(BM_WS_STUDY, 1, d));
   l.ws_dot = off;
   off += up(bm_workspace_bytes(BM_WS_DOT, 1, d));
   l.ws_rule = off;
   off += up(bm_sharded_workspace_bytes(n, d));
-  l.ws_pair2 = off;
-  off += up(bm_workspace_bytes(BM_WS_PAIRWISE, 2, d));
   l.total = off;
   return l;
 }
@@ -130,7 +126,7 @@ extern "C" int bm_step_worker(bm_comm* comm, const bm_step_params* p, const floa
   const int n = p->n, h = p->n - p->f_real, ks = p->ks, fr = p->f_real;
   if (n < 1 || n > BM_MAX_ROWS || h < 1 || ks < h || ks > BM_MAX_ROWS || fr < 0 ||
       (d > 0 && (defense_out == nullptr || sampled_avg_out == nullptr || honest_avg_out == nullptr)) ||
-      (fr > 0 && d > 0 && (byz_out == nullptr || attack_avg_out == nullptr)))
+      (fr > 0 && d > 0 && byz_out == nullptr))
     return BM_EINVAL;
   const bool distance_rule = p->rule == BM_RULE_KRUM || p->rule == BM_RULE_BULYAN;
   if (!distance_rule && p->rule != BM_RULE_MEDIAN && p->rule != BM_RULE_TRMEAN && p->rule != BM_RULE_PHOCAS &&
@@ -184,54 +180,23 @@ extern "C" int bm_step_worker(bm_comm* comm, const bm_step_params* p, const floa
   }
   if (rc != 0) return rc;
 
-  // ---- attack stack and defense vector ----
-  if (fr > 0) {
-    rc = bm_stack_stats(rows + h, fr, d, attack_avg_out, nullptr, 0.0f, BM_ATTACK_EMPIRE, sc->a3, base + lay.ws_stats,
-                        stream);
-    if (rc != 0) return rc;
+  // ---- the study block in one pass (attack / defense statistics, dots, l2, curvature combination) ----
+  int curv_mode = 0;
+  if (p->nb_past > 0 && curv != nullptr) {
+    if (p->past_count == 0 || past_newest == nullptr)
+      curv_mode = 1;
+    else
+      curv_mode = past_oldest != nullptr ? 3 : 2;
   }
-  const float* def_row[1] = {defense_out};
-  rc = bm_stack_stats(def_row, 1, d, nullptr, nullptr, 0.0f, BM_ATTACK_EMPIRE, sc->d3, base + lay.ws_stats, stream);
-  if (rc != 0) return rc;
-
-  // ---- dot products of the study block ----
-  const float* core[4] = {sampled_avg_out, honest_avg_out, defense_out, attack_avg_out};
-  const int nc = fr > 0 ? 4 : 3;
-  const bool has_past = p->nb_past > 0 && p->past_count > 0 && past_newest != nullptr && curv != nullptr;
-  const float* extra[2] = {past_newest, curv};
-  rc = bm_multi_dot(core, nc, has_past ? extra : nullptr, has_past ? 2 : 0, d, sc->dots, base + lay.ws_dot, stream);
-  if (rc != 0) return rc;
-
-  // ---- curvature combination (after the dots have read the old one: same stream) ----
-  if (p->nb_past > 0 && curv != nullptr && d > 0) {
-    if (p->past_count == 0) {
-      rc = hip_code(hipMemcpyAsync(curv, sampled_avg_out, (size_t)d * sizeof(float), hipMemcpyDeviceToDevice, s));
-      if (rc != 0) return rc;
-    } else {
-      float* out1[1] = {curv};
-      const float* p1[1] = {curv};
-      if (past_oldest != nullptr) {
-        const float* q0[1] = {past_oldest};
-        rc = bm_multi_fma3(out1, p1, q0, 1, d, 1.0f, p->oldest_weight, nullptr, stream);  // -(mu^(P-1))
-        if (rc != 0) return rc;
-      }
-      const float* q1[1] = {sampled_avg_out};
-      rc = bm_multi_fma3(out1, p1, q1, 1, d, p->mu, 1.0f, nullptr, stream);
-      if (rc != 0) return rc;
-    }
-  }
-
-  // ---- l2 distance from the origin ----
+  const bool has_past = curv_mode >= 2;
   const bool has_l2 = params != nullptr && origin != nullptr;
-  if (has_l2) {
-    const float* two[2] = {params, origin};
-    rc = bm_pairwise_sqdist(two, 2, d, sc->l2, base + lay.ws_pair2, stream);
-    if (rc != 0) return rc;
-  }
+  rc = bm_study_stats(sampled_avg_out, honest_avg_out, defense_out, byz_out, fr, attack_avg_out, past_newest, curv,
+                      past_oldest, curv_mode, p->mu, p->oldest_weight, params, origin, d, sc->study,
+                      base + lay.ws_study, stream);
+  if (rc != 0) return rc;
 
   // ---- one packed exchange of every scalar ----
-  hipLaunchKernelGGL(step_pack_kernel, dim3(1), dim3(64), 0, s, sc, fr > 0 ? 1 : 0, nc, has_past ? 1 : 0,
-                     has_l2 ? 1 : 0);
+  hipLaunchKernelGGL(step_pack_kernel, dim3(1), dim3(64), 0, s, sc, fr > 0 ? 1 : 0, has_past ? 1 : 0, has_l2 ? 1 : 0);
   BM_LAUNCH_CHECK();
   const int nranks = bm_comm_size(comm);
   if (nranks > BM_MAX_ROWS) return BM_EINVAL;

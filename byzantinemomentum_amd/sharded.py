@@ -154,6 +154,9 @@ class HipBackend:
   def clip_factors_from_sq(self, sq, k, clip):
     return self.stats.clip_factors_from_sq(sq, k, clip)
 
+  def study_stats(self, *args, **kwargs):
+    return self.stats.study_stats(*args, **kwargs)
+
   def study_dots(self, core, extra):
     return self.stats.study_dots(core, extra)
 

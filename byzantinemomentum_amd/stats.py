@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from . import gars
 
-__all__ = ["compute_avg_dev_max", "stack_stats_async", "study_dots", "multi_axpby", "row_sqnorms", "momentum_stats",
+__all__ = ["compute_avg_dev_max", "stack_stats_async", "study_dots", "study_stats", "multi_axpby", "row_sqnorms", "momentum_stats",
            "multi_fma3", "clip_factors", "clip_factors_from_sq", "multi_scale", "clip_gradients", "l2_distance",
            "step_worker"]
 
@@ -85,6 +85,31 @@ def study_dots(core, extra=()):
                                 _lib.pointer_table(extra) if extra else None, len(extra), d, _ptr(out),
                                 _ptr(ws), gars._stream(device)), "bm_multi_dot")
   return out[:nc * nc].view(nc, nc), out[nc * nc:]
+
+
+def study_stats(s_avg, h_avg, defense, byz, f_real, past_newest=None, curv=None, past_oldest=None, curv_mode=0, mu=0.0,
+                oldest_weight=0.0, params=None, origin=None, attack_avg_out=None):
+  """The study block of a step in ONE pass (bm_study_stats, include/bm_gar.h): statistics of the attack stack
+  (f_real copies of `byz`) and of the defense vector, the Gram matrix of (sampled avg, honest avg, defense, attack
+  avg), <s, past_newest>, <s, C>, |params - origin|^2, and the in-place update of the curvature combination C =
+  `curv` for the next step (curv_mode: 0 none, 1 C <- s, 2 C <- s + mu C, 3 the same after taking
+  oldest_weight * past_oldest out of C).  Returns the device fp64 vector of STUDY_SLOTS statistics; no sync."""
+  vecs = [t for t in (s_avg, h_avg, defense, byz if f_real > 0 else None, past_newest if curv_mode >= 2 else None,
+                      curv if curv_mode >= 1 else None, past_oldest if curv_mode == 3 else None, params, origin,
+                      attack_avg_out) if t is not None]
+  _, d, device = gars._validate(vecs)
+  if (params is None) != (origin is None):
+    raise gars.GarInputError("study_stats needs both params and origin, or neither")
+  lib = _lib.load()
+  out = torch.empty(_lib.STUDY_SLOTS, dtype=torch.float64, device=device)
+  ws = gars._workspace(device, _lib.WS_STUDY, 1, d, "ws_study")
+  opt = lambda t: _ptr(t) if t is not None else None  # noqa: E731
+  with torch.cuda.device(device):
+    _lib.check(lib.bm_study_stats(_ptr(s_avg), _ptr(h_avg), _ptr(defense), opt(byz if f_real > 0 else None), int(f_real),
+                                  opt(attack_avg_out), opt(past_newest), opt(curv), opt(past_oldest), int(curv_mode),
+                                  ctypes.c_float(mu), ctypes.c_float(oldest_weight), opt(params), opt(origin), d,
+                                  _ptr(out), _ptr(ws), gars._stream(device)), "bm_study_stats")
+  return out
 
 
 def row_sqnorms(gradients):
@@ -208,13 +233,13 @@ def step_worker(comm, sampled, buffers, n, f_decl, f_real, rule, m, mu, one_minu
                 nb_past, past_count, past_newest, curv, past_oldest, params=None, origin=None):
   """One simulation step with worker-side momentum as ONE C call (bm_step_worker, include/bm_gar.h).
 
-  comm: sharded.NativeComm or None.  Returns (defense, sampled_avg, honest_avg, byz, attack_avg, stats) with
-  `stats` the device fp64 vector documented in the header (already reduced over the ranks). No sync."""
+  comm: sharded.NativeComm or None.  Returns (defense, sampled_avg, honest_avg, byz, stats) with `stats` the
+  device fp64 vector documented in the header (already reduced over the ranks). No sync."""
   ks, d, device = gars._validate(list(sampled))
   lib = _lib.load()
   new = lambda: torch.empty(d, dtype=torch.float32, device=device)  # noqa: E731
   defense, s_avg, h_avg = new(), new(), new()
-  byz, a_avg = (new(), new()) if f_real > 0 else (None, None)
+  byz = new() if f_real > 0 else None  # (the attack average is not materialised: attack_avg_out = NULL)
   stats = torch.empty(lib.bm_step_stats_count(), dtype=torch.float64, device=device)
   ws = gars._Scratch.get(device, "ws_stepcall", nbytes=int(lib.bm_step_workspace_bytes(n, d)))
   par = _lib.StepParams(n=n, f_decl=f_decl, f_real=f_real, ks=ks, rule=_lib.RULE_IDS[rule], m=m or 0,
@@ -227,7 +252,7 @@ def step_worker(comm, sampled, buffers, n, f_decl, f_real, rule, m, mu, one_minu
   with torch.cuda.device(device):
     _lib.check(lib.bm_step_worker(comm.handle if comm is not None else None, ctypes.byref(par),
                                   _lib.pointer_table(sampled), _lib.pointer_table(buffers), d, _ptr(defense),
-                                  _ptr(s_avg), _ptr(h_avg), opt(byz), opt(a_avg), opt(past_newest), opt(curv),
+                                  _ptr(s_avg), _ptr(h_avg), opt(byz), None, opt(past_newest), opt(curv),
                                   opt(past_oldest), opt(params), opt(origin), _ptr(stats), _ptr(ws),
                                   gars._stream(device)), "bm_step_worker")
-  return defense, s_avg, h_avg, byz, a_avg, stats
+  return defense, s_avg, h_avg, byz, stats

@@ -218,24 +218,25 @@ class AggregationStep:
       self._update = self.server_momentum
     else:
       self._update = defense
-    # 5. remaining statistics
-    a_avg, a_out3 = ops.stack_stats(attacks) if self.f_real > 0 else (None, None)
-    _, d_out3 = ops.stack_stats([defense], want_avg=False)  # norm and max only: the average of one row is the row
-    core = [s_avg, h_avg, defense] + ([a_avg] if a_avg is not None else [])
-    have_past = self.nb_past > 0 and len(self.pasts) > 0
-    gram, extra = ops.study_dots(core, [self.pasts[0], self._curv] if have_past else [])
-    l2 = ops.pairwise_sqdist([params, origin])[0, 1].reshape(1) if params is not None and origin is not None else None
-    self._pending = dict(s=s_out3, h=h_out3, a=a_out3, d=d_out3, gram=gram, extra=extra, npast=2 if have_past else 0,
-                         prev_s2=self._prev_s2 if have_past else None, l2=l2, ks=ks, floats=None)
-    # grad_pasts.appendleft(PastGrad(sampled_grad_avg, sampled_norm_avg))  (attack.py:868): every step,
-    # whether or not the scalars are fetched; the norm of the newest entry stays on the device
+    # 5. remaining statistics, ONE pass over the vectors (bm_study_stats): attack stack, defense vector, the Gram
+    #    matrix behind the cosines, the dots with the past, l2 from the origin, and the curvature combination
+    #    for the next step.  grad_pasts.appendleft(PastGrad(sampled_grad_avg, sampled_norm_avg)) (attack.py:868)
+    #    happens every step, whether or not the scalars are fetched.
+    count = len(self.pasts) if self.nb_past > 0 else 0
+    mode = 0
     if self.nb_past > 0:
       if self._curv is None:
-        self._curv = s_avg.clone()
-      else:
-        if len(self.pasts) == self.nb_past:  # the oldest entry leaves the deque: take its term out of C first
-          ops.multi_fma3([self._curv], [self._curv], [self.pasts[-1]], 1.0, -(self.mu ** (self.nb_past - 1)))
-        ops.multi_fma3([self._curv], [self._curv], [s_avg], self.mu, 1.0)
+        self._curv = torch.empty_like(s_avg)  # written by the first step (C <- s)
+      mode = 1 if count == 0 else (3 if count == self.nb_past else 2)  # 3: the oldest entry leaves the deque
+    has_l2 = params is not None and origin is not None
+    study = ops.study_stats(s_avg, h_avg, defense, byz if self.f_real > 0 else None, self.f_real,
+                            past_newest=self.pasts[0] if count > 0 else None, curv=self._curv,
+                            past_oldest=self.pasts[-1] if mode == 3 else None, curv_mode=mode, mu=self.mu,
+                            oldest_weight=-(self.mu ** (self.nb_past - 1)) if self.nb_past > 0 else 0.0,
+                            params=params if has_l2 else None, origin=origin if has_l2 else None)
+    self._pending = dict(s=s_out3, h=h_out3, study=study, npast=2 if count > 0 else 0,
+                         prev_s2=self._prev_s2 if count > 0 else None, has_l2=has_l2, ks=ks, floats=None)
+    if self.nb_past > 0:
       self.pasts.appendleft(s_avg)
       self._prev_s2 = s_out3[:1]
     return defense
@@ -248,7 +249,7 @@ class AggregationStep:
     if self.nb_past > 0 and self._curv is None:
       self._curv = torch.empty_like(sampled[0])  # written by the first step (C <- s)
     full = count == self.nb_past and count > 0
-    defense, s_avg, h_avg, byz, a_avg, stats = self.ops.step_worker(
+    defense, s_avg, h_avg, byz, stats = self.ops.step_worker(
       self.agg.native, sampled, self.buffers, self.n, self.f_decl, self.f_real, self.gar, self.gar_args.get("m"),
       self.mu, omd, self.clip, self.attack, self.factor, self.nb_past, count,
       self.pasts[0] if count > 0 else None, self._curv, self.pasts[-1] if full else None, params, origin)
@@ -270,13 +271,9 @@ class AggregationStep:
 
   def _exchange(self, pend):
     """One packed exchange of every scalar of the step: sums and maxima, all ranks."""
-    sums = [pend["s"][:2], pend["h"][:2], pend["d"][:2], pend["gram"].reshape(-1), pend["extra"]]
-    maxes = [pend["s"][2:], pend["h"][2:], pend["d"][2:]]
-    if pend["a"] is not None:
-      sums.append(pend["a"][:2])
-      maxes.append(pend["a"][2:])
-    if pend["l2"] is not None:
-      sums.append(pend["l2"])
+    st = pend["study"]  # layout: include/bm_gar.h (bm_study_stats)
+    sums = [pend["s"][:2], pend["h"][:2], st[:20], st[22:23]]
+    maxes = [pend["s"][2:], pend["h"][2:], st[20:22]]
     if pend["prev_s2"] is not None:
       sums.append(pend["prev_s2"])
     sums, maxes = self.agg.exchange(torch.cat(sums), torch.cat(maxes))
@@ -327,20 +324,19 @@ class AggregationStep:
       pend["floats"] = self._floats_from_packed(pend)
       return pend["floats"]
     sums, maxes = self._exchange(pend)
-    it = iter(sums)
-    s2, sd = next(it), next(it)
-    h2, hd = next(it), next(it)
-    d2, _ = next(it), next(it)
-    nc = pend["gram"].shape[0]
-    g = [[next(it) for _ in range(nc)] for _ in range(nc)]
-    ex = [next(it) for _ in range(pend["npast"])]
-    a2 = ad = math.nan
-    if pend["a"] is not None:
-      a2, ad = next(it), next(it)
-    l2 = math.sqrt(next(it)) if pend["l2"] is not None else math.nan
-    prev_norm = math.sqrt(next(it)) if pend["prev_s2"] is not None else math.nan
-    smax, hmax, dmax = maxes[0], maxes[1], maxes[2]
-    amax = maxes[3] if pend["a"] is not None else math.nan
+    s2, sd, h2, hd = sums[0:4]
+    st = sums[4:24]          # Gram 4 x 4 | <s, past>, <s, C> | sum avg_a^2, sum_i |a_i - avg_a|^2
+    att = self.f_real > 0
+    nc = 4 if att else 3
+    g = [[st[4 * a + b] for b in range(4)] for a in range(4)]
+    ex = st[16:18]
+    d2 = g[2][2]
+    a2, ad = (st[18], st[19]) if att else (math.nan, math.nan)
+    l2 = math.sqrt(sums[24]) if pend["has_l2"] else math.nan
+    prev_norm = math.sqrt(sums[25]) if pend["prev_s2"] is not None else math.nan
+    smax, hmax = maxes[0], maxes[1]
+    amax = maxes[2] if att else math.nan
+    dmax = maxes[3]
     k_s, k_h, k_a = pend["ks"], self.h, self.f_real
 
     def dev(v, k):
@@ -355,8 +351,8 @@ class AggregationStep:
       "l2_origin": l2,
       "sampled_norm_avg": math.sqrt(s2), "sampled_norm_dev": dev(sd, k_s), "sampled_norm_max": smax,
       "honest_norm_avg": math.sqrt(h2), "honest_norm_dev": dev(hd, k_h), "honest_norm_max": hmax,
-      "attack_norm_avg": math.sqrt(a2) if pend["a"] is not None else math.nan,
-      "attack_norm_dev": dev(ad, k_a) if pend["a"] is not None else math.nan, "attack_norm_max": amax,
+      "attack_norm_avg": math.sqrt(a2) if att else math.nan,
+      "attack_norm_dev": dev(ad, k_a) if att else math.nan, "attack_norm_max": amax,
       "defense_norm_avg": math.sqrt(d2), "defense_norm_max": dmax,
       "cosin_splhon": cos(0, 1), "cosin_spldef": cos(0, 2), "cosin_hondef": cos(1, 2),
       "cosin_splatt": cos(0, 3), "cosin_honatt": cos(1, 3), "cosin_attdef": cos(3, 2),

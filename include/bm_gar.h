@@ -60,7 +60,8 @@ enum bm_ws_kind {
   BM_WS_AKSEL    = 1, /* bm_aksel_pass1                */
   BM_WS_STATS    = 2, /* bm_stack_stats                */
   BM_WS_DOT      = 3, /* bm_multi_dot                  */
-  BM_WS_STEP     = 4  /* bm_momentum_stats             */
+  BM_WS_STEP     = 4, /* bm_momentum_stats             */
+  BM_WS_STUDY    = 5  /* bm_study_stats                */
 };
 int64_t bm_workspace_bytes(int kind, int n, int64_t d);
 
@@ -135,6 +136,31 @@ int bm_stack_stats(const float* const* rows, int k, int64_t d, float* avg_out,
  *                   averages of the curvature term, attack.py:863-865).  All fp64. */
 int bm_multi_dot(const float* const* core, int nc, const float* const* extra, int ne,
                  int64_t d, double* out, void* ws, void* stream);
+
+/* The study block of a step (attack.py:830,848-868) in ONE pass over the d-sized vectors:
+ *   - statistics of the attack stack = f_real copies of byz (tools.compute_avg_dev_max, attack.py:848): the
+ *     sequential mean a and the deviations are rebuilt per element from byz with the reference's operations;
+ *     a is written to attack_avg_out only if that is non-NULL;
+ *   - |defense|^2 and max|defense| (attack.py:851-852);
+ *   - the Gram matrix of core = (sampled avg, honest avg, defense, attack avg) behind the six cosines
+ *     (attack.py:854-859), <sampled avg, past_newest> (attack.py:861-862) and <sampled avg, curv>, curv being
+ *     C = sum_i mu^i past_i: the curvature term mu * sum_i mu^i <s, past_i> of attack.py:863-866 as ONE dot;
+ *   - |params - origin|^2 (attack.py:830) when both are non-NULL;
+ *   - the update of C for the next step, in place, AFTER its dot product:
+ *       curv_mode 0  no curvature term kept (curv, past_* ignored)
+ *                 1  first step: C <- sampled avg (no dots with the past)
+ *                 2  C <- sampled avg + mu * C
+ *                 3  C <- sampled avg + mu * (C + oldest_weight * past_oldest), oldest_weight = -(mu^(P-1)):
+ *                    the entry that leaves a full ring of P past averages is taken out first.
+ * out (DEVICE, BM_STUDY_SLOTS doubles):
+ *   [4a+b] <core_a, core_b> (row/column 3 zero when f_real = 0)   [16] <s, past_newest>   [17] <s, C before the update>
+ *   [18] sum avg_a^2   [19] sum_i |a_i - avg_a|^2   [20] max|avg_a|   [21] max|defense|   [22] |params - origin|^2
+ * ws: bm_workspace_bytes(BM_WS_STUDY).  f_real = 0: no attack (byz ignored). */
+#define BM_STUDY_SLOTS 32
+int bm_study_stats(const float* sampled_avg, const float* honest_avg, const float* defense, const float* byz,
+                   int f_real, float* attack_avg_out, const float* past_newest, float* curv,
+                   const float* past_oldest, int curv_mode, float mu, float oldest_weight, const float* params,
+                   const float* origin, int64_t d, double* out, void* ws, void* stream);
 
 /* order_out = stable argsort (ties to the lower index, NaN last) of n fp64 keys that live on
  * the device: the `d.sort(key=...)` of aggregators/aksel.py:48 without a host round trip. */
@@ -211,8 +237,9 @@ int bm_sharded_bulyan(bm_comm* comm, const float* const* rows, int n, int64_t d_
 
 /* ---------------------------------------------------------------------------------------------
  * One simulation step with worker-side momentum (attack.py:786-868) as ONE call on the caller's stream:
- * [clipping factors] -> bm_momentum_stats -> rule over buffers + [byz] * f_real -> attack / defense
- * statistics -> study dots -> curvature combination -> l2 from the origin -> one packed exchange.
+ * [clipping factors] -> bm_momentum_stats -> rule over buffers + [byz] * f_real -> bm_study_stats (attack /
+ * defense statistics, study dots, l2 from the origin, curvature combination: one pass) -> one packed exchange.
+ * attack_avg_out may be NULL (the attack average is only needed as a vector by callers that want it).
  * comm NULL = one rank; otherwise every collective of the dim-sharded step (row norms when clipping, the
  * n x n squared distances, the packed statistics) goes through it.  d = coordinates of this rank.
  *

@@ -145,6 +145,36 @@ class OracleBackend:
     norm = sq[:k].sqrt()
     return torch.where(norm > clip, clip / norm, torch.ones_like(norm)).float()
 
+  def study_stats(self, s_avg, h_avg, defense, byz, f_real, past_newest=None, curv=None, past_oldest=None, curv_mode=0,
+                  mu=0.0, oldest_weight=0.0, params=None, origin=None, attack_avg_out=None):
+    """CPU restatement of bm_study_stats (include/bm_gar.h): same slots, fp64 reductions, C updated in place."""
+    out = torch.zeros(32, dtype=torch.float64)
+    core = [s_avg, h_avg, defense]
+    if f_real > 0:
+      a_avg = self._seq_mean([byz] * f_real)   # compute_avg_dev_max over f_real copies (tools/pytorch.py:105-125)
+      core.append(a_avg)
+      o3 = self._out3([byz] * f_real, a_avg)
+      out[18], out[19], out[20] = o3[0], o3[1], o3[2]
+      if attack_avg_out is not None:
+        attack_avg_out.copy_(a_avg)
+    c64 = [c.double() for c in core]
+    for a in range(len(core)):
+      for b in range(len(core)):
+        out[4 * a + b] = torch.dot(c64[a], c64[b])
+    out[21] = defense.abs().max().item() if defense.numel() else 0.0
+    if curv_mode >= 2:
+      out[16] = torch.dot(c64[0], past_newest.double())
+      out[17] = torch.dot(c64[0], curv.double())
+    if params is not None and origin is not None:
+      out[22] = (params.double() - origin.double()).pow(2).sum()
+    if curv_mode == 1:
+      curv.copy_(s_avg)
+    elif curv_mode >= 2:
+      if curv_mode == 3:
+        curv.add_(past_oldest, alpha=oldest_weight)
+      curv.mul_(mu).add_(s_avg)
+    return out
+
   def study_dots(self, core, extra):
     c64 = [c.double() for c in core]
     nc = len(core)

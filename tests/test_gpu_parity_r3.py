@@ -84,8 +84,9 @@ def test_step_steady_state_against_reference_loop(bm, cfg):
         curvs.append(want["curv_sampled"])
     params = params - 0.05 * want_upd
   # the test is meaningful: the curvature is dominated by the persistent component (~ mu * sum mu^i * 0.09 d)
+  # (clipping scales the sampled gradients down by up to ~0.6, hence the 0.2)
   full = mu * sum(mu ** i for i in range(P)) * 0.09 * d
-  assert curvs[-1] > 0.5 * full, (curvs[-1], full)
+  assert curvs[-1] > (0.5 if cfg["clip"] is None else 0.2) * full, (curvs[-1], full)
 
 
 def test_full_size_c5_steady_state_curvature(bm):
