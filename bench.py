@@ -184,10 +184,11 @@ def cpu_baseline_distance(stack, f, rule, d_sample):
 # ---------------------------------------------------------------------------- #
 # Live HBM traffic: rocprofv3 PMC passes of this very command (separate runs, --kernel-trace only)
 
-def measure_traffic(argv, kernel_substring):
-  """HBM bytes per launch of the kernel whose name contains `kernel_substring`:
-  FETCH_SIZE and WRITE_SIZE (KiB) from two rocprofv3 --pmc passes, FETCH_SIZE doubled as
-  MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950.  None if rocprofv3 is unavailable."""
+def measure_traffic(argv, kernel_substrings, extras=False):
+  """HBM bytes per launch of every kernel whose name contains one of `kernel_substrings` (dict key -> substring):
+  FETCH_SIZE and WRITE_SIZE (KiB) from two rocprofv3 --pmc passes (their own runs, --kernel-trace only) of this very
+  command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950.
+  Returns {key: bytes} (keys whose kernel was not launched are absent); None if rocprofv3 is unavailable."""
   exe = shutil.which("rocprofv3")
   if exe is None:
     return None
@@ -197,22 +198,40 @@ def measure_traffic(argv, kernel_substring):
     with tempfile.TemporaryDirectory(dir="/tmp") as tmp:
       cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "pmc", "--",
              sys.executable, str(ROOT / "bench.py"), *argv, "--steps", "4", "--warmup", "1", "--no-cpu-baseline",
-             "--no-extras", "--no-traffic"]
+             "--no-traffic"] + ([] if extras else ["--no-extras"])
       try:
-        subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, timeout=300, check=True)
+        subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, timeout=420, check=True)
       except Exception:  # noqa: BLE001
         return None
-      per_dispatch = {}
+      sums, counts = {}, {}
       for path in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
         with open(path) as fh:
+          per_dispatch = {}
           for row in csv.DictReader(fh):
-            if kernel_substring in row["Kernel_Name"] and row["Counter_Name"] == counter:
-              key = row["Dispatch_Id"]
-              per_dispatch[key] = per_dispatch.get(key, 0.0) + float(row["Counter_Value"])
-      if not per_dispatch:
-        return None
-      values[counter] = sum(per_dispatch.values()) / len(per_dispatch)
-  return int(1024 * (2 * values["FETCH_SIZE"] + values["WRITE_SIZE"]))
+            if row["Counter_Name"] != counter:
+              continue
+            for key, sub in kernel_substrings.items():
+              if sub in row["Kernel_Name"]:
+                slot = (key, row["Dispatch_Id"])
+                per_dispatch[slot] = per_dispatch.get(slot, 0.0) + float(row["Counter_Value"])
+          for (key, _), val in per_dispatch.items():
+            sums[key] = sums.get(key, 0.0) + val
+            counts[key] = counts.get(key, 0) + 1
+      values[counter] = {key: sums[key] / counts[key] for key in sums}
+  return {key: int(1024 * (2 * values["FETCH_SIZE"][key] + values["WRITE_SIZE"][key]))
+          for key in values["FETCH_SIZE"] if key in values["WRITE_SIZE"]}
+
+
+# kernel-name substrings of the dominant kernel(s) behind each per_gar entry, with the algorithmic bytes of ONE launch
+def traffic_kernels(d2, d5):
+  return {
+    "median": ("colwise_burst_kernel<25, 0", 4 * d2 * 26),
+    "trmean": ("colwise_burst_kernel<25, 1", 4 * d2 * 26),
+    "krum_c3.distances": ("gram3_partial_kernel<13, 2", 4 * d2 * 51),
+    "bulyan_c4_1gpu.pass2": ("bulyan_pass2_kernel<25, 5", 4 * d2 * 19),
+    "step_c5.first_pass": ("momentum_stats_kernel<20, 4", 4 * d5 * 63),
+    "step_c5.study": ("study_stats_kernel<true, 3", 4 * d5 * 8),
+  }
 
 
 # ---------------------------------------------------------------------------- #
@@ -360,7 +379,7 @@ def main():
     per_gar[name] = entry(timer.mean_ms(name), nbytes, config=workload_name)
 
   # ---- N > 1: the same shards through the communication-free pair, the all-gather, one-GPU reference ----
-  if world > 1 and workload in ("bulyan", "krum"):
+  if distributed and workload in ("bulyan", "krum"):  # (also one rank under torchrun: the same code path, testable on one GPU)
     ms = timed_loop(lambda i: bm.median(stacks[i & 1]), 10, 2, timer, "x_median")
     ms2 = timed_loop(lambda i: bm.trmean(stacks[i & 1], f), 10, 2, timer, "x_trmean")
     out = rule(stacks[0], f)
@@ -372,6 +391,24 @@ def main():
       per_gar[key] = entry(t.item(), nbytes, config=f"same shards, n={n}, total d={d_total}, max over ranks")
     del stacks
     torch.cuda.empty_cache()
+    # worker-parallel production: every rank holds the FULL-length gradients of its own workers
+    # (rank p runs workers p, p + P, ...); ONE all-to-all turns worker-major into dimension-major, then the rule
+    from byzantinemomentum_amd.sharded import owned_workers
+    mine = owned_workers(n, world, rank)
+    gen = torch.Generator(device=device).manual_seed(999 + rank)
+    produced = [0.1 * torch.randn(d_total, device=device, generator=gen) for _ in mine]
+    ms_a2a = timed_loop(lambda i: agg.to_dim_sharded(produced, n, d_total), 8, 2, timer, "x_a2a")
+    ms_wp = timed_loop(lambda i: rule(agg.to_dim_sharded(produced, n, d_total), f), 8, 2, timer, "x_wp")
+    for key, val in (("layout_exchange", ms_a2a), (workload + "_from_worker_parallel", ms_wp)):
+      t = torch.tensor([val], dtype=torch.float64, device=device)
+      dist.all_reduce(t, op=dist.ReduceOp.MAX)
+      sent = 4 * d_total * len(owned_workers(n, world, 0)) * (world - 1) // world
+      per_gar[key] = dict(entry(t.item(), 4 * d_total * n + (4 * d_total * (m + 1) if key != "layout_exchange" else 0),
+                                config=f"worker-major -> dimension-major by one all-to-all (RCCL), n={n}, total d={d_total}, "
+                                       f"{world} ranks" + ("" if key == "layout_exchange" else f", then {workload}")),
+                          bytes_sent_per_rank=sent)
+    del produced
+    torch.cuda.empty_cache()
     single = None
     if rank == 0:
       full = make_stacks(n, f, d_total, device, 2, 4321, args.aliased_byz)
@@ -379,7 +416,7 @@ def main():
       single = timed_loop(lambda i: fn(full[i & 1], f), 10, 3, timer, "x_single")
       del full
     dist.barrier()
-    if rank == 0:
+    if rank == 0 and world > 1:
       extra["single_gpu_same_workload"] = {"value": 1e3 / single, "unit": "agg/s", "ms": single,
                                            "note": "the unsharded rule on rank 0 alone, same total d"}
 
@@ -390,7 +427,7 @@ def main():
       extra["cpu_baseline"] = cpu_baseline_colwise(first, f)
     del stacks, first
     torch.cuda.empty_cache()
-    per_gar.update(extras_single_gpu(bm, device, timer, args.aliased_byz))
+    per_gar.update(extras_single_gpu(bm, device, timer, args.aliased_byz, cpu_baseline=not args.no_cpu_baseline))
   elif world == 1 and rank == 0 and not args.no_cpu_baseline:
     if workload == "colwise":
       extra["cpu_baseline"] = cpu_baseline_colwise(stacks[0], f)
@@ -400,11 +437,21 @@ def main():
   if rank == 0:
     dominant = max(algo_bytes, key=lambda k: per_gar[k]["avg_ms"])
     dk = per_gar[dominant]
-    traffic = None
+    traffic, per_kernel = None, None
     if world == 1 and not args.no_traffic and "BM_BENCH_CHILD" not in os.environ:
       child = ["--workload", workload, "--gar", args.gar] + (["--d", str(args.d)] if args.d else []) + \
           (["--aliased-byz"] if args.aliased_byz else [])
-      traffic = measure_traffic(child, dominant_kernel)
+      with_extras = workload == "colwise" and not args.no_extras and args.d is None
+      if with_extras:  # one pair of passes over the default line with its extras: every dominant kernel at once
+        kernels = traffic_kernels(D_RESNET18, D_WRN)
+        got = measure_traffic(child, {k: v[0] for k, v in kernels.items()}, extras=True)
+        if got is not None:
+          per_kernel = {k: {"kernel": kernels[k][0], "traffic": got[k], "algorithmic_bytes": kernels[k][1],
+                            "ratio": got[k] / kernels[k][1]} for k in got}
+          traffic = got.get(dominant)
+      else:
+        got = measure_traffic(child, {"dominant": dominant_kernel})
+        traffic = None if got is None else got.get("dominant")
     line = {
       "metric": "aggregations/sec (Byzantine-robust GAR over n workers x d dims; achieved HBM GB/s per GAR in roofline/per_gar)",
       "value": aggs_per_step * args.steps / elapsed,
@@ -422,10 +469,12 @@ def main():
       "roofline": {"bound": "hbm", "kernel": dominant, "achieved": dk["gbps"], "peak": HBM_PEAK_GBPS * world,
                    "unit": "GB/s", "frac": dk["gbps"] / (HBM_PEAK_GBPS * world), "traffic": traffic,
                    "traffic_source": None if traffic is None else
-                   f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, kernel {dominant_kernel}: "
-                   "1024*(2*FETCH_SIZE + WRITE_SIZE) per launch"},
+                   f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, kernel {dominant_kernel}"
+                   f"{' (' + dominant + ')' if per_kernel is not None else ''}: 1024*(2*FETCH_SIZE + WRITE_SIZE) per launch"},
       "per_gar": per_gar,
     }
+    if per_kernel is not None:
+      line["roofline"]["traffic_per_kernel"] = per_kernel
     line.update(extra)
     print(json.dumps(line))
   if distributed:
@@ -435,13 +484,13 @@ def main():
 def step_algorithmic_bytes(d, n, f, gar):
   """4-byte units of d per step as THIS implementation moves them (lists the
   reference's 103 + rule + 3 + 29): fused first pass = sampled + buffers read, buffers written, three
-  d-vectors written (ks + 2h + 3 = 63); rule; attack stats 2, defense stats 1; dots of 4 core vectors + the
-  newest past + the curvature combination C (6); update of C in place (two passes of 3: the oldest past
-  out, the new average in) — 12 instead of the 4 + 25 separate past dots."""
+  d-vectors written (ks + 2h + 3 = 63); the rule; the study block in one pass (bm_study_stats): sampled avg, honest
+  avg, defense, Byzantine vector, newest past, curvature combination C and the past average that leaves the deque
+  read, C written (8) — round 2 spent 15 there (attack stats 2, defense stats 1, dots 6, two passes of 3 over C)."""
   h = n - f
   m = n - f - 2
   gar_units = {"krum": n + m + 1, "bulyan": n + m + 1, "median": n + 1, "trmean": n + 1}.get(gar, n + 1)
-  return 4 * d * ((h + 2 * h + 3) + gar_units + 2 + 1 + 12)
+  return 4 * d * ((h + 2 * h + 3) + gar_units + 8)
 
 
 def attack_search(bm, honests, n, f, d, evals=16):
@@ -465,7 +514,7 @@ def attack_search(bm, honests, n, f, d, evals=16):
   return res
 
 
-def extras_single_gpu(bm, device, timer, aliased):
+def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
   """C3, C4 (one GPU) and C5 in a few iterations each: the driver-run record then carries every
   single-GPU configuration of BASELINE.json, not only the headline one."""
   from byzantinemomentum_amd.step import AggregationStep
@@ -481,6 +530,21 @@ def extras_single_gpu(bm, device, timer, aliased):
                       distance_pass_ms=ms_pair, distance_pass_gbps=4 * d * n / ms_pair / 1e6)
     if name == "krum_c3":
       out["attack_search_c3_krum"] = attack_search(bm, stacks[0][:n - f], n, f, d)
+      if cpu_baseline:
+        out[name]["cpu_baseline"] = cpu_baseline_distance(stacks[0], f, "krum", 1 << 18)
+    else:
+      # the other rules of aggregators/ on the C2 / C4 shape (n = 25, f = 5, d = 11.2 M)
+      c = (n + 1) // 2
+      ms_a = timed_loop(lambda i: bm.aksel(stacks[i & 1], f), 12, 3, timer, "aksel_c2")
+      out["aksel_c2"] = entry(ms_a, 4 * d * n + 4 * d * (c + 1),
+                              config=f"aksel.py:35-64, n={n}, f={f}, mode mid ({c} rows averaged), d={d}: median fused "
+                                     f"with the n row distances, then the selected mean")
+      ms_c = timed_loop(lambda i: bm.cge(stacks[i & 1], f), 12, 3, timer, "cge_c2")
+      out["cge_c2"] = entry(ms_c, 4 * d * n + 4 * d * (n - f + 1), config=f"cge.py:28-57, n={n}, f={f}, d={d}")
+      ms_b = timed_loop(lambda i: bm.brute(stacks[i & 1], f), 6, 2, timer, "brute_n25")
+      out["brute_n25"] = entry(ms_b, 4 * d * n + 4 * d * (n - f + 1),
+                               config=f"brute.py:32-80, n={n}, f={f} (53 130 subsets searched on the host from the "
+                                      f"device's distances: one synchronisation), d={d}")
     del stacks
     torch.cuda.empty_cache()
   n, f, d = 25, 5, D_WRN

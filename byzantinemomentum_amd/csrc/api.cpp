@@ -16,9 +16,9 @@ static double env_double(const char* name, double dflt) {
   return atof(v);
 }
 const Tuning& tuning() {
-  static const Tuning t = {env_int("BM_FORCE_VEC", 0), env_int("BM_COL_MAX_BLOCKS", 256 * 64), env_int("BM_COL_BURST", 8), env_int("BM_MEAN_BURST", 8), env_int("BM_BUL_BURST", 0),
-                           env_int("BM_PAIR_BLOCKS", 0), env_int("BM_PAIR_STRIPS", 0), env_int("BM_PAIR_ABLATE", 0), env_int("BM_PAIR_NBUF", 2),
-                           env_int("BM_PAIR_MODE", 0), env_int("BM_PAIR_CENTRE", 2), env_int("BM_PAIR_PLANES", 0), env_int("BM_STEP_STREAM", 0), env_int("BM_RESULT_NT", 1), env_int("BM_COL_ABLATE", 0), env_int("BM_STEP_BURST", 8), env_int("BM_PAIR_DITHER", 0), env_double("BM_PAIR_TAU", 2e-3)};
+  static const Tuning t = {env_int("BM_COL_BURST", 8),  env_int("BM_MEAN_BURST", 8), env_int("BM_BUL_BURST", 0),
+                           env_int("BM_STEP_BURST", 8), env_int("BM_STEP_STREAM", 0), env_int("BM_PAIR_MODE", 0),
+                           env_int("BM_PAIR_PLANES", 0), env_int("BM_PAIR_DITHER", 0), env_double("BM_PAIR_TAU", 2e-3)};
   return t;
 }
 }  // namespace bm

@@ -189,6 +189,9 @@ __device__ __forceinline__ void store_result_policy(float* p, const float (&src)
     store_result<VEC>(p, src);
 }
 
+// Grid cap of the plain column kernels (grid-stride above it).
+constexpr int kColMaxBlocks = 256 * 64;
+
 // Columns per launch such that every byte offset fits 32 bits (saddr addressing).
 constexpr int64_t kMaxColsPerLaunch = (int64_t)1 << 29;
 
@@ -246,24 +249,15 @@ namespace bm {
 // Launch-shape knobs, read once from the environment (experiments only; defaults are the
 // measured best on MI355X).
 struct Tuning {
-  int force_vec;       // BM_FORCE_VEC: 0 auto, 1 or 2 force a narrower column vector
-  int col_max_blocks;  // BM_COL_MAX_BLOCKS: grid cap of the column kernels
-  int col_burst;       // BM_COL_BURST: burst form of median/trmean from this many iterations per CU on (0 = never)
-  int mean_burst;      // BM_MEAN_BURST: the same for bm_selected_mean (averages of 12 rows or more)
-  int bul_burst;       // BM_BUL_BURST: the same for Bulyan pass 2 (n <= 25); 0 (default): off, not yet validated on hardware
-  int pair_blocks;     // BM_PAIR_BLOCKS: persistent grid of the pairwise-distance kernel
-  int pair_strips;     // BM_PAIR_STRIPS: force a tile shape, strips*100+slots (e.g. 208), 0 = automatic
-  int pair_ablate;     // BM_PAIR_ABLATE: 1 = no compute, 2 = no staging (experiments)
-  int pair_nbuf;       // BM_PAIR_NBUF: LDS tile buffers of the Gram kernel, 2 (default, measured best) or 3
-  int pair_mode;       // BM_PAIR_MODE: 0 = centred bf16x3 Gram (default), 1 = direct differences, 2 = fp32 Gram
-  int pair_centre;     // BM_PAIR_CENTRE (mode 0): 2 (default) median of three rows, 1 row mean, 0 none (experiments)
+  int col_burst;       // BM_COL_BURST: iterations per CU from which median / trmean take their burst form (default 8; 0 = never, 1 = always: tests)
+  int mean_burst;      // BM_MEAN_BURST: the same for the selected mean (default 8)
+  int bul_burst;       // BM_BUL_BURST: the same for Bulyan's pass 2
+  int step_burst;      // BM_STEP_BURST: the same for bm_momentum_stats (default 8)
+  int step_stream;     // BM_STEP_STREAM: 1 = the streaming form of bm_momentum_stats at every row count (tests)
+  int pair_mode;       // BM_PAIR_MODE: 0 = centred bf16 Gram + accuracy gate (default), 1 = direct differences for every pair
   int pair_planes;     // BM_PAIR_PLANES (mode 0): 0 (default) by length, 2 or 3 forced
-  int step_stream;     // BM_STEP_STREAM: 0 (default) register-resident form of bm_momentum_stats up to 20 rows, streaming above; 1 = streaming form at every size
-  int result_nt;       // BM_RESULT_NT: 1 (default) non-temporal stores for result vectors, 0 = default cache policy (experiments)
-  int col_ablate;      // BM_COL_ABLATE: 1 = median/trmean at n=25 without the output store (experiment)
-  int step_burst;      // BM_STEP_BURST: iterations per CU from which bm_momentum_stats takes its burst form (default 8; 0 = never)
-  int pair_dither;     // BM_PAIR_DITHER (mode 0, two planes): seed of the coordinate dither (default 0); -1 = no dither, round to nearest (experiments)
-  double pair_tau;     // BM_PAIR_TAU: accuracy gate of the Gram modes (see gram_to_sqdist_kernel); <= 0 disables
+  int pair_dither;     // BM_PAIR_DITHER (mode 0, two planes): seed of the coordinate dither (default 0); -1 = round to nearest (A/B)
+  double pair_tau;     // BM_PAIR_TAU: accuracy gate of mode 0 (see gram_to_sqdist_kernel); <= 0 disables
 };
 const Tuning& tuning();
 }  // namespace bm

@@ -201,8 +201,6 @@ static int launch_bulyan_fast(const float* const* rows_host, const int32_t* orde
   constexpr int kMaxVec = (MMAX <= 20) ? 4 : (MMAX <= 44 ? 2 : 1);
   int vec = common_vec_width(reinterpret_cast<const void* const*>(rows_host), N, out_all);
   if (vec > kMaxVec) vec = kMaxVec;
-  const int forced = tuning().force_vec;
-  if (forced == 1 || (forced == 2 && vec >= 2)) vec = forced;
   // pieces of at most 2^29 columns so that byte offsets fit 32 bits inside the kernel
   for (int64_t lo = 0; lo < d_all; lo += kMaxColsPerLaunch) {
     const int64_t d = (d_all - lo < kMaxColsPerLaunch) ? (d_all - lo) : kMaxColsPerLaunch;
@@ -217,22 +215,22 @@ static int launch_bulyan_fast(const float* const* rows_host, const int32_t* orde
         const int cus = compute_units();
         if (tuning().bul_burst > 0 && nvec / ((int64_t)cus * kBurstThreads) >= tuning().bul_burst) {
           hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 4 ? 4 : 1), true>), dim3(cus), dim3(kBurstThreads),
-                             0, s, tab, order, nvec, tuning().result_nt, out);
+                             0, s, tab, order, nvec, 1, out);
           burst = true;
         }
       }
       if (!burst) {
         hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 4 ? 4 : 1)>),
-                           dim3(stream_grid(nvec, kBulBlock, tuning().col_max_blocks)), dim3(kBulBlock), 0,
-                           s, tab, order, nvec, tuning().result_nt, out);
+                           dim3(stream_grid(nvec, kBulBlock, kColMaxBlocks)), dim3(kBulBlock), 0,
+                           s, tab, order, nvec, 1, out);
       }
       BM_LAUNCH_CHECK();
       body = nvec * 4;
     } else if (vec == 2 && kMaxVec >= 2 && d / 2 > 0) {
       const int64_t nvec = d / 2;
       hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 2 ? 2 : 1)>),
-                         dim3(stream_grid(nvec, kBulBlock, tuning().col_max_blocks)), dim3(kBulBlock), 0,
-                         s, tab, order, nvec, tuning().result_nt, out);
+                         dim3(stream_grid(nvec, kBulBlock, kColMaxBlocks)), dim3(kBulBlock), 0,
+                         s, tab, order, nvec, 1, out);
       BM_LAUNCH_CHECK();
       body = nvec * 2;
     }
@@ -241,8 +239,8 @@ static int launch_bulyan_fast(const float* const* rows_host, const int32_t* orde
       for (int i = 0; i < N; ++i) tail.p[i] = tab.p[i] + body;
       const int64_t rest = d - body;
       hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, 1>),
-                         dim3(stream_grid(rest, kBulBlock, tuning().col_max_blocks)), dim3(kBulBlock), 0,
-                         s, tail, order, rest, tuning().result_nt, out + body);
+                         dim3(stream_grid(rest, kBulBlock, kColMaxBlocks)), dim3(kBulBlock), 0,
+                         s, tail, order, rest, 1, out + body);
       BM_LAUNCH_CHECK();
     }
   }
@@ -361,7 +359,7 @@ extern "C" int bm_bulyan_pass2(const float* const* rows, int n, const int32_t* o
   if (d == 0) return 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int m_max = n - f - 2;
-  if (m == m_max && tuning().force_vec != -1) {
+  if (m == m_max) {
     // register-resident instances for the (n, f) grid the reference exercises
     // (reproduce.py:139,182; reproduce-appendix.py:121-158) and their neighbours
 #define BM_BULYAN_CASE(NN, FF) \
@@ -386,7 +384,7 @@ extern "C" int bm_bulyan_pass2(const float* const* rows, int n, const int32_t* o
   for (int i = 0; i < n; ++i) tab.p[i] = rows[i];
   const int theta = n - 2 * f - 2;
   const size_t lds = (size_t)(m_max + theta) * kBulBlock * sizeof(float);
-  const int grid = stream_grid(d, kBulBlock, tuning().col_max_blocks);
+  const int grid = stream_grid(d, kBulBlock, kColMaxBlocks);
   if (lds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bulyan_pass2_generic_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -45,17 +45,9 @@ static int launch_colwise_vec(const RowTable& rows_all, int64_t d_all, int f, fl
         continue;
       }
     }
-    const int grid = stream_grid(nvec, kColBlock, tuning().col_max_blocks);
-    if constexpr (N == 25 && VEC == 4 && (OP == BM_OP_MEDIAN || OP == BM_OP_TRMEAN)) {
-      if (tuning().col_ablate == 1) {  // experiment only: the read-only rate of the same kernel
-        hipLaunchKernelGGL((colwise_kernel<N, OP, VEC, true>), dim3(grid), dim3(kColBlock), 0, stream, rows,
-                           nvec, tail, f, inv_keep, tuning().result_nt, out_all + lo);
-        BM_LAUNCH_CHECK();
-        continue;
-      }
-    }
+    const int grid = stream_grid(nvec, kColBlock, kColMaxBlocks);
     hipLaunchKernelGGL((colwise_kernel<N, OP, VEC>), dim3(grid), dim3(kColBlock), 0, stream, rows,
-                       nvec, tail, f, inv_keep, tuning().result_nt, out_all + lo);
+                       nvec, tail, f, inv_keep, 1, out_all + lo);
     BM_LAUNCH_CHECK();
   }
   return 0;
@@ -72,8 +64,6 @@ static int launch_colwise_n(const float* const* rows_host, int64_t d, int f, flo
   int vec = common_vec_width(reinterpret_cast<const void* const*>(rows_host), N, out);
   constexpr int kMaxVec = (N <= 28) ? 4 : (N <= 56 ? 2 : 1);
   if (vec > kMaxVec) vec = kMaxVec;
-  const int forced = tuning().force_vec;  // experiment knob (BM_FORCE_VEC), 0 = automatic
-  if (forced == 1 || (forced == 2 && vec >= 2)) vec = forced;
   if (vec == 4 && kMaxVec >= 4)
     return launch_colwise_vec < N, OP, (kMaxVec >= 4 ? 4 : 1) > (tab, d, f, out, stream);
   if (vec == 2 && kMaxVec >= 2)

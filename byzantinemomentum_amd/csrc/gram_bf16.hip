@@ -43,7 +43,6 @@
 //     krum.py:62 stable sort);
 //   * fp32 chains cover 32 coordinates, per-wave fp32 sums ~100 chunks, everything wider is fp64
 //     (workgroup, grid, GPUs) in a fixed order: deterministic, no atomics.
-#include <type_traits>
 #include "bm_common.h"
 
 namespace bm {
@@ -127,6 +126,11 @@ __device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
                                                  0, 0, 0);
 }
 
+// workgroups per CU by shape (3 leave 168 VGPRs, 2 leave 256); the host sizes its grid with the same function
+__host__ __device__ constexpr int b3_workgroups_per_cu(int K, int NPL) {
+  return (K <= 6 || (K == 7 && NPL == 2) || (K == 8 && NPL == 3)) ? 3 : 2;
+}
+
 // K = ceil(n/4) load instructions per chunk; RB = ceil(K/4) 16-row blocks; NPL bf16 planes (3 = the
 // exact split, 2 = h + rne_bf16(x - h): 16 significant bits, see gram3_partials).
 template <int K, int NPL>
@@ -137,8 +141,11 @@ struct B3Shape {
   static constexpr int PS = N4 * kB3RowBytes;           // plane stride
   static constexpr int WS = NPL * PS;                   // wave region
   static constexpr int NSETS = (K <= 8 && (NPL == 2 || K * NPL <= 21)) ? 2 : 1;  // register sets of loads in flight
-  // workgroups per CU aimed at (K = 8 with the fp64 running sums of the two-plane form does not fit 168 VGPRs)
-  static constexpr int MINW = (K <= 7 || (K == 8 && NPL == 3)) ? 3 : 2;
+  // workgroups per CU aimed at (3 leave 168 VGPRs: K = 8 with two planes and K = 7 with three no longer fit them
+  // since the m m products have an accumulator of their own)
+  static constexpr int MINW = b3_workgroups_per_cu(K, NPL);
+  // fold the accumulators of a block pair behind the MFMAs of the next one (needs 16 more VGPRs)
+  static constexpr bool PIPE = !(NPL == 3 && K >= 15);
   static constexpr int kPtrBytes = BM_MAX_ROWS * 8;
   static constexpr int kRedBytes = kB3Waves * 256 * 8;
   static constexpr int kLds = kPtrBytes + (kB3Waves * WS > kRedBytes ? kB3Waves * WS : kRedBytes);
@@ -178,12 +185,11 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
   const bool last_ok = (16 * (RB - 1) + li) < S::N4;
   const int rd_last0 = last_ok ? rd0 + (RB - 1) * 16 * kB3RowBytes : (lg << 4);
 
-  // Per-wave running sums of the chunk results.  Two planes (long vectors: a wave folds 85-280 chunks) keep them
-  // in fp64: an fp32 running sum of NEARLY EQUAL terms (rows with few distinct values: constant, quantised)
-  // rounds the same way at every step, the error grows like 2^-25 * chunks instead of averaging out (measured
-  // 3e-7 on G at d = 11.2 M with constant rows, i.e. 1.5e-4 on a squared distance that cancels 200-fold).  The
-  // three-plane form (d < 2^20: at most 8 chunks per wave) keeps fp32.
-  using Acc = typename std::conditional<NPL == 2, double, float>::type;
+  // Per-wave running sums of the chunk results, fp32 over 85-280 chunks.  (Rows of few distinct values do not make
+  // this sum drift: when every chunk adds the same value that value has a short mantissa — products of two bf16 —
+  // and the sum stays exact; otherwise the terms differ in their low bits and the roundings average out.  Measured
+  // in round 3: fp64 running sums changed no result, they only cost 40 VGPRs.)
+  using Acc = float;
   Acc outer[NP][4];
 #pragma unroll
   for (int p = 0; p < NP; ++p)
@@ -289,8 +295,15 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
   // Fragments of both 32-coordinate steps are read first; every block pair then runs its MFMAs of
   // both steps into the same three accumulators, which are folded into the per-wave fp32 sums once
   // per chunk (64 coordinates).
-  auto fold = [](Acc (&acc)[4], const f32x4 a0, const f32x4 a1, const f32x4 a2) {
-    const f32x4 t = a0 + (a1 + a2);
+  // The matrix core does not round its sum to nearest: addends far below the accumulator lose their low bits when they
+  // are aligned (scripts/probes/mfma_round_probe.hip), a bias with the sign of the addend.  With products of random
+  // sign it averages out; with rows of few distinct values (all products of a chunk equal) it is systematic, 1e-7
+  // of a Gram entry, i.e. 1e-4 of a squared distance that cancels 500-fold just above the accuracy gate (measured,
+  // round 3).  So every accumulator only ever sums products of ONE magnitude class — S0 = h h, S3 = m m, S1 = h m
+  // (+ h l), S2 = m h (+ l h) — sums that are exact for such rows, and the classes meet in round-to-nearest VALU
+  // additions: t = S0 + ((S1 + S2) + S3), symmetric under the exchange of the two rows like S0 + (S1 + S2) was.
+  auto fold = [](Acc (&acc)[4], const f32x4 a0, const f32x4 a1, const f32x4 a2, const f32x4 a3) {
+    const f32x4 t = a0 + ((a1 + a2) + a3);
 #pragma unroll
     for (int v = 0; v < 4; ++v) acc[v] += (Acc)t[v];
   };
@@ -306,10 +319,10 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
         if constexpr (NPL == 3) fl[s][R] = *reinterpret_cast<const u32x4*>(wbase + off + 2 * S::PS);
       }
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
-    // Software pipeline over the block pairs: the MFMAs of pair p are issued before the three VALU
-    // folds of pair p-1, so the folds never wait for the matrix pipe; inside a pair the chain of S0
-    // (4 or 4 MFMAs) alternates with the S1 / S2 chains, dependent MFMAs are two issue slots apart.
-    f32x4 q0 = zero, q1 = zero, q2 = zero;  // accumulators of the previous pair, not folded yet
+    // Software pipeline over the block pairs: the MFMAs of pair p are issued before the VALU folds of pair p-1, so
+    // the folds never wait for the matrix pipe; inside a pair the four chains alternate, dependent MFMAs are at
+    // least two issue slots apart.
+    f32x4 q0 = zero, q1 = zero, q2 = zero, q3 = zero;  // accumulators of the previous pair, not folded yet
     int p = 0;
 #pragma unroll
     for (int I = 0; I < RB; ++I)
@@ -317,7 +330,7 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
       for (int J = I; J < RB; ++J) {
         f32x4 s0 = mfma_bf16(fh[0][I], fh[0][J], zero);
         f32x4 s1 = mfma_bf16(fh[0][I], fm[0][J], zero);
-        s0 = mfma_bf16(fm[0][I], fm[0][J], s0);
+        f32x4 s3 = mfma_bf16(fm[0][I], fm[0][J], zero);
         f32x4 s2 = mfma_bf16(fm[0][I], fh[0][J], zero);
         if constexpr (NPL == 3) {
           s1 = mfma_bf16(fh[0][I], fl[0][J], s1);
@@ -325,19 +338,24 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
         }
         s0 = mfma_bf16(fh[1][I], fh[1][J], s0);
         s1 = mfma_bf16(fh[1][I], fm[1][J], s1);
-        s0 = mfma_bf16(fm[1][I], fm[1][J], s0);
+        s3 = mfma_bf16(fm[1][I], fm[1][J], s3);
         s2 = mfma_bf16(fm[1][I], fh[1][J], s2);
         if constexpr (NPL == 3) {
           s1 = mfma_bf16(fh[1][I], fl[1][J], s1);
           s2 = mfma_bf16(fl[1][I], fh[1][J], s2);
         }
-        if (p > 0) fold(outer[p - 1], q0, q1, q2);
-        q0 = s0;
-        q1 = s1;
-        q2 = s2;
+        if constexpr (S::PIPE) {
+          if (p > 0) fold(outer[p - 1], q0, q1, q2, q3);
+          q0 = s0;
+          q1 = s1;
+          q2 = s2;
+          q3 = s3;
+        } else {
+          fold(outer[p], s0, s1, s2, s3);
+        }
         ++p;
       }
-    fold(outer[NP - 1], q0, q1, q2);
+    if constexpr (S::PIPE) fold(outer[NP - 1], q0, q1, q2, q3);
   };
 
   // ---- main loop: loads of the next chunk(s) stay in flight under the MFMAs of this one ----
@@ -384,6 +402,85 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
     }
 }
 
+// G = sum over workgroups (fixed order), then sq[i][j] = G_ii + G_jj - 2 G_ij in fp64.
+constexpr int kGramRedWaves = 16;  // 16 waves x 16 loads in flight: the sum is a latency chain over L2/HBM
+__global__ __launch_bounds__(64 * kGramRedWaves) void gram_reduce_kernel(const double* __restrict__ partial,
+                                                                         int nblocks, int n,
+                                                                         double* __restrict__ gram) {
+  __shared__ double wsum[kGramRedWaves][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int per_block = n * (n + 1) / 2;
+  const int e = blockIdx.x * 64 + lane;
+  double s = 0.0;
+  if (e < per_block) {
+#pragma unroll 16
+    for (int blk = wave; blk < nblocks; blk += kGramRedWaves) s += partial[(int64_t)blk * per_block + e];
+  }
+  wsum[wave][lane] = s;
+  __syncthreads();
+  if (wave != 0 || e >= per_block) return;
+  double tot = wsum[0][lane];
+#pragma unroll
+  for (int w = 1; w < kGramRedWaves; ++w) tot += wsum[w][lane];
+  gram[e] = tot;
+}
+
+// sq[i][j] = G_ii + G_jj - 2 G_ij in fp64, one workgroup.  Also decides whether the Gram form was
+// accurate enough: its absolute error is ~eps_G * (G_ii + G_jj) (eps_G ~ 6e-9, measured), so a pair
+// whose squared distance is below tau * (G_ii + G_jj) — two rows that nearly coincide relative to
+// their (centred) norms — has lost relative accuracy eps_G / tau.  The rows of such pairs are listed in
+// `sub` (sub[0] = count, sub[1..] = indices, ascending); the caller recomputes the distances among them
+// with the direct-difference kernel (pairwise.hip), which has no cancellation: near-duplicate rows
+// lie close to EACH OTHER, so that sub-stack is exactly where the Gram form cannot be trusted.
+// Bitwise-equal rows (G_ii == G_jj == G_ij) are exact (d2 = 0) and never listed.
+constexpr int kSqThreads = 1024;
+__global__ __launch_bounds__(kSqThreads) void gram_to_sqdist_kernel(const double* __restrict__ gram, int n,
+                                                                    double tau, double* __restrict__ sq,
+                                                                    int* __restrict__ sub) {
+  __shared__ int listed[BM_MAX_ROWS];
+  if (threadIdx.x < BM_MAX_ROWS) listed[threadIdx.x] = 0;
+  __syncthreads();
+  for (int e = threadIdx.x; e < n * n; e += kSqThreads) {
+    const int i = e / n, j = e - i * n;
+    if (i == j) {
+      // a row with a non-finite coordinate is at non-finite distance of everything, itself
+      // included in the reference (x - x = nan); keep 0 on the diagonal, it is never read
+      sq[e] = 0.0;
+      continue;
+    }
+    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const double gii = gram[b3_tri_index(lo, lo, n)], gjj = gram[b3_tri_index(hi, hi, n)];
+    const double gij = gram[b3_tri_index(lo, hi, n)];
+    double v = (gii + gjj) - 2.0 * gij;
+    const bool same = (gii == gjj) && (gij == gii);
+    if (!same && v < tau * (gii + gjj)) {  // NaN compares false: non-finite rows are never listed
+      listed[i] = 1;                       // benign race: every writer stores 1
+      listed[j] = 1;
+    }
+    if (v < 0.0) v = 0.0;  // rounding of nearly identical rows; NaN stays NaN
+    sq[e] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && sub != nullptr) {
+    int count = 0;
+    for (int r = 0; r < n; ++r)
+      if (listed[r]) sub[1 + count++] = r;
+    sub[0] = count;
+  }
+}
+
+// Fixed-order sum of the per-workgroup partial Gram matrices, then squared distances + accuracy flag.
+int gram_finish(const double* partial, int blocks, int n, double* gram, double* sq_nxn, int* sub, double tau,
+                hipStream_t s) {
+  const int64_t per_block = (int64_t)n * (n + 1) / 2;
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3((int)((per_block + 63) / 64)), dim3(64 * kGramRedWaves), 0, s,
+                     partial, blocks, n, gram);
+  BM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gram_to_sqdist_kernel, dim3(1), dim3(kSqThreads), 0, s, gram, n, tau, sq_nxn, sub);
+  BM_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int K, int NPL>
 static int launch_gram3_planes(const RowTable& tab, int n, int64_t d, bool aligned, int centre, double* partial,
                                int blocks, hipStream_t s) {
@@ -419,13 +516,6 @@ int gram3_partials(const float* const* rows, int n, int64_t d, int64_t d_total, 
   for (int i = 0; i < n; ++i) tab.p[i] = rows[i];
   const bool aligned = common_vec_width(reinterpret_cast<const void* const*>(rows), n, nullptr) == 4;
   const int K = (n + 3) / 4;
-  const int per_cu = (K <= 8) ? 3 : 2;
-  const int64_t chunks = (d + kB3Chunk - 1) / kB3Chunk;
-  int blocks = tuning().pair_blocks > 0 ? tuning().pair_blocks : 256 * per_cu;
-  if (blocks > kB3MaxBlocks) blocks = kB3MaxBlocks;
-  const int64_t need = (chunks + kB3Waves - 1) / kB3Waves;
-  if (blocks > need) blocks = (int)(need > 0 ? need : 1);
-  const int centre = tuning().pair_centre;
   // Planes: the exact three-way split below 2^20 coordinates; above, two planes (x ~ h + m, 16 significant
   // bits, the remainder rounded with the coordinate dither of split2_dithered: what is dropped has zero mean and
   // is independent across coordinates by construction), whose error on a squared distance is a random walk
@@ -435,6 +525,12 @@ int gram3_partials(const float* const* rows, int n, int64_t d, int64_t d_total, 
   // size.  BM_PAIR_PLANES forces 2 or 3.
   int planes = tuning().pair_planes;
   if (planes != 2 && planes != 3) planes = (d_total >= ((int64_t)1 << 20)) ? 2 : 3;
+  const int64_t chunks = (d + kB3Chunk - 1) / kB3Chunk;
+  int blocks = compute_units() * b3_workgroups_per_cu(K, planes);
+  if (blocks > kB3MaxBlocks) blocks = kB3MaxBlocks;
+  const int64_t need = (chunks + kB3Waves - 1) / kB3Waves;
+  if (blocks > need) blocks = (int)(need > 0 ? need : 1);
+  const int centre = 2;  // median of three rows (1 = row mean, 0 = none: measured alternatives)
   int rc;
   switch (K) {
 #define BM_B3_CASE(KK) \

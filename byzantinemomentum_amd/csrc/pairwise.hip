@@ -8,10 +8,12 @@
 // once (4*d*n bytes).
 //
 // bm_pairwise_sqdist dispatches on BM_PAIR_MODE:
-//   0 (default)  Gram contraction on the fp32 matrix cores, gram.hip;
-//   1            the kernel in this file: the direct form sum_k (a_k - b_k)^2, no cancellation at
-//                all, but two VALU lane-ops per (pair, coordinate) make it VALU-bound on gfx950
-//                (1.05 ms at n=51, d=11.2 M; VALU ~90 % busy).  Kept as the measured alternative.
+//   0 (default)  centred Gram contraction on the bf16 matrix cores with an error-free split, gram_bf16.hip,
+//                followed by an accuracy gate that hands nearly coincident rows to the kernel of this file;
+//   1            the kernel in this file for every pair: the direct form sum_k (a_k - b_k)^2, no cancellation
+//                at all, but two VALU lane-ops per (pair, coordinate) make it VALU-bound on gfx950
+//                (1.05 ms at n=51, d=11.2 M; VALU ~90 % busy).
+// (The fp32-MFMA Gram of round 1 is no longer part of the library: scripts/probes/gram_fp32_mfma.hip.)
 // Both give an exact 0 between bitwise-equal rows and bitwise-equal distances from them to any
 // third row (exact score ties, broken by index like the reference's stable sort, krum.py:62).
 //
@@ -381,7 +383,7 @@ __global__ __launch_bounds__(64 * kRedWaves) void pairwise_reduce_kernel(
 
 static int pair_grid_blocks(const PairGeom& g, int64_t d) {
   const int64_t chunks = (d + g.width - 1) / g.width;
-  int blocks = tuning().pair_blocks > 0 ? tuning().pair_blocks : 256 * 4;
+  int blocks = 256 * 4;
   if (blocks > chunks) blocks = (int)(chunks > 0 ? chunks : 1);
   return blocks;
 }
@@ -450,20 +452,14 @@ __global__ __launch_bounds__(kRankThreads) void krum_rank_kernel(const double* _
 }  // namespace bm
 
 namespace bm {
-int gram_sqdist(const float* const* rows, int n, int64_t d, double* sq_nxn, double* partial, double* gram,
-                int* sub, double tau, hipStream_t s);
 int gram_finish(const double* partial, int blocks, int n, double* gram, double* sq_nxn, int* sub, double tau,
                 hipStream_t s);
-int64_t gram_partial_doubles(int n);
 int gram3_partials(const float* const* rows, int n, int64_t d, int64_t d_total, double* partial, int* blocks_out,
                    hipStream_t s);
 int64_t gram3_partial_doubles(int n);
 
 // Workspace layout of bm_pairwise_sqdist: [row list of the gate: 512 B][Gram partials][Gram n(n+1)/2][direct partials]
-static int64_t pair_gram_doubles(int n) {
-  const int64_t a = gram_partial_doubles(n), b = gram3_partial_doubles(n);
-  return (a > b ? a : b) + (int64_t)n * (n + 1) / 2;
-}
+static int64_t pair_gram_doubles(int n) { return gram3_partial_doubles(n) + (int64_t)n * (n + 1) / 2; }
 
 // Direct-difference kernel + its reduction.  sub == nullptr: the whole stack, unconditionally.
 // Otherwise sub is the DEVICE row list written by gram_to_sqdist_kernel: both launches return
@@ -471,8 +467,7 @@ static int64_t pair_gram_doubles(int n) {
 // decision, no host synchronisation; the launch is shaped for the worst case, all n rows).
 static int pairwise_direct(const float* const* rows, int n, int64_t d, double* sq_nxn, double* partial,
                            const int* sub, hipStream_t s) {
-  const int forced = tuning().pair_strips;
-  const PairGeom g = pair_geometry(n, sub == nullptr ? forced : 0);
+  const PairGeom g = pair_geometry(n, 0);
   RowTable tab{};
   for (int i = 0; i < n; ++i) tab.p[i] = rows[i];
   int threads = g.threads, per_block = g.tiles * 16;
@@ -494,11 +489,7 @@ static int pairwise_direct(const float* const* rows, int n, int64_t d, double* s
   const int blocks = pair_grid_blocks(gw, d);
   const bool aligned =
       common_vec_width(reinterpret_cast<const void* const*>(rows), n, nullptr) == 4;
-  const int ablate = tuning().pair_ablate;  // experiments only (BM_PAIR_ABLATE)
-  auto kern = !aligned ? pairwise_partial_kernel<false>
-                       : (ablate == 1 ? pairwise_partial_kernel<true, 1>
-                                      : (ablate == 2 ? pairwise_partial_kernel<true, 2>
-                                                     : pairwise_partial_kernel<true, 0>));
+  auto kern = aligned ? pairwise_partial_kernel<true> : pairwise_partial_kernel<false>;
   if (lds_bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
@@ -527,25 +518,18 @@ extern "C" int bm_pairwise_sqdist_shard(const float* const* rows, int n, int64_t
   int* flag = static_cast<int*>(ws);  // flag[0] = rows to recompute, flag[1..] = their indices
   double* gram_partial = reinterpret_cast<double*>(static_cast<char*>(ws) + 512);
   double* direct_partial = gram_partial + pair_gram_doubles(n);
-  // BM_PAIR_MODE: 0 (default) centred Gram on the bf16 matrix cores, three-way split (gram_bf16.hip);
-  //               1 direct differences on the VALU (this file), no cancellation at all;
-  //               2 uncentred Gram on the fp32 matrix cores (gram.hip), kept as the measured alternative.
-  // Modes 0 and 2 end with the accuracy check of gram_to_sqdist_kernel; the rows of the pairs it flags
-  // are recomputed among themselves by the direct kernel (decided on the device, no host round trip).
+  // BM_PAIR_MODE: 0 (default) centred Gram on the bf16 matrix cores, error-free split (gram_bf16.hip), ending with the
+  //               accuracy check of gram_to_sqdist_kernel: the rows of the pairs it flags are recomputed among
+  //               themselves by the direct kernel (decided on the device, no host round trip);
+  //               1 direct differences on the VALU (this file) for every pair, no cancellation at all.
   const int mode = tuning().pair_mode;
   if (mode == 1) return pairwise_direct(rows, n, d, sq_nxn, direct_partial, nullptr, s);
   const double tau = tuning().pair_tau;
-  int rc;
-  if (mode == 2) {
-    double* gram = gram_partial + gram_partial_doubles(n);
-    rc = gram_sqdist(rows, n, d, sq_nxn, gram_partial, gram, flag, tau, s);
-  } else {
-    int blocks = 0;
-    rc = gram3_partials(rows, n, d, d_total, gram_partial, &blocks, s);
-    if (rc != 0) return rc;
-    double* gram = gram_partial + gram3_partial_doubles(n);
-    rc = gram_finish(gram_partial, blocks, n, gram, sq_nxn, flag, tau, s);
-  }
+  int blocks = 0;
+  int rc = gram3_partials(rows, n, d, d_total, gram_partial, &blocks, s);
+  if (rc != 0) return rc;
+  double* gram = gram_partial + gram3_partial_doubles(n);
+  rc = gram_finish(gram_partial, blocks, n, gram, sq_nxn, flag, tau, s);
   if (rc != 0 || tau <= 0.0) return rc;
   return pairwise_direct(rows, n, d, sq_nxn, direct_partial, flag, s);
 }
@@ -565,9 +549,7 @@ extern "C" int bm_krum_rank(const double* sq_nxn, int n, int f, int m, int mode,
 namespace bm {
 int64_t pairwise_workspace_bytes(int n, int64_t d) {
   const PairGeom g = pair_geometry(n, 0);
-  // upper bound on the grid (BM_PAIR_BLOCKS may raise it, keep a floor of 4096 workgroups)
-  int blocks = tuning().pair_blocks > 0 ? tuning().pair_blocks : 256 * 4;
-  if (blocks < 4096) blocks = 4096;
+  const int blocks = 4096;  // upper bound on the grid of the direct kernel
   (void)d;
   const int64_t direct = (int64_t)blocks * g.tiles * 16 * (int64_t)sizeof(double);
   return 512 + pair_gram_doubles(n) * (int64_t)sizeof(double) + direct;

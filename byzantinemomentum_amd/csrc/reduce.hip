@@ -109,7 +109,7 @@ static int launch_selected_mean(const RowTable& tab, const int32_t* idx, int m, 
   }
   const int grid = stream_grid(nvec, kRedBlock, 256 * 32);
   hipLaunchKernelGGL(selected_mean_kernel<VEC>, dim3(grid), dim3(kRedBlock), 0, s, tab, idx, m, nvec,
-                     (float)m, tuning().result_nt, out);
+                     (float)m, 1, out);
   BM_LAUNCH_CHECK();
   return 0;
 }
@@ -230,7 +230,7 @@ template <int KMAX, int VEC>
 static int launch_stack_stats(const RowTable& tab, int k, int64_t nvec, float* avg, float* scaled,
                               float scale, int kind, double* partial, int grid, hipStream_t s) {
   hipLaunchKernelGGL((stack_stats_kernel<KMAX, VEC>), dim3(grid), dim3(kRedBlock), 0, s, tab, k, nvec,
-                     avg, scaled, scale, kind, tuning().result_nt, partial);
+                     avg, scaled, scale, kind, 1, partial);
   BM_LAUNCH_CHECK();
   return 0;
 }

@@ -267,8 +267,8 @@ class ShardedAggregator:
     mine = owned_workers(n, world, rank)
     if len(my_gradients) != len(mine):
       raise ValueError(f"rank {rank} must pass the gradients of workers {mine}")
-    if not self.collective or world == 1:
-      return list(my_gradients)
+    if not self.collective:  # (one rank with forced collectives still goes through the exchange: that is how a
+      return list(my_gradients)  #  single-GPU box exercises the RCCL all-to-all)
     lo0, hi0 = shard_bounds(d, world, 0)
     per = hi0 - lo0                       # padded shard length (multiple of 64 coordinates)
     n_max = -(-n // world)

@@ -423,6 +423,16 @@ def test_rccl_path_on_one_gpu(bm):
     plain = ShardedAggregator(force_collectives=True, native_comm=False)
     assert plain.native is None and not plain.single_call
     assert torch.equal(plain.bulyan(dev, 5), out) and torch.equal(plain.krum(dev, 5), bm.krum(dev, 5))
+    # worker-major -> dimension-major: the all-to-all really goes through RCCL here (one rank, forced
+    # collectives); with one rank the layout it returns is every gradient restricted to [0, d): the inputs themselves,
+    # as contiguous 256-byte aligned views of ONE receive buffer, accepted as they are by the rules
+    for d_odd in (40007, 64, 1):
+      grads = [g[:d_odd].contiguous() for g in dev[:7]]
+      local = agg.to_dim_sharded(grads, 7, d_odd)
+      assert len(local) == 7 and all(torch.equal(a, b) for a, b in zip(local, grads))
+      assert all(t.is_contiguous() and t.data_ptr() % 256 == 0 for t in local)
+      assert local[0].untyped_storage().data_ptr() == local[6].untyped_storage().data_ptr()
+      assert torch.equal(agg.median(local), bm.median(grads)) and torch.equal(agg.krum(local, 1), bm.krum(grads, 1))
     # a whole step through forced collectives equals the step without any
     from byzantinemomentum_amd.step import AggregationStep
     a = AggregationStep(25, 5, 5, gar="bulyan", nb_past=2, aggregator=agg)

@@ -276,3 +276,82 @@ def test_full_size_aksel_and_cge_against_fp64(bm):
   for i in sel[1:]:
     ref.add_(rows[i])
   assert same_bits(bm.cge(rows, f), ref.cpu().div_(keep))
+
+
+# ---------------------------------------------------------------------------- #
+# The burst form of bm_momentum_stats (one workgroup per CU, barrier between the loads and the stores) is the default
+# from 8 iterations per CU on (4.2 M coordinates: the C5-size tests run it); here at every length
+
+def test_momentum_stats_burst_form_at_short_lengths():
+  import subprocess
+  import sys
+  from tests.test_gpu_parity_r2 import ROOT
+  env = dict(os.environ, BM_STEP_BURST="1", PYTHONPATH=ROOT)
+  out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity_r2.py"), "-q", "-x",
+                        "-m", "gpu", "-k", "test_momentum_stats_kernel_tiers or test_step_all_placements or "
+                        "test_single_call_step_equals_python_sequence"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=1200)
+  assert out.returncode == 0, (out.stdout[-3000:], out.stderr[-2000:])
+
+
+def test_study_stats_against_fp64(bm):
+  """bm_study_stats alone, every curvature mode, with and without attack / l2, odd lengths and unaligned views:
+  every slot against fp64 torch, C against the same fp32 operations."""
+  gen = torch.Generator(device=DEV).manual_seed(11)
+  for d, off in ((100003, 0), (4099, 1), (64, 0), (3, 0), (262147, 2)):
+    def vec():
+      return torch.randn(d + off, device=DEV, generator=gen)[off:]
+    s, h, df, byz, past, old, par, org = (vec() for _ in range(8))
+    for f_real in (0, 1, 5):
+      for mode in (0, 1, 2, 3):
+        for l2 in (False, True):
+          curv0 = vec()
+          curv = curv0.clone()
+          mu, w = 0.9, -(0.9 ** 4)
+          out = bm.stats.study_stats(s, h, df, byz if f_real else None, f_real, past_newest=past if mode >= 2 else None,
+                                     curv=curv if mode >= 1 else None, past_oldest=old if mode == 3 else None,
+                                     curv_mode=mode, mu=mu, oldest_weight=w, params=par if l2 else None,
+                                     origin=org if l2 else None).tolist()
+          core = [s, h, df]
+          if f_real:
+            a = byz.clone()
+            for _ in range(f_real - 1):
+              a = a + byz
+            a = a / f_real
+            core.append(a)
+          c64 = [c.double() for c in core]
+          for i in range(4):
+            for j in range(4):
+              want = float(torch.dot(c64[i], c64[j])) if i < len(core) and j < len(core) else 0.0
+              scale = math.sqrt(float(c64[i].pow(2).sum()) * float(c64[j].pow(2).sum())) if want else 1.0
+              assert abs(out[4 * i + j] - want) <= 1e-6 * scale, (d, f_real, mode, i, j)
+          if f_real:
+            assert abs(out[18] - float(c64[3].pow(2).sum())) <= 1e-6 * out[18]
+            dev = f_real * float((byz.double() - c64[3]).pow(2).sum())
+            assert abs(out[19] - dev) <= 1e-5 * dev + 1e-30, (out[19], dev)
+            assert out[20] == float(core[3].abs().max())
+          else:
+            assert out[18] == out[19] == out[20] == 0.0
+          assert out[21] == float(df.abs().max())
+          if mode >= 2:
+            for slot, other in ((16, past), (17, curv0)):
+              want = float(torch.dot(c64[0], other.double()))
+              assert abs(out[slot] - want) <= 1e-6 * math.sqrt(float(c64[0].pow(2).sum()) * float(other.double().pow(2).sum()))
+          else:
+            assert out[16] == out[17] == 0.0
+          want_l2 = float((par.double() - org.double()).pow(2).sum()) if l2 else 0.0
+          assert abs(out[22] - want_l2) <= 1e-6 * want_l2
+          if mode == 0:
+            assert torch.equal(curv, curv0)
+          elif mode == 1:
+            assert torch.equal(curv, s)
+          else:
+            t = curv0 if mode == 2 else torch.addcmul(curv0, torch.full_like(old, w), old)  # fma(w, oldest, C)
+            want_c = s + mu * t
+            assert float((curv - want_c).abs().max()) <= 2e-7 * float(want_c.abs().max()), (d, mode)
+  # NaN in the defense vector / the Byzantine vector propagates to the maxima like torch's abs().max()
+  s, h, df, byz = (torch.randn(1000, device=DEV, generator=gen) for _ in range(4))
+  df[17] = float("nan")
+  byz[3] = float("nan")
+  out = bm.stats.study_stats(s, h, df, byz, 2).tolist()
+  assert math.isnan(out[20]) and math.isnan(out[21])
