@@ -16,14 +16,14 @@ static double env_double(const char* name, double dflt) {
   return atof(v);
 }
 const Tuning& tuning() {
-  static const Tuning t = {env_int("BM_COL_BURST", 8),  env_int("BM_MEAN_BURST", 8), env_int("BM_BUL_BURST", 0),
+  static const Tuning t = {env_int("BM_COL_BURST", 8),  env_int("BM_MEAN_BURST", 8),
                            env_int("BM_STEP_BURST", 8), env_int("BM_STEP_STREAM", 0), env_int("BM_PAIR_MODE", 0),
                            env_int("BM_PAIR_PLANES", 0), env_int("BM_PAIR_DITHER", 0), env_double("BM_PAIR_TAU", 2e-3)};
   return t;
 }
 }  // namespace bm
 
-extern "C" int bm_abi_version(void) { return 10; }
+extern "C" int bm_abi_version(void) { return 11; }
 
 extern "C" const char* bm_error_string(int code) {
   if (code == 0) return "success";

@@ -226,6 +226,27 @@ static inline int compute_units() {
   return cached[dev];
 }
 
+// "Am I the last workgroup of this launch to get here?" — the placement-independent hand-off of the CDNA4 guide
+// (cdna_hip_programming.md, guideline 16): every wave drains its stores, the workgroup meets, ONE lane releases at
+// agent scope (L2 write-back: the per-XCD L2s are not coherent with each other), takes a ticket from `counter`,
+// and the workgroup holding the last ticket acquires at agent scope (its CU's L1 is invalidated) before it reads
+// what the others wrote with plain loads.  `counter` must be zero when the launch starts: the kernel that precedes
+// the launch on the stream zeroes it, every call.  Returns the same value on every lane of the workgroup.
+__device__ __forceinline__ bool arrive_last(int* counter, int total, int* lds_flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int ticket = atomicAdd(counter, 1);
+    const int last = (ticket == total - 1) ? 1 : 0;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *lds_flag = last;
+  }
+  __syncthreads();
+  return *lds_flag != 0;
+}
+
 // Deterministic block reduction (sum) of one double per thread; result valid on thread 0.
 template <int BLOCK>
 __device__ __forceinline__ double block_reduce_sum(double v, double* lds /* BLOCK/64 doubles */) {
@@ -251,7 +272,6 @@ namespace bm {
 struct Tuning {
   int col_burst;       // BM_COL_BURST: iterations per CU from which median / trmean take their burst form (default 8; 0 = never, 1 = always: tests)
   int mean_burst;      // BM_MEAN_BURST: the same for the selected mean (default 8)
-  int bul_burst;       // BM_BUL_BURST: the same for Bulyan's pass 2
   int step_burst;      // BM_STEP_BURST: the same for bm_momentum_stats (default 8)
   int step_stream;     // BM_STEP_STREAM: 1 = the streaming form of bm_momentum_stats at every row count (tests)
   int pair_mode;       // BM_PAIR_MODE: 0 = centred bf16 Gram + accuracy gate (default), 1 = direct differences for every pair

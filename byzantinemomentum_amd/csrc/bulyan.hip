@@ -21,11 +21,11 @@ constexpr int kBulBlock = 256;
 // Register-resident Bulyan pass 2 for a compile-time (n, f) and the default m = m_max.
 // ---------------------------------------------------------------------------
 //
-// BURST = true is the chip-wide store-burst form of colwise_burst_kernel (colwise_kernels.h): one workgroup of 1024
-// lanes per CU, column groups interleaved across the CUs, results of 10 iterations staged in LDS, a barrier, then
-// written back to back.  PREPARED AT THE END OF ROUND 2, NOT YET RUN ON HARDWARE: off unless BM_BUL_BURST > 0.
-template <int N, int F, int VEC, bool BURST = false>
-__global__ __launch_bounds__(BURST ? kBurstThreads : kBulBlock) void bulyan_pass2_kernel(
+// (The chip-wide store-burst form that pays for the column kernels and the selected mean does not pay here: measured
+// in round 3 with identical checksums, 153.0 -> 154.1 us at n = 25, 357.7 -> 359.1 us at n = 51, 87.2 -> 85.8 us at
+// n = 15, profiles/r03_c_bulyan_pass2_burst_ab.txt.  It was removed.)
+template <int N, int F, int VEC>
+__global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(
     RowTable rows, const int32_t* __restrict__ order, int64_t nvec, int nt_result, float* __restrict__ out) {
   constexpr int MMAX = N - F - 2;
   constexpr int THETA = N - 2 * F - 2;
@@ -100,40 +100,7 @@ __global__ __launch_bounds__(BURST ? kBurstThreads : kBulBlock) void bulyan_pass
       r[c] = has_nan ? kNaN : res;
     }
   };
-  if constexpr (BURST) {
-    using V = typename VecLoad<VEC>::T;
-    constexpr int kSlots = kBurstLdsBytes / (kBurstThreads * VEC * (int)sizeof(float));
-    __shared__ V stage[kSlots * kBurstThreads];
-    const uint32_t span = gridDim.x * kBurstThreads;
-    const uint32_t iters = (nv + span - 1) / span;
-    const uint32_t first = blockIdx.x * kBurstThreads + threadIdx.x;
-    for (uint32_t p0 = 0; p0 < iters; p0 += kSlots) {
-      const uint32_t p1 = (p0 + kSlots < iters) ? p0 + kSlots : iters;
-      for (uint32_t it = p0; it < p1; ++it) {
-        const uint32_t v = it * span + first;
-        if (v < nv) {
-          float x[VEC][MMAX], r[VEC];
-          load_group(v * (uint32_t)(VEC * sizeof(float)), x);
-          rule(x, r);
-          V packed;
-          if constexpr (VEC == 1) {
-            packed = r[0];
-          } else {
-#pragma unroll
-            for (int c = 0; c < VEC; ++c) packed[c] = r[c];
-          }
-          stage[(it - p0) * kBurstThreads + threadIdx.x] = packed;
-        }
-      }
-      __syncthreads();  // what makes the stores below a burst
-      for (uint32_t it = p0; it < p1; ++it) {
-        const uint32_t v = it * span + first;
-        if (v < nv) __builtin_nontemporal_store(stage[(it - p0) * kBurstThreads + threadIdx.x], reinterpret_cast<V*>(out) + v);
-      }
-    }
-    (void)stride;
-    (void)nt_result;
-  } else {
+  {
     for (uint32_t v = blockIdx.x * kBulBlock + threadIdx.x; v < nv; v += stride) {
       const uint32_t off = v * (uint32_t)(VEC * sizeof(float));
       float x[VEC][MMAX], r[VEC];
@@ -210,20 +177,9 @@ static int launch_bulyan_fast(const float* const* rows_host, const int32_t* orde
     int64_t body = 0;
     if (vec == 4 && kMaxVec >= 4 && d / 4 > 0) {
       const int64_t nvec = d / 4;
-      bool burst = false;
-      if constexpr (kMaxVec >= 4 && N <= 25) {
-        const int cus = compute_units();
-        if (tuning().bul_burst > 0 && nvec / ((int64_t)cus * kBurstThreads) >= tuning().bul_burst) {
-          hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 4 ? 4 : 1), true>), dim3(cus), dim3(kBurstThreads),
-                             0, s, tab, order, nvec, 1, out);
-          burst = true;
-        }
-      }
-      if (!burst) {
-        hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 4 ? 4 : 1)>),
-                           dim3(stream_grid(nvec, kBulBlock, kColMaxBlocks)), dim3(kBulBlock), 0,
-                           s, tab, order, nvec, 1, out);
-      }
+      hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 4 ? 4 : 1)>),
+                         dim3(stream_grid(nvec, kBulBlock, kColMaxBlocks)), dim3(kBulBlock), 0,
+                         s, tab, order, nvec, 1, out);
       BM_LAUNCH_CHECK();
       body = nvec * 4;
     } else if (vec == 2 && kMaxVec >= 2 && d / 2 > 0) {

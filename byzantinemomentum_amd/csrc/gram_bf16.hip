@@ -153,7 +153,8 @@ struct B3Shape {
 
 template <int K, int NPL, bool ALIGNED>
 __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_partial_kernel(
-    RowTable rows, int n, int64_t d, float inv_n, int centre, unsigned dither_seed, double* __restrict__ partial) {
+    RowTable rows, int n, int64_t d, float inv_n, int centre, unsigned dither_seed, double* __restrict__ partial,
+    int* __restrict__ arrival) {
   using S = B3Shape<K, NPL>;
   constexpr int RB = S::RB, NP = S::NP, NSETS = S::NSETS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -169,6 +170,8 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
     KargTable karg = (KargTable)__builtin_amdgcn_kernarg_segment_ptr();
     row_ptr[tid] = (const float*)karg[tid < n ? tid : 0];
   }
+  // the arrival counter of this call's reduction (gram_reduce_sqdist_kernel, next on the stream) starts from zero
+  if (blockIdx.x == 0 && tid == 0 && arrival != nullptr) *arrival = 0;
   __syncthreads();
 
   // ---- load side: lane (rho, x) owns coordinates 4x..4x+3 of rows 4k+rho ----
@@ -185,10 +188,15 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
   const bool last_ok = (16 * (RB - 1) + li) < S::N4;
   const int rd_last0 = last_ok ? rd0 + (RB - 1) * 16 * kB3RowBytes : (lg << 4);
 
-  // Per-wave running sums of the chunk results, fp32 over 85-280 chunks.  (Rows of few distinct values do not make
-  // this sum drift: when every chunk adds the same value that value has a short mantissa — products of two bf16 —
-  // and the sum stays exact; otherwise the terms differ in their low bits and the roundings average out.  Measured
-  // in round 3: fp64 running sums changed no result, they only cost 40 VGPRs.)
+  // Per-wave running sums of the chunk results, fp32 over 85-280 chunks, DITHERED: acc <- acc + fma(acc, rc, t) with
+  // rc a zero-mean pseudo-random number of the order of one ulp, a function of the chunk index alone.  Why: on rows
+  // of few distinct values every chunk adds (nearly) the same t, the rounding of acc + t has the same sign step after
+  // step and in all 2 048 waves at once, and the error grows like 2^-25 * chunks instead of averaging out —
+  // measured in round 3 on exactly constant rows: 1.2e-4 on a squared distance that cancels 200-fold at d = 11.2 M,
+  // 1.7e-5 at 2.5 M, nothing at 2^20.  The dither (triangular, two uniform terms of 1..2 ulp each: the bias that
+  // is left is below 5 % of the undithered one whatever the binade position) makes the roundings of a wave
+  // independent of each other and of the other waves', at the price of one v_fma per accumulator and chunk; every
+  // entry of a chunk sees the same rc, so bitwise-equal rows keep bitwise-equal sums.
   using Acc = float;
   Acc outer[NP][4];
 #pragma unroll
@@ -302,12 +310,15 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
   // round 3).  So every accumulator only ever sums products of ONE magnitude class — S0 = h h, S3 = m m, S1 = h m
   // (+ h l), S2 = m h (+ l h) — sums that are exact for such rows, and the classes meet in round-to-nearest VALU
   // additions: t = S0 + ((S1 + S2) + S3), symmetric under the exchange of the two rows like S0 + (S1 + S2) was.
-  auto fold = [](Acc (&acc)[4], const f32x4 a0, const f32x4 a1, const f32x4 a2, const f32x4 a3) {
+  auto fold = [](Acc (&acc)[4], const f32x4 a0, const f32x4 a1, const f32x4 a2, const f32x4 a3, const float rc) {
     const f32x4 t = a0 + ((a1 + a2) + a3);
 #pragma unroll
-    for (int v = 0; v < 4; ++v) acc[v] += (Acc)t[v];
+    for (int v = 0; v < 4; ++v) acc[v] = acc[v] + __builtin_fmaf(acc[v], rc, t[v]);
   };
-  auto multiply = [&]() {
+  auto multiply = [&](int64_t chunk) {
+    // rc = (u1 + u2 - 1) * 2^-23 with u1, u2 uniform on [0, 1): 16 bits each from one mix of the chunk index
+    const unsigned z = dither_pair((unsigned)chunk * 2u + 0x3C6EF372u);
+    const float rc = (float)((int)(z & 0xffffu) + (int)(z >> 16) - 65536) * 0x1.0p-39f;
     u32x4 fh[2][RB], fm[2][RB], fl[2][RB];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -345,17 +356,17 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
           s2 = mfma_bf16(fl[1][I], fh[1][J], s2);
         }
         if constexpr (S::PIPE) {
-          if (p > 0) fold(outer[p - 1], q0, q1, q2, q3);
+          if (p > 0) fold(outer[p - 1], q0, q1, q2, q3, rc);
           q0 = s0;
           q1 = s1;
           q2 = s2;
           q3 = s3;
         } else {
-          fold(outer[p], s0, s1, s2, s3);
+          fold(outer[p], s0, s1, s2, s3, rc);
         }
         ++p;
       }
-    if constexpr (S::PIPE) fold(outer[NP - 1], q0, q1, q2, q3);
+    if constexpr (S::PIPE) fold(outer[NP - 1], q0, q1, q2, q3, rc);
   };
 
   // ---- main loop: loads of the next chunk(s) stay in flight under the MFMAs of this one ----
@@ -370,7 +381,7 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
         contract(xs[b], c);
         const int64_t nxt = c + NSETS * nw;
         if (nxt < nchunks) issue(nxt, xs[b]);
-        multiply();
+        multiply(c);
       }
       c += nw;
     }
@@ -402,31 +413,8 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
     }
 }
 
-// G = sum over workgroups (fixed order), then sq[i][j] = G_ii + G_jj - 2 G_ij in fp64.
-constexpr int kGramRedWaves = 16;  // 16 waves x 16 loads in flight: the sum is a latency chain over L2/HBM
-__global__ __launch_bounds__(64 * kGramRedWaves) void gram_reduce_kernel(const double* __restrict__ partial,
-                                                                         int nblocks, int n,
-                                                                         double* __restrict__ gram) {
-  __shared__ double wsum[kGramRedWaves][64];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int per_block = n * (n + 1) / 2;
-  const int e = blockIdx.x * 64 + lane;
-  double s = 0.0;
-  if (e < per_block) {
-#pragma unroll 16
-    for (int blk = wave; blk < nblocks; blk += kGramRedWaves) s += partial[(int64_t)blk * per_block + e];
-  }
-  wsum[wave][lane] = s;
-  __syncthreads();
-  if (wave != 0 || e >= per_block) return;
-  double tot = wsum[0][lane];
-#pragma unroll
-  for (int w = 1; w < kGramRedWaves; ++w) tot += wsum[w][lane];
-  gram[e] = tot;
-}
-
-// sq[i][j] = G_ii + G_jj - 2 G_ij in fp64, one workgroup.  Also decides whether the Gram form was
-// accurate enough: its absolute error is ~eps_G * (G_ii + G_jj) (eps_G ~ 6e-9, measured), so a pair
+// sq[i][j] = G_ii + G_jj - 2 G_ij in fp64, by one workgroup of kSqThreads lanes.  Also decides whether the Gram form
+// was accurate enough: its absolute error is ~eps_G * (G_ii + G_jj) (eps_G ~ 6e-9, measured), so a pair
 // whose squared distance is below tau * (G_ii + G_jj) — two rows that nearly coincide relative to
 // their (centred) norms — has lost relative accuracy eps_G / tau.  The rows of such pairs are listed in
 // `sub` (sub[0] = count, sub[1..] = indices, ascending); the caller recomputes the distances among them
@@ -434,10 +422,9 @@ __global__ __launch_bounds__(64 * kGramRedWaves) void gram_reduce_kernel(const d
 // lie close to EACH OTHER, so that sub-stack is exactly where the Gram form cannot be trusted.
 // Bitwise-equal rows (G_ii == G_jj == G_ij) are exact (d2 = 0) and never listed.
 constexpr int kSqThreads = 1024;
-__global__ __launch_bounds__(kSqThreads) void gram_to_sqdist_kernel(const double* __restrict__ gram, int n,
-                                                                    double tau, double* __restrict__ sq,
-                                                                    int* __restrict__ sub) {
-  __shared__ int listed[BM_MAX_ROWS];
+constexpr int kArrivalSlot = 96;  // int slot of the 512-byte row-list area that counts the workgroups of the reduction
+__device__ __forceinline__ void gram_to_sqdist(const double* __restrict__ gram, int n, double tau,
+                                               double* __restrict__ sq, int* __restrict__ sub, int* listed) {
   if (threadIdx.x < BM_MAX_ROWS) listed[threadIdx.x] = 0;
   __syncthreads();
   for (int e = threadIdx.x; e < n * n; e += kSqThreads) {
@@ -469,21 +456,56 @@ __global__ __launch_bounds__(kSqThreads) void gram_to_sqdist_kernel(const double
   }
 }
 
+// G = sum over workgroups (fixed order); the workgroup that finishes LAST (arrival counter in the row-list area,
+// zeroed by the Gram kernel of the same call) then forms the squared distances and the gate's row list: one launch
+// instead of two (the second one was 5-7 us of a 76 us per-rank aggregation at 8 GPUs).  Which workgroup comes
+// last does not matter for the result: every entry of G is summed by one workgroup in a fixed order.
+constexpr int kGramRedWaves = 16;  // 16 waves x 16 loads in flight: the sum is a latency chain over L2/HBM
+static_assert(64 * kGramRedWaves == kSqThreads, "the last workgroup of the reduction runs gram_to_sqdist");
+__global__ __launch_bounds__(64 * kGramRedWaves) void gram_reduce_sqdist_kernel(
+    const double* __restrict__ partial, int nblocks, int n, double* __restrict__ gram, double tau,
+    double* __restrict__ sq, int* __restrict__ sub) {
+  __shared__ double wsum[kGramRedWaves][64];
+  __shared__ int listed[BM_MAX_ROWS];
+  __shared__ int last;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int per_block = n * (n + 1) / 2;
+  const int e = blockIdx.x * 64 + lane;
+  double s = 0.0;
+  if (e < per_block) {
+#pragma unroll 16
+    for (int blk = wave; blk < nblocks; blk += kGramRedWaves) s += partial[(int64_t)blk * per_block + e];
+  }
+  wsum[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0 && e < per_block) {
+    double tot = wsum[0][lane];
+#pragma unroll
+    for (int w = 1; w < kGramRedWaves; ++w) tot += wsum[w][lane];
+    gram[e] = tot;
+  }
+  // arrival: release this workgroup's entries of G, take a ticket; the last ticket acquires everybody's
+  if (!arrive_last(sub + kArrivalSlot, (int)gridDim.x, &last)) return;
+  gram_to_sqdist(gram, n, tau, sq, sub, listed);
+  if (threadIdx.x == 0) {
+    sub[kArrivalSlot] = 0;
+    sub[kArrivalSlot + 1] = 0;  // arrival counter of the gated direct kernel (pairwise.hip), next on the stream
+  }
+}
+
 // Fixed-order sum of the per-workgroup partial Gram matrices, then squared distances + accuracy flag.
 int gram_finish(const double* partial, int blocks, int n, double* gram, double* sq_nxn, int* sub, double tau,
                 hipStream_t s) {
   const int64_t per_block = (int64_t)n * (n + 1) / 2;
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3((int)((per_block + 63) / 64)), dim3(64 * kGramRedWaves), 0, s,
-                     partial, blocks, n, gram);
-  BM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gram_to_sqdist_kernel, dim3(1), dim3(kSqThreads), 0, s, gram, n, tau, sq_nxn, sub);
+  hipLaunchKernelGGL(gram_reduce_sqdist_kernel, dim3((int)((per_block + 63) / 64)), dim3(64 * kGramRedWaves), 0, s,
+                     partial, blocks, n, gram, tau, sq_nxn, sub);
   BM_LAUNCH_CHECK();
   return 0;
 }
 
 template <int K, int NPL>
 static int launch_gram3_planes(const RowTable& tab, int n, int64_t d, bool aligned, int centre, double* partial,
-                               int blocks, hipStream_t s) {
+                               int* arrival, int blocks, hipStream_t s) {
   using S = B3Shape<K, NPL>;
   auto kern = aligned ? gram3_partial_kernel<K, NPL, true> : gram3_partial_kernel<K, NPL, false>;
   if (S::kLds > 64 * 1024) {
@@ -492,16 +514,16 @@ static int launch_gram3_planes(const RowTable& tab, int n, int64_t d, bool align
     if (e != hipSuccess) return hip_code(e);
   }
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * kB3Waves), S::kLds, s, tab, n, d, 1.0f / (float)n, centre,
-                     (unsigned)tuning().pair_dither, partial);
+                     (unsigned)tuning().pair_dither, partial, arrival);
   BM_LAUNCH_CHECK();
   return 0;
 }
 
 template <int K>
 static int launch_gram3(const RowTable& tab, int n, int64_t d, bool aligned, int centre, int planes,
-                        double* partial, int blocks, hipStream_t s) {
-  return planes == 2 ? launch_gram3_planes<K, 2>(tab, n, d, aligned, centre, partial, blocks, s)
-                     : launch_gram3_planes<K, 3>(tab, n, d, aligned, centre, partial, blocks, s);
+                        double* partial, int* arrival, int blocks, hipStream_t s) {
+  return planes == 2 ? launch_gram3_planes<K, 2>(tab, n, d, aligned, centre, partial, arrival, blocks, s)
+                     : launch_gram3_planes<K, 3>(tab, n, d, aligned, centre, partial, arrival, blocks, s);
 }
 
 constexpr int kB3MaxBlocks = 1024;
@@ -509,9 +531,10 @@ constexpr int kB3MaxBlocks = 1024;
 int64_t gram3_partial_doubles(int n) { return (int64_t)kB3MaxBlocks * ((int64_t)n * (n + 1) / 2); }
 
 // Partial Gram matrices of the centred rows; returns the number of workgroups (= partial blocks)
-// through *blocks_out.  `partial` holds gram3_partial_doubles(n) doubles.
-int gram3_partials(const float* const* rows, int n, int64_t d, int64_t d_total, double* partial, int* blocks_out,
-                   hipStream_t s) {
+// through *blocks_out.  `partial` holds gram3_partial_doubles(n) doubles; `sub` is the 512-byte row-list area of the
+// accuracy gate, whose arrival counter (for gram_finish, next on the stream) this launch resets.
+int gram3_partials(const float* const* rows, int n, int64_t d, int64_t d_total, double* partial, int* sub,
+                   int* blocks_out, hipStream_t s) {
   RowTable tab{};
   for (int i = 0; i < n; ++i) tab.p[i] = rows[i];
   const bool aligned = common_vec_width(reinterpret_cast<const void* const*>(rows), n, nullptr) == 4;
@@ -534,7 +557,7 @@ int gram3_partials(const float* const* rows, int n, int64_t d, int64_t d_total, 
   int rc;
   switch (K) {
 #define BM_B3_CASE(KK) \
-  case KK: rc = launch_gram3<KK>(tab, n, d, aligned, centre, planes, partial, blocks, s); break;
+  case KK: rc = launch_gram3<KK>(tab, n, d, aligned, centre, planes, partial, sub + kArrivalSlot, blocks, s); break;
     BM_B3_CASE(1) BM_B3_CASE(2) BM_B3_CASE(3) BM_B3_CASE(4) BM_B3_CASE(5) BM_B3_CASE(6) BM_B3_CASE(7)
     BM_B3_CASE(8) BM_B3_CASE(9) BM_B3_CASE(10) BM_B3_CASE(11) BM_B3_CASE(12) BM_B3_CASE(13) BM_B3_CASE(14)
     BM_B3_CASE(15) BM_B3_CASE(16)

@@ -138,13 +138,46 @@ __device__ __forceinline__ int row_offset_bytes(const PairGeom& g, int I, int a)
   return blk * kDmaPitch + (a % g.rb) * g.row_bytes;
 }
 
+constexpr int kRedWaves = 8;
+constexpr int kDirectArrivalSlot = 97;  // int slot of the gate's 512-byte row-list area: arrival counter of the gated call
+
+// entry e = tile*16 + a*4 + b of a reduced partial -> sq[i][j] and sq[j][i] (sub: sub-stack position -> row)
+__device__ __forceinline__ void pair_scatter(int e, double tot, const PairGeom& g, int n_full, double* __restrict__ sq,
+                                             const int* __restrict__ sub) {
+  const int tile = e >> 4, a = (e >> 2) & 3, b = e & 3;
+  int I = 0, t = tile, row_len = g.ng;
+  while (t >= row_len) {
+    t -= row_len;
+    --row_len;
+    ++I;
+  }
+  const int J = I + t;
+  int i = I * kTileR + a, j = J * kTileR + b;
+  if (i >= g.n || j >= g.n) return;
+  const bool keep = (i != j) && (I != J || a < b);
+  if (sub != nullptr) {  // sub-stack position -> row of the full stack
+    i = sub[1 + i];
+    j = sub[1 + j];
+  }
+  const int n = n_full;
+  if (i == j) {
+    sq[i * n + j] = 0.0;
+  } else if (keep) {
+    // off-diagonal tiles hold each unordered pair once; diagonal tiles hold (a,b) and (b,a)
+    // with bitwise-equal sums, keep the a<b copy
+    sq[i * n + j] = tot;
+    sq[j * n + i] = tot;
+  }
+}
+
 // ALIGNED: every row pointer is 16-byte aligned -> full tiles are brought in by the LDS-DMA
 // engine (global_load_lds_dwordx4: no staging VGPRs, no ds_write) into the OTHER of two tile
 // buffers while the workgroup computes on the current one.  Ragged last tiles and unaligned inputs
 // use a plain load + ds_write loop (same layout, not overlapped).
 template <bool ALIGNED, int ABLATE = 0>
 __global__ __launch_bounds__(kPairMaxThreads) void pairwise_partial_kernel(
-    RowTable rows, PairGeom g, int64_t d, double* __restrict__ partial, const int* __restrict__ sub) {
+    RowTable rows, PairGeom g, int64_t d, double* __restrict__ partial, int* __restrict__ sub, int n_full,
+    double* __restrict__ sq) {
   // sub (device, may be NULL): the rows the accuracy gate of the Gram path asks to recompute
   // (gram_to_sqdist_kernel): sub[0] = how many (0: this launch has nothing to do), sub[1..] = their
   // indices.  The kernel then works on that sub-stack with the geometry of ITS row count.
@@ -325,20 +358,41 @@ __global__ __launch_bounds__(kPairMaxThreads) void pairwise_partial_kernel(
     for (int st = 0; st < g.strips; ++st) s += (double)red[st * per_block + e];
     partial[(int64_t)blockIdx.x * per_block + e] = s;
   }
+  if (sub == nullptr) return;  // whole-stack call: pairwise_reduce_kernel follows on the stream
+  // Gated call: the workgroup that arrives LAST adds the partials itself, in the order of pairwise_reduce_kernel
+  // (same bits), so that the common case — an empty row list — costs one empty launch instead of two.
+  __shared__ double wsum[kRedWaves][64];
+  __shared__ int last;
+  if (!arrive_last(sub + kDirectArrivalSlot, (int)gridDim.x, &last)) return;
+  for (int e0 = 0; e0 < per_block; e0 += 64) {
+    for (int q = tid; q < 64 * kRedWaves; q += blockDim.x) {
+      const int w = q >> 6, e = e0 + (q & 63);
+      double s = 0.0;
+      if (e < per_block) {
+#pragma unroll 16
+        for (int blk = w; blk < (int)gridDim.x; blk += kRedWaves) s += partial[(int64_t)blk * per_block + e];
+      }
+      wsum[w][q & 63] = s;
+    }
+    __syncthreads();
+    if (tid < 64 && e0 + tid < per_block) {
+      double tot = wsum[0][tid];
+#pragma unroll
+      for (int w = 1; w < kRedWaves; ++w) tot += wsum[w][tid];
+      pair_scatter(e0 + tid, tot, g, n_full, sq, sub);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) sub[kDirectArrivalSlot] = 0;
 }
 
 // Cross-workgroup reduction in a fixed order.  A workgroup of 8 waves owns 64 consecutive
 // partial entries e = tile*16 + a*4 + b (coalesced 512-byte reads); wave w adds the partials of
 // workgroups w, w+8, ... in increasing order, then wave 0 adds the 8 wave sums in order and
-// scatters the value to sq[i][j] and sq[j][i].
-constexpr int kRedWaves = 8;
+// scatters the value to sq[i][j] and sq[j][i].  (Whole-stack calls; the gated call reduces inside
+// pairwise_partial_kernel, in the same order.)
 __global__ __launch_bounds__(64 * kRedWaves) void pairwise_reduce_kernel(
-    const double* __restrict__ partial, int nblocks, PairGeom g, int n_full, double* __restrict__ sq,
-    const int* __restrict__ sub) {
-  if (sub != nullptr) {
-    if (sub[0] == 0) return;
-    g = pair_geometry(sub[0], 0);
-  }
+    const double* __restrict__ partial, int nblocks, PairGeom g, int n_full, double* __restrict__ sq) {
   __shared__ double wsum[kRedWaves][64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int per_block = g.tiles * 16;
@@ -354,31 +408,7 @@ __global__ __launch_bounds__(64 * kRedWaves) void pairwise_reduce_kernel(
   double tot = wsum[0][lane];
 #pragma unroll
   for (int w = 1; w < kRedWaves; ++w) tot += wsum[w][lane];
-  // e -> (tile, a, b) -> (I, J) -> (i, j)
-  const int tile = e >> 4, a = (e >> 2) & 3, b = e & 3;
-  int I = 0, t = tile, row_len = g.ng;
-  while (t >= row_len) {
-    t -= row_len;
-    --row_len;
-    ++I;
-  }
-  const int J = I + t;
-  int i = I * kTileR + a, j = J * kTileR + b;
-  if (i >= g.n || j >= g.n) return;
-  const bool keep = (i != j) && (I != J || a < b);
-  if (sub != nullptr) {  // sub-stack position -> row of the full stack
-    i = sub[1 + i];
-    j = sub[1 + j];
-  }
-  const int n = n_full;
-  if (i == j) {
-    sq[i * n + j] = 0.0;
-  } else if (keep) {
-    // off-diagonal tiles hold each unordered pair once; diagonal tiles hold (a,b) and (b,a)
-    // with bitwise-equal sums, keep the a<b copy
-    sq[i * n + j] = tot;
-    sq[j * n + i] = tot;
-  }
+  pair_scatter(e, tot, g, n_full, sq, nullptr);
 }
 
 static int pair_grid_blocks(const PairGeom& g, int64_t d) {
@@ -394,34 +424,36 @@ static int pair_grid_blocks(const PairGeom& g, int64_t d) {
 // fp64 — the same sequence of additions as the reference's `sum(sorted(...)[:take])`.
 // ---------------------------------------------------------------------------
 constexpr int kRankThreads = 1024;
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  const unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)bits, lane);
+  const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), lane);
+  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __global__ __launch_bounds__(kRankThreads) void krum_rank_kernel(const double* __restrict__ sq, int n,
                                                                  int f, int m, int mode,
                                                                  int32_t* __restrict__ order,
                                                                  double* __restrict__ scores_out) {
-  __shared__ double dist[BM_MAX_ROWS][BM_MAX_ROWS + 1];
-  __shared__ unsigned char pos[BM_MAX_ROWS][BM_MAX_ROWS];
+  __shared__ double srt[BM_MAX_ROWS][BM_MAX_ROWS + 1];  // srt[i][r] = r-th smallest distance of row i to the others
   __shared__ double score[BM_MAX_ROWS];
   const double kInf = __builtin_inf();
-  const int tid = threadIdx.x;
-  for (int e = tid; e < n * n; e += kRankThreads) {
-    const int i = e / n, j = e - i * n;
-    // sqrt in fp64, non-finite -> +inf (krum.py:46-47)
-    double v = sqrt(sq[e]);
-    if (!(v == v) || v == kInf || v == -kInf) v = kInf;
-    dist[i][j] = v;
-  }
-  __syncthreads();
-  for (int e = tid; e < n * n; e += kRankThreads) {
-    const int i = e / n, j = e - i * n;
-    if (i == j) continue;
-    const double v = dist[i][j];
-    int rank = 0;
-#pragma unroll 8
-    for (int l = 0; l < n; ++l) {  // independent LDS reads: unrolled so that they pipeline
-      const double o = dist[i][l];
-      rank += (l != i && (o < v || (o == v && l < j))) ? 1 : 0;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // One wave per row (n <= 64): lane j holds dist(i, j) = sqrt in fp64, non-finite -> +inf (krum.py:46-47); its rank
+  // among the row's other distances is counted against every lane's value broadcast from its register
+  // (v_readlane: no LDS traffic; round 2 read n^2 * n doubles from LDS here, 8 us of the 19 at n = 51).
+  for (int i = wave; i < n; i += kRankThreads / 64) {
+    const bool mine = lane < n && lane != i;
+    double v = kInf;
+    if (mine) {
+      v = sqrt(sq[i * n + lane]);
+      if (!(v == v) || v == kInf || v == -kInf) v = kInf;
     }
-    pos[i][rank] = (unsigned char)j;
+    int rank = 0;
+    for (int l = 0; l < n; ++l) {  // wave-uniform
+      const double o = readlane_f64(v, l);
+      rank += (l != i && (o < v || (o == v && l < lane))) ? 1 : 0;
+    }
+    if (mine) srt[i][rank] = v;
   }
   __syncthreads();
   if (tid < n) {
@@ -431,7 +463,7 @@ __global__ __launch_bounds__(kRankThreads) void krum_rank_kernel(const double* _
     if (take < 0) take = 0;
     double s = 0.0;
 #pragma unroll 8
-    for (int t = 0; t < take; ++t) s += dist[tid][pos[tid][t]];  // additions stay in ascending order
+    for (int t = 0; t < take; ++t) s += srt[tid][t];  // additions stay in ascending order
     score[tid] = s;
     if (scores_out != nullptr) scores_out[tid] = s;
   }
@@ -454,8 +486,8 @@ __global__ __launch_bounds__(kRankThreads) void krum_rank_kernel(const double* _
 namespace bm {
 int gram_finish(const double* partial, int blocks, int n, double* gram, double* sq_nxn, int* sub, double tau,
                 hipStream_t s);
-int gram3_partials(const float* const* rows, int n, int64_t d, int64_t d_total, double* partial, int* blocks_out,
-                   hipStream_t s);
+int gram3_partials(const float* const* rows, int n, int64_t d, int64_t d_total, double* partial, int* sub,
+                   int* blocks_out, hipStream_t s);
 int64_t gram3_partial_doubles(int n);
 
 // Workspace layout of bm_pairwise_sqdist: [row list of the gate: 512 B][Gram partials][Gram n(n+1)/2][direct partials]
@@ -466,7 +498,7 @@ static int64_t pair_gram_doubles(int n) { return gram3_partial_doubles(n) + (int
 // immediately when it is empty, else recompute exactly the pairs among the listed rows (device-side
 // decision, no host synchronisation; the launch is shaped for the worst case, all n rows).
 static int pairwise_direct(const float* const* rows, int n, int64_t d, double* sq_nxn, double* partial,
-                           const int* sub, hipStream_t s) {
+                           int* sub, hipStream_t s) {
   const PairGeom g = pair_geometry(n, 0);
   RowTable tab{};
   for (int i = 0; i < n; ++i) tab.p[i] = rows[i];
@@ -495,11 +527,13 @@ static int pairwise_direct(const float* const* rows, int n, int64_t d, double* s
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return hip_code(e);
   }
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds_bytes, s, tab, g, d, partial, sub);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds_bytes, s, tab, g, d, partial, sub, n, sq_nxn);
   BM_LAUNCH_CHECK();
-  hipLaunchKernelGGL(pairwise_reduce_kernel, dim3((per_block + 63) / 64), dim3(64 * kRedWaves), 0, s,
-                     partial, blocks, g, n, sq_nxn, sub);
-  BM_LAUNCH_CHECK();
+  if (sub == nullptr) {
+    hipLaunchKernelGGL(pairwise_reduce_kernel, dim3((per_block + 63) / 64), dim3(64 * kRedWaves), 0, s,
+                       partial, blocks, g, n, sq_nxn);
+    BM_LAUNCH_CHECK();
+  }
   return 0;
 }
 }  // namespace bm
@@ -526,7 +560,7 @@ extern "C" int bm_pairwise_sqdist_shard(const float* const* rows, int n, int64_t
   if (mode == 1) return pairwise_direct(rows, n, d, sq_nxn, direct_partial, nullptr, s);
   const double tau = tuning().pair_tau;
   int blocks = 0;
-  int rc = gram3_partials(rows, n, d, d_total, gram_partial, &blocks, s);
+  int rc = gram3_partials(rows, n, d, d_total, gram_partial, flag, &blocks, s);
   if (rc != 0) return rc;
   double* gram = gram_partial + gram3_partial_doubles(n);
   rc = gram_finish(gram_partial, blocks, n, gram, sq_nxn, flag, tau, s);

@@ -325,6 +325,52 @@ __global__ __launch_bounds__(64) void dot_finish_kernel(const double* __restrict
 }
 
 // ---------------------------------------------------------------------------
+// row_sqnorms: sq[i] = sum_j rows[i][j]^2 for k rows, every row read once by its own slice of the grid
+// (blockIdx.y = row).  Behind cge.py:28-38 (`gradient.norm().item()` per gradient) and the clipping of
+// attack.py:776-779,791-794; round 2 took the norms from 4 x 4 Gram blocks (bm_multi_dot, ceil(k/4) launches).
+// ---------------------------------------------------------------------------
+constexpr int kNormBlocks = 128;  // workgroups per row: k * 128 * 8 bytes of partials fit the BM_WS_DOT workspace
+template <int VEC>
+__global__ __launch_bounds__(kRedBlock) void row_sqnorms_kernel(RowTable rows, int64_t nvec, double* __restrict__ partial) {
+  __shared__ double red[kRedBlock / 64];
+  const float* row = rows.p[blockIdx.y];
+  float acc[2] = {0.0f, 0.0f};
+  const int64_t stride = (int64_t)gridDim.x * kRedBlock;
+  int64_t v = (int64_t)blockIdx.x * kRedBlock + threadIdx.x;
+  for (; v + stride < nvec; v += 2 * stride) {  // two loads in flight per lane
+    float a[VEC], b[VEC];
+    load_stream<VEC>(row + v * VEC, a);
+    load_stream<VEC>(row + (v + stride) * VEC, b);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      acc[0] = __builtin_fmaf(a[e], a[e], acc[0]);
+      acc[1] = __builtin_fmaf(b[e], b[e], acc[1]);
+    }
+  }
+  if (v < nvec) {
+    float a[VEC];
+    load_stream<VEC>(row + v * VEC, a);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[0] = __builtin_fmaf(a[e], a[e], acc[0]);
+  }
+  const double r = block_reduce_sum<kRedBlock>((double)acc[0] + (double)acc[1], red);
+  if (threadIdx.x == 0) partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = r;
+}
+
+// one wave per row: fixed-order sum of the row's body partials and of its (scalar) tail partial
+__global__ __launch_bounds__(64) void row_sqnorms_finish_kernel(const double* __restrict__ body, int nbody,
+                                                               const double* __restrict__ tail, int ntail,
+                                                               double* __restrict__ out) {
+  const int row = blockIdx.x, lane = threadIdx.x;
+  double tot = 0.0;
+  for (int b = lane; b < nbody; b += 64) tot += body[(int64_t)row * nbody + b];
+  for (int b = lane; b < ntail; b += 64) tot += tail[(int64_t)row * ntail + b];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
+  if (lane == 0) out[row] = tot;
+}
+
+// ---------------------------------------------------------------------------
 // multi_axpby: y_i = fma(b, x_i, a*y_i) for k vectors; blockIdx.y selects the vector.
 // (torch's vectorised `add_(x, alpha=b)` after `mul_(a)` is a*y rounded, then one fused
 //  multiply-add.)
@@ -556,6 +602,41 @@ extern "C" int bm_stable_argsort(const double* keys, int n, int32_t* order_out, 
   if (keys == nullptr || order_out == nullptr || n < 1 || n > BM_MAX_ROWS) return BM_EINVAL;
   hipLaunchKernelGGL(stable_argsort_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream),
                      keys, n, order_out);
+  BM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int bm_row_sqnorms(const float* const* rows, int k, int64_t d, double* sq_out, void* ws, void* stream) {
+  using namespace bm;
+  if (rows == nullptr || sq_out == nullptr || ws == nullptr || k < 1 || k > BM_MAX_ROWS || d < 0) return BM_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  RowTable tab{};
+  for (int i = 0; i < k; ++i) tab.p[i] = rows[i];
+  const int vec = common_vec_width(reinterpret_cast<const void* const*>(rows), k, nullptr);
+  double* body_part = static_cast<double*>(ws);
+  double* tail_part = body_part + (int64_t)BM_MAX_ROWS * kNormBlocks;
+  int nbody = 0, ntail = 0;
+  int64_t body = 0;
+  if (vec >= 2 && d / vec > 0) {
+    const int64_t nvec = d / vec;
+    nbody = stream_grid(nvec, kRedBlock, kNormBlocks);
+    if (vec == 4)
+      hipLaunchKernelGGL(row_sqnorms_kernel<4>, dim3(nbody, k), dim3(kRedBlock), 0, s, tab, nvec, body_part);
+    else
+      hipLaunchKernelGGL(row_sqnorms_kernel<2>, dim3(nbody, k), dim3(kRedBlock), 0, s, tab, nvec, body_part);
+    BM_LAUNCH_CHECK();
+    body = nvec * vec;
+  }
+  if (body < d) {
+    RowTable tail{};
+    for (int i = 0; i < k; ++i) tail.p[i] = rows[i] + body;
+    const int64_t rest = d - body;
+    ntail = (body == 0) ? stream_grid(rest, kRedBlock, kNormBlocks) : 1;
+    hipLaunchKernelGGL(row_sqnorms_kernel<1>, dim3(ntail, k), dim3(kRedBlock), 0, s, tail, rest, tail_part);
+    BM_LAUNCH_CHECK();
+  }
+  // d == 0: no partial at all, the finish kernel writes zeros
+  hipLaunchKernelGGL(row_sqnorms_finish_kernel, dim3(k), dim3(64), 0, s, body_part, nbody, tail_part, ntail, sq_out);
   BM_LAUNCH_CHECK();
   return 0;
 }

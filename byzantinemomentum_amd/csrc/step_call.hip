@@ -30,16 +30,10 @@ struct StepScalars {
   double out6[6];
   double study[BM_STUDY_SLOTS];  // bm_study_stats
   double rowsq[BM_MAX_ROWS];
-  double gram4[(BM_MAX_ROWS / 4) * 16];  // row norms: one 4 x 4 Gram block per group of four rows (ks <= BM_MAX_ROWS)
   double mine[kStatSlots];
   double all[kStatSlots * BM_MAX_ROWS];  // up to 64 ranks
   float clipf[BM_MAX_ROWS];
 };
-
-__global__ void step_diag_kernel(const double* __restrict__ gram, int nc, double* __restrict__ rowsq) {
-  const int i = threadIdx.x;
-  if (i < nc) rowsq[i] = gram[i * nc + i];
-}
 
 __global__ void step_pack_kernel(StepScalars* sc, int has_attack, int has_past, int has_l2) {
   if (threadIdx.x != 0) return;
@@ -141,13 +135,8 @@ extern "C" int bm_step_worker(bm_comm* comm, const bm_step_params* p, const floa
   // ---- clipping factors (device scalars, global under sharding) ----
   const float* clipf = nullptr;
   if (p->clip > 0.0f) {
-    for (int lo = 0; lo < ks; lo += 4) {
-      const int nc = ks - lo < 4 ? ks - lo : 4;
-      rc = bm_multi_dot(sampled + lo, nc, nullptr, 0, d, sc->gram4 + (lo / 4) * 16, base + lay.ws_dot, stream);
-      if (rc != 0) return rc;
-      hipLaunchKernelGGL(step_diag_kernel, dim3(1), dim3(64), 0, s, sc->gram4 + (lo / 4) * 16, nc, sc->rowsq + lo);
-      BM_LAUNCH_CHECK();
-    }
+    rc = bm_row_sqnorms(sampled, ks, d, sc->rowsq, base + lay.ws_dot, stream);
+    if (rc != 0) return rc;
     rc = bm_allreduce_sum_f64(comm, sc->rowsq, ks, stream);
     if (rc != 0) return rc;
     rc = bm_clip_factors(sc->rowsq, ks, p->clip, sc->clipf, stream);

@@ -269,8 +269,7 @@ class ShardedAggregator:
       raise ValueError(f"rank {rank} must pass the gradients of workers {mine}")
     if not self.collective:  # (one rank with forced collectives still goes through the exchange: that is how a
       return list(my_gradients)  #  single-GPU box exercises the RCCL all-to-all)
-    lo0, hi0 = shard_bounds(d, world, 0)
-    per = hi0 - lo0                       # padded shard length (multiple of 64 coordinates)
+    per = -(-(-(-d // world)) // 64) * 64    # padded shard length: ceil(d / P) rounded up to 64 coordinates (256 B)
     n_max = -(-n // world)
     # a rank that owns no worker (n < P) still takes part in the exchange with an all-zero send buffer:
     # dtype / device come from its gradients when it has some, else from the arguments

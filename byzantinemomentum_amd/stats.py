@@ -113,12 +113,14 @@ def study_stats(s_avg, h_avg, defense, byz, f_real, past_newest=None, curv=None,
 
 
 def row_sqnorms(gradients):
-  """Squared L2 norm of every gradient (fp64, on the device): one read of the stack."""
+  """Squared L2 norm of every gradient (fp64, on the device): one read of the stack, one call (bm_row_sqnorms)."""
   n, d, device = gars._validate(gradients)
+  lib = _lib.load()
   res = torch.empty(_lib.MAX_ROWS, dtype=torch.float64, device=device)
-  for lo in range(0, n, 4):
-    gram, _ = study_dots(gradients[lo:lo + 4])
-    res[lo:lo + gram.shape[0]] = gram.diagonal()
+  ws = gars._workspace(device, _lib.WS_DOT, 1, d, "ws_dot")
+  with torch.cuda.device(device):
+    _lib.check(lib.bm_row_sqnorms(_lib.pointer_table(gradients), n, d, _ptr(res), _ptr(ws), gars._stream(device)),
+               "bm_row_sqnorms")
   return res[:n]
 
 

@@ -162,6 +162,11 @@ int bm_study_stats(const float* sampled_avg, const float* honest_avg, const floa
                    const float* past_oldest, int curv_mode, float mu, float oldest_weight, const float* params,
                    const float* origin, int64_t d, double* out, void* ws, void* stream);
 
+/* sq_out[i] = |rows[i]|^2 (DEVICE, k doubles), every row read once: the `gradient.norm().item()` of
+ * aggregators/cge.py:28-38 and of the clipping at attack.py:776-779,791-794 for all gradients in one call, without a
+ * host round trip per gradient.  ws: bm_workspace_bytes(BM_WS_DOT). */
+int bm_row_sqnorms(const float* const* rows, int k, int64_t d, double* sq_out, void* ws, void* stream);
+
 /* order_out = stable argsort (ties to the lower index, NaN last) of n fp64 keys that live on
  * the device: the `d.sort(key=...)` of aggregators/aksel.py:48 without a host round trip. */
 int bm_stable_argsort(const double* keys, int n, int32_t* order_out, void* stream);

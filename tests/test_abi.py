@@ -72,4 +72,12 @@ def test_new_entry_points_validate_arguments_without_gpu(lib):
   assert lib.bm_comm_size(None) == 1
   assert lib.bm_allreduce_sum_f64(None, None, 4, None) == _lib.EINVAL
   assert lib.bm_comm_init(None, 1, 0, None) == _lib.EINVAL
+  # round 3
+  assert lib.bm_study_stats(None, None, None, None, 0, None, None, None, None, 0, 0.9, 0.0, None, None, 10, None, None,
+                            None) == _lib.EINVAL
+  assert lib.bm_study_stats(None, None, None, None, 0, None, None, None, None, 5, 0.9, 0.0, None, None, 0, rows, rows,
+                            None) == _lib.EINVAL  # curv_mode out of range
+  assert lib.bm_row_sqnorms(rows, 0, 10, None, None, None) == _lib.EINVAL
+  assert lib.bm_pairwise_sqdist_shard(rows, 3, 10, 5, None, None, None) == _lib.EINVAL  # d_total < d
+  assert lib.bm_workspace_bytes(_lib.WS_STUDY, 1, 1000) > 0
   assert b"RCCL" in lib.bm_error_string(_lib.ENOCOMM) and b"RCCL" in lib.bm_error_string(_lib.ECOMM)

@@ -317,7 +317,7 @@ def test_study_stats_against_fp64(bm):
             a = byz.clone()
             for _ in range(f_real - 1):
               a = a + byz
-            a = a / f_real
+            a = a / torch.full_like(a, float(f_real))  # true division like the kernel and torch-CPU (a Python scalar becomes x * (1/f) on the GPU)
             core.append(a)
           c64 = [c.double() for c in core]
           for i in range(4):
@@ -355,3 +355,21 @@ def test_study_stats_against_fp64(bm):
   byz[3] = float("nan")
   out = bm.stats.study_stats(s, h, df, byz, 2).tolist()
   assert math.isnan(out[20]) and math.isnan(out[21])
+
+
+def test_row_sqnorms_against_fp64(bm):
+  """bm_row_sqnorms (cge.py:28-38, the clipping norms of attack.py:791-794): every row count tier, odd lengths,
+  unaligned views, empty input; non-finite rows give non-finite norms (CGE ranks them last)."""
+  gen = torch.Generator(device=DEV).manual_seed(21)
+  for k, d, off in ((1, 5, 0), (3, 100003, 0), (25, 40009, 1), (64, 1027, 2), (7, 300000, 0), (4, 0, 0)):
+    rows = [(1.0 + i) * torch.randn(d + off, device=DEV, generator=gen)[off:] for i in range(k)]
+    got = bm.stats.row_sqnorms(rows).tolist()
+    for g, r in zip(got, rows):
+      want = float(r.double().pow(2).sum())
+      assert abs(g - want) <= 1e-6 * want, (k, d, g, want)
+  rows = [torch.randn(1000, device=DEV, generator=gen) for _ in range(5)]
+  rows[2][7] = float("inf")
+  rows[4][0] = float("nan")
+  got = bm.stats.row_sqnorms(rows).tolist()
+  assert math.isinf(got[2]) and math.isnan(got[4]) and all(math.isfinite(got[i]) for i in (0, 1, 3))
+  assert bm.gars.cge_selection(rows, 2)[:3].cpu().tolist() == sorted(range(5), key=lambda i: got[i] if math.isfinite(got[i]) else math.inf)[:3]
