@@ -553,7 +553,9 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
   mu_vec = 0.1 * torch.randn(d, device=device, generator=gen)
   sets = [[mu_vec + s * torch.randn(d, device=device, generator=gen) for s in torch.linspace(0.5, 1.5, h).tolist()]
           for _ in range(2)]
-  for gar in ("krum", "median"):
+  # (inside the PMC child run only the krum step: the median step would launch the C2 column kernel's instance at
+  #  another length and blur its per-launch average)
+  for gar in (("krum",) if "BM_BENCH_CHILD" in os.environ else ("krum", "median")):
     runner = AggregationStep(n, f, f, gar=gar, momentum=0.99, dampening=0.99, attack_factor=1.1, nb_past=25)
 
     def one(i):

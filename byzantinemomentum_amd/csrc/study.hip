@@ -125,11 +125,13 @@ __global__ __launch_bounds__(kStudyBlock) void study_stats_kernel(StudyArgs a, i
   }
   if (a_nan) amax = __builtin_nanf("");  // torch's abs().max() propagates NaN; fmaxf does not
   if (d_nan) dmax = __builtin_nanf("");
-  double* p = partial + (int64_t)blockIdx.x * kStudyPartial;
+  // partial layout: [slot][kStudyMaxBlocks + 1 workgroups] (the finish kernel then reads contiguous doubles)
+  constexpr int64_t kSlotStride = kStudyMaxBlocks + 1;
+  double* p = partial + blockIdx.x;
 #pragma unroll
   for (int i = 0; i < kStudySums; ++i) {
     const double r = block_reduce_sum<kStudyBlock>((double)acc[i], red);
-    if (threadIdx.x == 0) p[i] = r;
+    if (threadIdx.x == 0) p[i * kSlotStride] = r;
   }
   // NaN-propagating maxima
   float m2[2] = {amax, dmax};
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(kStudyBlock) void study_stats_kernel(StudyArgs a, i
         const float o = mred[wv];
         mm = (mm != mm || o != o) ? __builtin_nanf("") : fmaxf(mm, o);
       }
-      p[kStudySums + k] = (double)mm;
+      p[(kStudySums + k) * kSlotStride] = (double)mm;
     }
     __syncthreads();
   }
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(64) void study_finish_kernel(const double* __restri
   bool nan = false;
   const bool is_max = slot >= kStudySums;
   for (int b = lane; b < nparts; b += 64) {
-    const double v = partial[(int64_t)b * kStudyPartial + slot];
+    const double v = partial[(int64_t)slot * (kStudyMaxBlocks + 1) + b];
     if (is_max) {
       nan |= (v != v);
       tot = v > tot ? v : tot;
@@ -292,7 +294,7 @@ extern "C" int bm_study_stats(const float* sampled_avg, const float* honest_avg,
     const int64_t rest = d - body;
     const int grid = (body == 0) ? stream_grid(rest, kStudyBlock, kStudyMaxBlocks) : 1;
     rc = launch_study(t, att, l2, curv_mode, 1, f_real, mu, oldest_weight, rest, grid,
-                      partial + (int64_t)nparts * kStudyPartial, s);
+                      partial + nparts, s);
     if (rc != 0) return rc;
     nparts += grid;
   }
