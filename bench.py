@@ -59,6 +59,9 @@ def parse():
   p.add_argument("--no-cpu-baseline", action="store_true")
   p.add_argument("--no-extras", action="store_true", help="N = 1: skip the per_gar measurements of C3/C4/C5")
   p.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 FETCH_SIZE/WRITE_SIZE passes")
+  p.add_argument("--separate-rows", action="store_true",
+                 help="allocate every synthetic gradient with its own torch.empty instead of byzantinemomentum_amd."
+                      "layout.alloc_rows (rows of one allocation at a skewed stride): the placement A/B of DESIGN 3")
   p.add_argument("--aliased-byz", action="store_true",
                  help="make the f Byzantine rows ONE aliased tensor as the reference's attacks do "
                       "(attacks/identical.py:86); they are then served from cache and the HBM traffic "
@@ -81,13 +84,31 @@ def make_stacks(n, f, d, device, count, seed, aliased):
     mu = 0.1 * torch.randn(d, device=device, generator=gen)
     h = n - f
     sig = torch.linspace(0.5, 1.5, h).tolist()
-    honest = [mu + s * torch.randn(d, device=device, generator=gen) for s in sig]
+    rows = new_rows(n if not aliased else h + 1, d, device)
+    for i, s in enumerate(sig):
+      rows[i].copy_(mu + s * torch.randn(d, device=device, generator=gen))
+    honest = rows[:h]
     byz = torch.stack(honest).mean(dim=0).mul_(-0.1)
     if aliased:
-      stacks.append(honest + [byz] * f)
+      rows[h].copy_(byz)
+      stacks.append(honest + [rows[h]] * f)
     else:
-      stacks.append(honest + [byz + 0.3 * torch.randn(d, device=device, generator=gen) for _ in range(f)])
+      for j in range(f):
+        rows[h + j].copy_(byz + 0.3 * torch.randn(d, device=device, generator=gen))
+      stacks.append(list(rows))
   return stacks
+
+
+SEPARATE_ROWS = False  # --separate-rows: one torch.empty per row instead of byzantinemomentum_amd.layout.alloc_rows
+
+
+def new_rows(count, d, device):
+  """Row buffers of a synthetic stack: placed by the package's allocator (rows of one allocation at a skewed stride,
+  byzantinemomentum_amd/layout.py) unless --separate-rows asks for one allocation per row."""
+  if SEPARATE_ROWS:
+    return [torch.empty(d, dtype=torch.float32, device=device) for _ in range(count)]
+  from byzantinemomentum_amd.layout import alloc_rows
+  return alloc_rows(count, d, device)
 
 
 class KernelTimer:
@@ -237,7 +258,9 @@ def traffic_kernels(d2, d5):
 # ---------------------------------------------------------------------------- #
 
 def main():
+  global SEPARATE_ROWS
   args = parse()
+  SEPARATE_ROWS = args.separate_rows
   if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
     # `python bench.py --gpus N`: become N ranks, one per GPU (torch.distributed.run, RCCL over xGMI)
     import socket
@@ -329,8 +352,12 @@ def main():
                              aggregator=agg)
     gen = torch.Generator(device=device).manual_seed(77 + rank)
     mu_vec = 0.1 * torch.randn(d, device=device, generator=gen)
-    sets = [[mu_vec + s * torch.randn(d, device=device, generator=gen) for s in torch.linspace(0.5, 1.5, h).tolist()]
-            for _ in range(2)]
+    sets = []
+    for _ in range(2):
+      rows = new_rows(h, d, device)
+      for r, s in zip(rows, torch.linspace(0.5, 1.5, h).tolist()):
+        r.copy_(mu_vec + s * torch.randn(d, device=device, generator=gen))
+      sets.append(rows)
     aggs_per_step = 1
     algo_bytes = {"step": step_algorithmic_bytes(d_total, n, f, args.gar)}
 
@@ -396,7 +423,9 @@ def main():
     from byzantinemomentum_amd.sharded import owned_workers
     mine = owned_workers(n, world, rank)
     gen = torch.Generator(device=device).manual_seed(999 + rank)
-    produced = [0.1 * torch.randn(d_total, device=device, generator=gen) for _ in mine]
+    produced = new_rows(max(len(mine), 1), d_total, device)[:len(mine)]
+    for r in produced:
+      r.copy_(0.1 * torch.randn(d_total, device=device, generator=gen))
     ms_a2a = timed_loop(lambda i: agg.to_dim_sharded(produced, n, d_total), 8, 2, timer, "x_a2a")
     ms_wp = timed_loop(lambda i: rule(agg.to_dim_sharded(produced, n, d_total), f), 8, 2, timer, "x_wp")
     for key, val in (("layout_exchange", ms_a2a), (workload + "_from_worker_parallel", ms_wp)):
@@ -462,6 +491,8 @@ def main():
       "dtype": "f32", "data": "synthetic",
       "config": {"workload": workload_name, "n_workers": n, "f": f, "d_total": d_total, "d_per_gpu": d,
                  "byzantine_rows": "aliased" if args.aliased_byz else "distinct buffers",
+                 "row_placement": "one torch.empty per row" if args.separate_rows else
+                                  "byzantinemomentum_amd.layout.alloc_rows (rows of one allocation, stride = 2 MB multiple + 4352 B)",
                  "parallelism": f"dim-shard x{world}" if world > 1 else "single GPU",
                  "collectives": ("none" if not distributed else
                                  "libbm_gar's own RCCL communicator, one C call per aggregation" if agg.native is not None
@@ -551,8 +582,12 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
   h = n - f
   gen = torch.Generator(device=device).manual_seed(77)
   mu_vec = 0.1 * torch.randn(d, device=device, generator=gen)
-  sets = [[mu_vec + s * torch.randn(d, device=device, generator=gen) for s in torch.linspace(0.5, 1.5, h).tolist()]
-          for _ in range(2)]
+  sets = []
+  for _ in range(2):
+    rows = new_rows(h, d, device)
+    for r, s in zip(rows, torch.linspace(0.5, 1.5, h).tolist()):
+      r.copy_(mu_vec + s * torch.randn(d, device=device, generator=gen))
+    sets.append(rows)
   # (inside the PMC child run only the krum step: the median step would launch the C2 column kernel's instance at
   #  another length and blur its per-launch average)
   for gar in (("krum",) if "BM_BENCH_CHILD" in os.environ else ("krum", "median")):

@@ -7,6 +7,7 @@ surface of LPD-EPFL/ByzantineMomentum's `aggregators/` package.  See DESIGN.md.
 from . import _lib  # noqa: F401
 from . import gars  # noqa: F401
 from . import stats  # noqa: F401
+from . import layout  # noqa: F401
 from .gars import (median, trmean, phocas, meamed, krum, bulyan, brute, aksel, average, cge)  # noqa: F401
 from .stats import compute_avg_dev_max  # noqa: F401
 

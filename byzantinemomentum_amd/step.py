@@ -107,6 +107,15 @@ class AggregationStep:
 
   # ------------------------------------------------------------------------ #
 
+  @staticmethod
+  def _new_rows(count, like, zero=False):
+    """`count` vectors shaped like `like`; on a GPU they are rows of one allocation placed by layout.alloc_rows
+    (the n rows a kernel reads together then fall on different HBM channels)."""
+    if like.is_cuda:
+      from .layout import alloc_rows
+      return alloc_rows(count, like.shape[0], like.device, like.dtype, zero=zero)
+    return [torch.zeros_like(like) if zero else torch.empty_like(like) for _ in range(count)]
+
   def _aggregate(self, gradients):
     agg, f = self.agg, self.f_decl
     if self.gar == "median":
@@ -173,7 +182,7 @@ class AggregationStep:
     # 1.+2. momentum, attack vector, sampled/honest statistics
     if self.momentum_at == "worker":
       if self.buffers is None:
-        self.buffers = [torch.zeros_like(g) for g in sampled[:h]]
+        self.buffers = self._new_rows(h, sampled[0], zero=True)
       if self.attack_evals is None:
         s_avg, h_avg, byz, out6 = ops.momentum_stats(sampled, self.buffers, self.mu, omd, factors, self.factor, self.attack)
       else:  # the attack direction alone; the Byzantine vector follows the factor search
@@ -185,11 +194,11 @@ class AggregationStep:
       if factors is not None:
         ops.multi_scale(sampled, factors)  # in place, like the reference's grad.mul_
       if self.momentum_at == "server" and self.server_momentum is not None:
-        honests = [torch.empty_like(g) for g in sampled[:h]]
+        honests = self._new_rows(h, sampled[0])
         ops.multi_fma3(honests, sampled[:h], [self.server_momentum] * h, omd, self.mu)
       elif self.momentum_at == "server":
         # first step: grad_momentum_server is zero (attack.py:678), hon_i = (1-damp)*g_i
-        honests = [torch.empty_like(g) for g in sampled[:h]]
+        honests = self._new_rows(h, sampled[0])
         zero = torch.zeros_like(sampled[0])
         ops.multi_fma3(honests, sampled[:h], [zero] * h, omd, self.mu)
       else:
@@ -244,7 +253,7 @@ class AggregationStep:
   def _run_single_call(self, sampled, ks, omd, params, origin):
     h = self.h
     if self.buffers is None:
-      self.buffers = [torch.zeros_like(g) for g in sampled[:h]]
+      self.buffers = self._new_rows(h, sampled[0], zero=True)
     count = len(self.pasts) if self.nb_past > 0 else 0
     if self.nb_past > 0 and self._curv is None:
       self._curv = torch.empty_like(sampled[0])  # written by the first step (C <- s)

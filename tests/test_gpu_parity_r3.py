@@ -373,3 +373,29 @@ def test_row_sqnorms_against_fp64(bm):
   got = bm.stats.row_sqnorms(rows).tolist()
   assert math.isinf(got[2]) and math.isnan(got[4]) and all(math.isfinite(got[i]) for i in (0, 1, 3))
   assert bm.gars.cge_selection(rows, 2)[:3].cpu().tolist() == sorted(range(5), key=lambda i: got[i] if math.isfinite(got[i]) else math.inf)[:3]
+
+
+def test_rows_from_the_package_allocator(bm):
+  """layout.alloc_rows: rows of one allocation at a skewed stride are ordinary inputs (same bits out of every rule as
+  separately allocated tensors), 256-byte aligned, and what AggregationStep uses for its momentum buffers."""
+  from byzantinemomentum_amd.layout import alloc_rows, ROW_SKEW_BYTES
+  from byzantinemomentum_amd.step import AggregationStep
+  n, f = 11, 2
+  for d in (300007, 1 << 20, 77):
+    rows, h = O.make_stack("hetero", n, f, d, seed=3)
+    sep = [r.to(DEV) for r in rows]
+    slab = alloc_rows(n, d, DEV)
+    for a, b in zip(slab, sep):
+      a.copy_(b)
+    assert all(t.data_ptr() % 256 == 0 and t.is_contiguous() for t in slab)
+    assert (slab[1].data_ptr() - slab[0].data_ptr()) % 256 == 0 and slab[0].untyped_storage().data_ptr() == slab[-1].untyped_storage().data_ptr()
+    if d * 4 >= 1 << 20:
+      assert (slab[1].data_ptr() - slab[0].data_ptr()) % (2 << 20) == ROW_SKEW_BYTES
+    for rule in (bm.median, lambda g: bm.trmean(g, f), lambda g: bm.krum(g, f), lambda g: bm.bulyan(g, f),
+                 lambda g: bm.aksel(g, f), lambda g: bm.cge(g, f)):
+      assert torch.equal(rule(slab), rule(sep))
+    assert torch.equal(bm.gars.pairwise_sqdist(slab), bm.gars.pairwise_sqdist(sep))
+  step = AggregationStep(n, f, f, gar="median", nb_past=0)
+  step.run(sep[:n - f])
+  bufs = step.buffers
+  assert len(bufs) == n - f and bufs[0].untyped_storage().data_ptr() == bufs[-1].untyped_storage().data_ptr()
