@@ -352,12 +352,9 @@ def main():
                              aggregator=agg)
     gen = torch.Generator(device=device).manual_seed(77 + rank)
     mu_vec = 0.1 * torch.randn(d, device=device, generator=gen)
-    sets = []
-    for _ in range(2):
-      rows = new_rows(h, d, device)
-      for r, s in zip(rows, torch.linspace(0.5, 1.5, h).tolist()):
-        r.copy_(mu_vec + s * torch.randn(d, device=device, generator=gen))
-      sets.append(rows)
+    # (one allocation per sampled gradient: for the step that placement measured best)
+    sets = [[mu_vec + s * torch.randn(d, device=device, generator=gen) for s in torch.linspace(0.5, 1.5, h).tolist()]
+            for _ in range(2)]
     aggs_per_step = 1
     algo_bytes = {"step": step_algorithmic_bytes(d_total, n, f, args.gar)}
 
@@ -492,7 +489,7 @@ def main():
       "config": {"workload": workload_name, "n_workers": n, "f": f, "d_total": d_total, "d_per_gpu": d,
                  "byzantine_rows": "aliased" if args.aliased_byz else "distinct buffers",
                  "row_placement": "one torch.empty per row" if args.separate_rows else
-                                  "byzantinemomentum_amd.layout.alloc_rows (rows of one allocation, stride = 2 MB multiple + 4352 B)",
+                                  "byzantinemomentum_amd.layout.alloc_rows (rows of one allocation, stride = 2 MB multiple + 4352 B) for the C2 / C3 / C4 stacks; one allocation per row for the C5 step",
                  "parallelism": f"dim-shard x{world}" if world > 1 else "single GPU",
                  "collectives": ("none" if not distributed else
                                  "libbm_gar's own RCCL communicator, one C call per aggregation" if agg.native is not None
@@ -582,12 +579,9 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
   h = n - f
   gen = torch.Generator(device=device).manual_seed(77)
   mu_vec = 0.1 * torch.randn(d, device=device, generator=gen)
-  sets = []
-  for _ in range(2):
-    rows = new_rows(h, d, device)
-    for r, s in zip(rows, torch.linspace(0.5, 1.5, h).tolist()):
-      r.copy_(mu_vec + s * torch.randn(d, device=device, generator=gen))
-    sets.append(rows)
+  # (one allocation per sampled gradient: for the step that placement measured best)
+  sets = [[mu_vec + s * torch.randn(d, device=device, generator=gen) for s in torch.linspace(0.5, 1.5, h).tolist()]
+          for _ in range(2)]
   # (inside the PMC child run only the krum step: the median step would launch the C2 column kernel's instance at
   #  another length and blur its per-launch average)
   for gar in (("krum",) if "BM_BENCH_CHILD" in os.environ else ("krum", "median")):

@@ -377,9 +377,8 @@ def test_row_sqnorms_against_fp64(bm):
 
 def test_rows_from_the_package_allocator(bm):
   """layout.alloc_rows: rows of one allocation at a skewed stride are ordinary inputs (same bits out of every rule as
-  separately allocated tensors), 256-byte aligned, and what AggregationStep uses for its momentum buffers."""
+  separately allocated tensors) and 256-byte aligned."""
   from byzantinemomentum_amd.layout import alloc_rows, ROW_SKEW_BYTES
-  from byzantinemomentum_amd.step import AggregationStep
   n, f = 11, 2
   for d in (300007, 1 << 20, 77):
     rows, h = O.make_stack("hetero", n, f, d, seed=3)
@@ -395,7 +394,6 @@ def test_rows_from_the_package_allocator(bm):
                  lambda g: bm.aksel(g, f), lambda g: bm.cge(g, f)):
       assert torch.equal(rule(slab), rule(sep))
     assert torch.equal(bm.gars.pairwise_sqdist(slab), bm.gars.pairwise_sqdist(sep))
-  step = AggregationStep(n, f, f, gar="median", nb_past=0)
-  step.run(sep[:n - f])
-  bufs = step.buffers
-  assert len(bufs) == n - f and bufs[0].untyped_storage().data_ptr() == bufs[-1].untyped_storage().data_ptr()
+  # successive allocations continue the skew sequence: the rows of a second stack do not line up with the first one's
+  again = alloc_rows(n, 1 << 20, DEV)
+  assert (again[0].data_ptr() - slab[0].data_ptr()) % (2 << 20) != 0
