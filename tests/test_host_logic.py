@@ -142,3 +142,29 @@ def test_burst_form_index_map_covers_every_column_group_once():
   for nv, grid, threads, slots in ((1, 4, 8, 3), (95, 4, 8, 3), (96, 4, 8, 3), (97, 4, 8, 3), (1000, 4, 8, 3),
                                    (513, 8, 16, 10), (5000, 3, 32, 9), (32 * 7 * 10, 7, 32, 10)):
     replay(nv, grid, threads, slots)
+
+
+def test_alloc_rows_layout_on_cpu():
+  """layout.alloc_rows: rows of one allocation, 256-byte aligned starts, a pitch of (row bytes rounded up) + skew,
+  successive calls continuing the skew sequence; short rows do not get a 2 MB pitch; bad arguments refused."""
+  import torch
+  from byzantinemomentum_amd import layout
+  d = 300000  # 1.2 MB per row: the 2 MB pitch applies
+  rows = layout.alloc_rows(5, d, "cpu", zero=True)
+  assert len(rows) == 5 and all(r.shape == (d,) and r.is_contiguous() and r.dtype == torch.float32 for r in rows)
+  assert float(sum(r.abs().sum() for r in rows)) == 0.0
+  pitch = rows[1].data_ptr() - rows[0].data_ptr()
+  assert pitch == (2 << 20) + layout.ROW_SKEW_BYTES and all(
+    rows[i + 1].data_ptr() - rows[i].data_ptr() == pitch for i in range(4))
+  assert rows[0].untyped_storage().data_ptr() == rows[4].untyped_storage().data_ptr()
+  rows[2].fill_(1.0)  # rows do not overlap
+  assert float(rows[1].sum()) == 0.0 and float(rows[3].sum()) == 0.0 and float(rows[2].sum()) == d
+  more = layout.alloc_rows(3, d, "cpu")
+  assert (more[0].data_ptr() - rows[0].data_ptr()) % 256 == 0
+  short = layout.alloc_rows(4, 100, "cpu")
+  assert short[1].data_ptr() - short[0].data_ptr() == 512 + layout.ROW_SKEW_BYTES  # 400 B rounded up to 256, plus the skew
+  assert layout.alloc_rows(2, 0, "cpu")[1].shape == (0,)
+  with pytest.raises(ValueError):
+    layout.alloc_rows(0, 10, "cpu")
+  with pytest.raises(ValueError):
+    layout.alloc_rows(2, 10, "cpu", skew=100)
