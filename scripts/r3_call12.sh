@@ -1,0 +1,18 @@
+#!/bin/bash
+out=gpurun_out/r3c12
+mkdir -p $out
+export TMPDIR=/tmp
+echo "== driver-style default bench"
+( time python bench.py --gpus 1 --steps 20 --warmup 5 ) > $out/bench_default.json 2> $out/bench_default.err; tail -4 $out/bench_default.err
+python3 - <<PY
+import json
+l=json.loads([x for x in open('$out/bench_default.json').read().strip().splitlines() if x.startswith('{')][-1])
+print('value', l['value'], 'ms', l['ms_per_step'], 'roofline', l['roofline']['frac'], l['roofline']['traffic'])
+for k,v in (l['roofline'].get('traffic_per_kernel') or {}).items(): print('  traffic', k, v['traffic'], round(v['ratio'],4))
+for k,v in l['per_gar'].items():
+    print('  ', k, {a: (round(b,4) if isinstance(b,float) else b) for a,b in v.items() if a in ('avg_ms','frac_of_8TBps','distance_pass_ms','scalar_form_ms')}, (v.get('cpu_baseline') or {}).get('value'))
+print('cpu', l.get('cpu_baseline',{}).get('value'), l.get('cpu_baseline',{}).get('cores'))
+PY
+echo "== counters: C4 (bulyan)"
+bash scripts/pmc_collect.sh $out bulyan -- python bench.py --workload bulyan --steps 6 --no-cpu-baseline --no-traffic > $out/pmc_bulyan.txt 2>&1
+grep -A14 -E "bulyan_pass2_kernel<25, 5, 4|gram3_partial_kernel<7" $out/pmc_bulyan.txt | cut -c1-120 | head -40
