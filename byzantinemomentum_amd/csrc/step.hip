@@ -14,7 +14,7 @@
 // VGPRs (two-pass deviations without re-reading), row base pointers come from the kernarg
 // table; reductions leave the kernel as fp64 per-workgroup partials and are finished in a fixed
 // order by a one-wave kernel: deterministic, no float atomics, no host synchronisation.
-#include "bm_common.h"
+#include "colwise_kernels.h"  // column_rule: the coordinate-wise rules on register-resident values
 
 namespace bm {
 
@@ -60,14 +60,19 @@ __device__ __forceinline__ float block_reduce_absmax(float m, float* lds) {
 // (saddr form, no 64-bit VALU arithmetic).  The 2T row pointers are NOT kept in SGPRs across the loop (80 of them
 // at T = 20: round 2's kernel spilled 322 SGPRs to VGPR lanes): each use fetches its pointer from the kernarg
 // segment with a scalar load behind an opaque copy of the segment address, so nothing is hoisted.
+//   RULE   -1, or BM_OP_MEDIAN / BM_OP_TRMEAN: the coordinate-wise rule over the T updated buffers and NB copies of the
+//          Byzantine vector (attack.py:821 with a coordinate-wise GAR) is applied to the values this pass already
+//          holds in registers and written to defense_out: the rule's own pass over the n rows (n + 1 of the 97 row
+//          passes of a C5 step with the median) disappears.  Same network, same operations, same bits as bm_colwise.
 typedef const float* __attribute__((address_space(4))) const* KargRowPtrs;
 constexpr int kStepBurstBlock = 512;
 
-template <int T, int VEC, bool EXACT, bool CLIP, bool BURST>
+template <int T, int VEC, bool EXACT, bool CLIP, bool BURST, int RULE = -1, int NB = 0>
 __global__ __launch_bounds__(BURST ? kStepBurstBlock : kStepBlock) void momentum_stats_kernel(
     StepTable tab, int ks_rt, int h_rt, uint32_t nvec, float mu, float omd, const float* __restrict__ clipf,
     float* __restrict__ s_avg_out, float* __restrict__ h_avg_out, float* __restrict__ byz_out, float scale,
-    int attack_kind, double* __restrict__ partial) {
+    int attack_kind, double* __restrict__ partial, int rule_f, float rule_inv_keep, float* __restrict__ defense_out) {
+  static_assert(RULE < 0 || (EXACT && NB >= 1), "the fused rule needs the row count at compile time");
   constexpr int BLOCK = BURST ? kStepBurstBlock : kStepBlock;
   __shared__ double red[BLOCK / 64];
   __shared__ float mred[BLOCK / 64];
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(BURST ? kStepBurstBlock : kStepBlock) void momentum
     const bool live = v < nvec;
     const uint32_t off = v * (uint32_t)(VEC * sizeof(float));
     float g[T][VEC], b[T][VEC];
-    float sa[VEC], ha[VEC], bz[VEC];
+    float sa[VEC], ha[VEC], bz[VEC], df[VEC];
     asm volatile("" : "+s"(kbase));  // (outside the divergent region: the segment address stays wave-uniform)
     // row counts: compile-time when EXACT, else per-iteration opaque copies (the 2T predicates are recomputed where
     // they are used instead of living in SGPR pairs across the loop)
@@ -159,6 +164,14 @@ __global__ __launch_bounds__(BURST ? kStepBurstBlock : kStepBlock) void momentum
         const float dir = ((attack_kind & 15) == BM_ATTACK_LITTLE) ? __builtin_sqrtf(qh / (fh - 1.0f)) : -t;
         const float att = dir * scale;  // grad_att.mul_(factor)
         bz[c] = (attack_kind & BM_ATTACK_DIRECTION) ? att : t + att;  // byz_grad = grad_avg.add_(grad_att)
+        if constexpr (RULE >= 0) {  // defense = GAR(honests + [byz] * NB) for this column (attack.py:821)
+          float x[T + NB];
+#pragma unroll
+          for (int i = 0; i < T; ++i) x[i] = b[i][c];
+#pragma unroll
+          for (int i = 0; i < NB; ++i) x[T + i] = bz[c];
+          df[c] = column_rule<T + NB, RULE>(x, rule_f, rule_inv_keep, nullptr);
+        }
       }
     }
     if constexpr (BURST) __syncthreads();  // not for the data: it is what turns the stores of a CU into one burst
@@ -171,6 +184,7 @@ __global__ __launch_bounds__(BURST ? kStepBurstBlock : kStepBlock) void momentum
       if (s_avg_out != nullptr) store_stream_off<VEC>(s_avg_out, off, sa);
       if (h_avg_out != nullptr) store_stream_off<VEC>(h_avg_out, off, ha);
       if (byz_out != nullptr) store_stream_off<VEC>(byz_out, off, bz);
+      if constexpr (RULE >= 0) store_stream_off<VEC>(defense_out, off, df);
     }
   }
   if (nan_s) mxs = __builtin_nanf("");  // torch's abs().max() propagates NaN; fmaxf does not
@@ -400,10 +414,10 @@ static int launch_momentum_stats_form(const StepTable& tab, int ks, int h, int64
   if (tuning().step_burst > 0 && burst_iters >= tuning().step_burst && cus < *grid_io) {
     *grid_io = cus;
     hipLaunchKernelGGL((momentum_stats_kernel<T, VEC, EXACT, CLIP, true>), dim3(cus), dim3(kStepBurstBlock), 0, s, tab,
-                       ks, h, (uint32_t)nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial);
+                       ks, h, (uint32_t)nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial, 0, 0.0f, nullptr);
   } else {
     hipLaunchKernelGGL((momentum_stats_kernel<T, VEC, EXACT, CLIP, false>), dim3(*grid_io), dim3(kStepBlock), 0, s, tab,
-                       ks, h, (uint32_t)nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial);
+                       ks, h, (uint32_t)nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial, 0, 0.0f, nullptr);
   }
   BM_LAUNCH_CHECK();
   return 0;
@@ -527,22 +541,90 @@ __global__ __launch_bounds__(64) void clip_factors_kernel(const double* __restri
   factors[i] = (norm > (double)clip) ? (float)((double)clip / norm) : 1.0f;
 }
 
+// ---------------------------------------------------------------------------
+// First pass + coordinate-wise rule in one kernel (median / trimmed mean over the h = 20 updated buffers and 1..6
+// copies of the Byzantine vector: the C5 shape and its neighbours).  Returns false when no instance fits.
+// ---------------------------------------------------------------------------
+constexpr int kFusedT = 20;
+template <int RULE, int NB, bool CLIP>
+static void launch_fused_rule(const StepTable& tab, int64_t nvec, float mu, float omd, const float* clipf, float* s_avg,
+                              float* h_avg, float* byz, float scale, int kind, double* partial, int rule_f,
+                              float* defense, int* grid_io, hipStream_t s) {
+  constexpr int N = kFusedT + NB;
+  const int keep = (RULE == BM_OP_TRMEAN) ? (N - 2 * rule_f) : N;
+  const float inv_keep = 1.0f / (float)(keep > 0 ? keep : 1);
+  const int cus = compute_units();
+  const int64_t burst_iters = nvec / ((int64_t)cus * kStepBurstBlock);
+  if (tuning().step_burst > 0 && burst_iters >= tuning().step_burst && cus < *grid_io) {
+    *grid_io = cus;
+    hipLaunchKernelGGL((momentum_stats_kernel<kFusedT, 4, true, CLIP, true, RULE, NB>), dim3(cus), dim3(kStepBurstBlock), 0,
+                       s, tab, kFusedT, kFusedT, (uint32_t)nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial,
+                       rule_f, inv_keep, defense);
+  } else {
+    hipLaunchKernelGGL((momentum_stats_kernel<kFusedT, 4, true, CLIP, false, RULE, NB>), dim3(*grid_io), dim3(kStepBlock), 0,
+                       s, tab, kFusedT, kFusedT, (uint32_t)nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial,
+                       rule_f, inv_keep, defense);
+  }
+}
+
+template <int RULE, int NB>
+static void launch_fused_rule_clip(const StepTable& tab, int64_t nvec, float mu, float omd, const float* clipf,
+                                   float* s_avg, float* h_avg, float* byz, float scale, int kind, double* partial,
+                                   int rule_f, float* defense, int* grid_io, hipStream_t s) {
+  if (clipf != nullptr)
+    launch_fused_rule<RULE, NB, true>(tab, nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial, rule_f, defense, grid_io, s);
+  else
+    launch_fused_rule<RULE, NB, false>(tab, nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial, rule_f, defense, grid_io, s);
+}
+
+static bool fused_rule_instance(int ks, int h, int nb, int op) {
+  return ks == kFusedT && h == kFusedT && nb >= 1 && nb <= 6 && (op == BM_OP_MEDIAN || op == BM_OP_TRMEAN) &&
+         tuning().step_stream != 1;
+}
+
+static int launch_fused_rule_any(int op, int nb, const StepTable& tab, int64_t nvec, float mu, float omd,
+                                 const float* clipf, float* s_avg, float* h_avg, float* byz, float scale, int kind,
+                                 double* partial, int rule_f, float* defense, int* grid_io, hipStream_t s) {
+#define BM_FUSED_ARGS tab, nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial, rule_f, defense, grid_io, s
+#define BM_FUSED_NB(NBV)                                                        \
+  case NBV:                                                                     \
+    if (op == BM_OP_MEDIAN)                                                     \
+      launch_fused_rule_clip<BM_OP_MEDIAN, NBV>(BM_FUSED_ARGS);                 \
+    else                                                                        \
+      launch_fused_rule_clip<BM_OP_TRMEAN, NBV>(BM_FUSED_ARGS);                 \
+    break;
+  switch (nb) {
+    BM_FUSED_NB(1) BM_FUSED_NB(2) BM_FUSED_NB(3) BM_FUSED_NB(4) BM_FUSED_NB(5) BM_FUSED_NB(6)
+    default: return BM_EINVAL;
+  }
+#undef BM_FUSED_NB
+#undef BM_FUSED_ARGS
+  BM_LAUNCH_CHECK();
+  return 0;
+}
+
 static inline int vec_of(uintptr_t bits) { return (bits & 15u) == 0 ? 4 : ((bits & 7u) == 0 ? 2 : 1); }
 
 }  // namespace bm
 
-extern "C" int bm_momentum_stats(const float* const* sampled, int ks, float* const* buffers, int h, int64_t d,
-                                 float mu, float one_minus_damp, const float* clip_factors, float* sampled_avg,
-                                 float* honest_avg, float* byz_out, float scale, int attack_kind, double* out6,
-                                 void* ws, void* stream) {
-  using namespace bm;
+namespace bm {
+// rule_op < 0: the first pass alone (bm_momentum_stats); else also defense = rule(buffers + [byz] * nb) (bm_momentum_stats_colwise)
+static int momentum_stats_impl(const float* const* sampled, int ks, float* const* buffers, int h, int64_t d, float mu,
+                               float one_minus_damp, const float* clip_factors, float* sampled_avg, float* honest_avg,
+                               float* byz_out, float scale, int attack_kind, double* out6, void* ws, void* stream,
+                               int rule_op, int rule_f, int nb, float* defense_out) {
   if (sampled == nullptr || buffers == nullptr || out6 == nullptr || ws == nullptr || h < 1 || ks < h ||
       ks > BM_MAX_ROWS || d < 0 || ((attack_kind & ~BM_ATTACK_DIRECTION) != BM_ATTACK_EMPIRE && (attack_kind & ~BM_ATTACK_DIRECTION) != BM_ATTACK_LITTLE))
+    return BM_EINVAL;
+  if (rule_op >= 0 && ((rule_op != BM_OP_MEDIAN && rule_op != BM_OP_TRMEAN && rule_op != BM_OP_PHOCAS && rule_op != BM_OP_MEAMED) ||
+                       nb < 1 || h + nb > BM_MAX_ROWS || (attack_kind & BM_ATTACK_DIRECTION) != 0 ||
+                       (d > 0 && (byz_out == nullptr || defense_out == nullptr)) ||
+                       (rule_op != BM_OP_MEDIAN && (rule_f < 0 || h + nb < 2 * rule_f + 1))))
     return BM_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   StepTable tab{};
   uintptr_t bits = reinterpret_cast<uintptr_t>(sampled_avg) | reinterpret_cast<uintptr_t>(honest_avg) |
-                   reinterpret_cast<uintptr_t>(byz_out);
+                   reinterpret_cast<uintptr_t>(byz_out) | reinterpret_cast<uintptr_t>(rule_op >= 0 ? defense_out : nullptr);
   for (int i = 0; i < ks; ++i) {
     tab.g[i] = sampled[i];
     bits |= reinterpret_cast<uintptr_t>(sampled[i]);
@@ -574,7 +656,17 @@ extern "C" int bm_momentum_stats(const float* const* sampled, int ks, float* con
     float* ha = honest_avg ? honest_avg + lo : nullptr;
     float* bz = byz_out ? byz_out + lo : nullptr;
     int64_t body = 0;
-    if (vec >= 2 && dp / vec > 0) {
+    // the rule inside the first pass where an instance exists (16-byte columns, ks = h = 20, 1..6 Byzantine copies)
+    const bool fused = rule_op >= 0 && vec == 4 && dp / 4 > 0 && fused_rule_instance(ks, h, nb, rule_op);
+    if (fused) {
+      const int64_t nvec = dp / 4;
+      int grid = stream_grid(nvec, kStepBlock, cap);
+      rc = launch_fused_rule_any(rule_op, nb, piece, nvec, mu, one_minus_damp, clip_factors, sa, ha, bz, scale,
+                                 attack_kind, partial + (int64_t)nparts * 6, rule_f, defense_out + lo, &grid, s);
+      if (rc != 0) return rc;
+      nparts += grid;
+      body = nvec * 4;
+    } else if (vec >= 2 && dp / vec > 0) {
       const int64_t nvec = dp / vec;
       int grid = stream_grid(nvec, kStepBlock, cap);
       rc = (vec == 4) ? dispatch_momentum_stats<4>(piece, ks, h, nvec, mu, one_minus_damp, clip_factors, sa, ha, bz,
@@ -599,11 +691,40 @@ extern "C" int bm_momentum_stats(const float* const* sampled, int ks, float* con
       if (rc != 0) return rc;
       nparts += grid;
     }
+    if (rule_op >= 0) {  // the columns of this piece the fused kernel did not cover: the rule as its own launch
+      const int64_t from = fused ? body : 0;
+      if (from < dp) {
+        const float* rows[BM_MAX_ROWS];
+        for (int i = 0; i < h; ++i) rows[i] = buffers[i] + lo + from;
+        for (int i = 0; i < nb; ++i) rows[h + i] = byz_out + lo + from;
+        rc = bm_colwise(rule_op, rows, h + nb, dp - from, rule_f, defense_out + lo + from, stream);
+        if (rc != 0) return rc;
+      }
+    }
   }
   // d == 0: nparts == 0 and the finish kernel writes zeros — every rank of a sharded job reaches its collective
   hipLaunchKernelGGL(step_finish_kernel, dim3(1), dim3(kFinishThreads), 0, s, partial, nparts, out6);
   BM_LAUNCH_CHECK();
   return 0;
+}
+}  // namespace bm
+
+extern "C" int bm_momentum_stats(const float* const* sampled, int ks, float* const* buffers, int h, int64_t d,
+                                 float mu, float one_minus_damp, const float* clip_factors, float* sampled_avg,
+                                 float* honest_avg, float* byz_out, float scale, int attack_kind, double* out6,
+                                 void* ws, void* stream) {
+  return bm::momentum_stats_impl(sampled, ks, buffers, h, d, mu, one_minus_damp, clip_factors, sampled_avg, honest_avg,
+                                 byz_out, scale, attack_kind, out6, ws, stream, -1, 0, 0, nullptr);
+}
+
+extern "C" int bm_momentum_stats_colwise(const float* const* sampled, int ks, float* const* buffers, int h, int64_t d,
+                                         float mu, float one_minus_damp, const float* clip_factors, float* sampled_avg,
+                                         float* honest_avg, float* byz_out, float scale, int attack_kind, int rule_op,
+                                         int rule_f, int n_byz, float* defense_out, double* out6, void* ws,
+                                         void* stream) {
+  if (rule_op < 0) return BM_EINVAL;
+  return bm::momentum_stats_impl(sampled, ks, buffers, h, d, mu, one_minus_damp, clip_factors, sampled_avg, honest_avg,
+                                 byz_out, scale, attack_kind, out6, ws, stream, rule_op, rule_f, n_byz, defense_out);
 }
 
 extern "C" int bm_multi_fma3(float* const* out, const float* const* p, const float* const* q, int k, int64_t d,

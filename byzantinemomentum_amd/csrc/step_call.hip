@@ -144,30 +144,43 @@ extern "C" int bm_step_worker(bm_comm* comm, const bm_step_params* p, const floa
     clipf = sc->clipf;
   }
 
-  // ---- pass 1: momentum, statistics of the sampled and honest stacks, Byzantine vector ----
-  rc = bm_momentum_stats(sampled, ks, buffers, h, d, p->mu, p->one_minus_damp, clipf, sampled_avg_out, honest_avg_out,
-                         fr > 0 ? byz_out : nullptr, p->attack_scale, p->attack_kind, sc->out6, base + lay.ws_step,
-                         stream);
+  // ---- pass 1: momentum, statistics of the sampled and honest stacks, Byzantine vector; a coordinate-wise rule over
+  //      the buffers and the Byzantine copies rides along (inside the same kernel for median / trmean at h = 20) ----
+  const bool distance_rule_ = p->rule == BM_RULE_KRUM || p->rule == BM_RULE_BULYAN;
+  const bool rides_along = !distance_rule_ && fr >= 1;
+  if (rides_along) {
+    const int op = p->rule == BM_RULE_MEDIAN ? BM_OP_MEDIAN
+                   : p->rule == BM_RULE_TRMEAN ? BM_OP_TRMEAN : p->rule == BM_RULE_PHOCAS ? BM_OP_PHOCAS : BM_OP_MEAMED;
+    rc = bm_momentum_stats_colwise(sampled, ks, buffers, h, d, p->mu, p->one_minus_damp, clipf, sampled_avg_out,
+                                   honest_avg_out, byz_out, p->attack_scale, p->attack_kind, op, p->f_decl, fr,
+                                   defense_out, sc->out6, base + lay.ws_step, stream);
+  } else {
+    rc = bm_momentum_stats(sampled, ks, buffers, h, d, p->mu, p->one_minus_damp, clipf, sampled_avg_out, honest_avg_out,
+                           fr > 0 ? byz_out : nullptr, p->attack_scale, p->attack_kind, sc->out6, base + lay.ws_step,
+                           stream);
+  }
   if (rc != 0) return rc;
 
   // ---- the rule over honests + [byz] * f_real ----
-  const float* rows[BM_MAX_ROWS];
-  for (int i = 0; i < h; ++i) rows[i] = buffers[i];
-  for (int i = h; i < n; ++i) rows[i] = byz_out;
-  const int m = p->m > 0 ? p->m : n - p->f_decl - 2;
-  switch (p->rule) {
-    case BM_RULE_KRUM:
-      rc = bm_sharded_krum(comm, rows, n, d, p->f_decl, m, defense_out, nullptr, base + lay.ws_rule, stream);
-      break;
-    case BM_RULE_BULYAN:
-      rc = bm_sharded_bulyan(comm, rows, n, d, p->f_decl, m, defense_out, nullptr, base + lay.ws_rule, stream);
-      break;
-    case BM_RULE_MEDIAN: rc = bm_colwise(BM_OP_MEDIAN, rows, n, d, 0, defense_out, stream); break;
-    case BM_RULE_TRMEAN: rc = bm_colwise(BM_OP_TRMEAN, rows, n, d, p->f_decl, defense_out, stream); break;
-    case BM_RULE_PHOCAS: rc = bm_colwise(BM_OP_PHOCAS, rows, n, d, p->f_decl, defense_out, stream); break;
-    default: rc = bm_colwise(BM_OP_MEAMED, rows, n, d, p->f_decl, defense_out, stream); break;
+  if (!rides_along) {
+    const float* rows[BM_MAX_ROWS];
+    for (int i = 0; i < h; ++i) rows[i] = buffers[i];
+    for (int i = h; i < n; ++i) rows[i] = byz_out;
+    const int m = p->m > 0 ? p->m : n - p->f_decl - 2;
+    switch (p->rule) {
+      case BM_RULE_KRUM:
+        rc = bm_sharded_krum(comm, rows, n, d, p->f_decl, m, defense_out, nullptr, base + lay.ws_rule, stream);
+        break;
+      case BM_RULE_BULYAN:
+        rc = bm_sharded_bulyan(comm, rows, n, d, p->f_decl, m, defense_out, nullptr, base + lay.ws_rule, stream);
+        break;
+      case BM_RULE_MEDIAN: rc = bm_colwise(BM_OP_MEDIAN, rows, n, d, 0, defense_out, stream); break;
+      case BM_RULE_TRMEAN: rc = bm_colwise(BM_OP_TRMEAN, rows, n, d, p->f_decl, defense_out, stream); break;
+      case BM_RULE_PHOCAS: rc = bm_colwise(BM_OP_PHOCAS, rows, n, d, p->f_decl, defense_out, stream); break;
+      default: rc = bm_colwise(BM_OP_MEAMED, rows, n, d, p->f_decl, defense_out, stream); break;
+    }
+    if (rc != 0) return rc;
   }
-  if (rc != 0) return rc;
 
   // ---- the study block in one pass (attack / defense statistics, dots, l2, curvature combination) ----
   int curv_mode = 0;

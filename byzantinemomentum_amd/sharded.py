@@ -142,6 +142,9 @@ class HipBackend:
   def momentum_stats(self, sampled, buffers, mu, omd, factors, scale, attack, direction=False):
     return self.stats.momentum_stats(sampled, buffers, mu, omd, factors, scale, attack, direction)
 
+  def momentum_stats_colwise(self, *args, **kwargs):
+    return self.stats.momentum_stats_colwise(*args, **kwargs)
+
   def multi_fma3(self, outs, ps, qs, a, b, p_scale=None):
     return self.stats.multi_fma3(outs, ps, qs, a, b, p_scale)
 

@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from . import gars
 
-__all__ = ["compute_avg_dev_max", "stack_stats_async", "study_dots", "study_stats", "multi_axpby", "row_sqnorms", "momentum_stats",
+__all__ = ["compute_avg_dev_max", "stack_stats_async", "study_dots", "study_stats", "multi_axpby", "row_sqnorms", "momentum_stats", "momentum_stats_colwise",
            "multi_fma3", "clip_factors", "clip_factors_from_sq", "multi_scale", "clip_gradients", "l2_distance",
            "step_worker"]
 
@@ -168,6 +168,32 @@ def momentum_stats(sampled, buffers, mu, one_minus_damp, clip_factors_dev=None, 
       _attack_id(attack, direction), _ptr(out6), _ptr(ws),
       gars._stream(device)), "bm_momentum_stats")
   return s_avg, h_avg, byz, out6
+
+
+_COLWISE_OPS = {"median": _lib.OP_MEDIAN, "trmean": _lib.OP_TRMEAN, "phocas": _lib.OP_PHOCAS, "meamed": _lib.OP_MEAMED}
+
+
+def momentum_stats_colwise(sampled, buffers, mu, one_minus_damp, clip_factors_dev, attack_scale, attack, rule, f, n_byz):
+  """momentum_stats followed by a coordinate-wise rule over the updated buffers and `n_byz` copies of the Byzantine
+  vector — for the median / trimmed mean over 20 buffers and 1..6 copies INSIDE the same kernel
+  (bm_momentum_stats_colwise).  Returns (sampled_avg, honest_avg, byz, defense, out6). No sync."""
+  ks, d, device = gars._validate(list(sampled))
+  h = gars._validate(list(buffers) + [sampled[0]])[0] - 1
+  if h < 1 or ks < h or n_byz < 1:
+    raise gars.GarInputError("momentum_stats_colwise needs 1 <= len(buffers) <= len(sampled) and n_byz >= 1")
+  lib = _lib.load()
+  s_avg, h_avg, byz, defense = (torch.empty(d, dtype=torch.float32, device=device) for _ in range(4))
+  out6 = torch.empty(6, dtype=torch.float64, device=device)
+  ws = gars._workspace(device, _lib.WS_STEP, 1, d, "ws_step")
+  gars.invalidate_rank_cache()
+  with torch.cuda.device(device):
+    _lib.check(lib.bm_momentum_stats_colwise(
+      _lib.pointer_table(sampled), ks, _lib.pointer_table(buffers), h, d, ctypes.c_float(mu),
+      ctypes.c_float(one_minus_damp), _ptr(clip_factors_dev) if clip_factors_dev is not None else None,
+      _ptr(s_avg), _ptr(h_avg), _ptr(byz), ctypes.c_float(attack_scale), _attack_id(attack, False),
+      _COLWISE_OPS[rule], int(f), int(n_byz), _ptr(defense), _ptr(out6), _ptr(ws), gars._stream(device)),
+      "bm_momentum_stats_colwise")
+  return s_avg, h_avg, byz, defense, out6
 
 
 def multi_fma3(outs, ps, qs, a, b, p_scale_dev=None):

@@ -178,10 +178,16 @@ class AggregationStep:
       agg.all_reduce_sum(sq)
       factors = ops.clip_factors_from_sq(sq, ks, self.clip)
     # 1.+2. momentum, attack vector, sampled/honest statistics
+    fused_defense = None
     if self.momentum_at == "worker":
       if self.buffers is None:
         self.buffers = self._new_rows(h, sampled[0], zero=True)
-      if self.attack_evals is None:
+      fused_rule = (self.attack_evals is None and self.f_real >= 1 and not self.gar_args
+                    and self.gar in ("median", "trmean", "phocas", "meamed") and hasattr(ops, "momentum_stats_colwise"))
+      if fused_rule:  # first pass + coordinate-wise rule in one call (one kernel for median / trmean at h = 20)
+        s_avg, h_avg, byz, fused_defense, out6 = ops.momentum_stats_colwise(
+          sampled, self.buffers, self.mu, omd, factors, self.factor, self.attack, self.gar, self.f_decl, self.f_real)
+      elif self.attack_evals is None:
         s_avg, h_avg, byz, out6 = ops.momentum_stats(sampled, self.buffers, self.mu, omd, factors, self.factor, self.attack)
       else:  # the attack direction alone; the Byzantine vector follows the factor search
         s_avg, h_avg, byz, out6 = ops.momentum_stats(sampled, self.buffers, self.mu, omd, factors, 1.0, self.attack,
@@ -213,7 +219,7 @@ class AggregationStep:
       ops.multi_fma3([byz], [h_avg], [direction], 1.0, self.last_factor)
     attacks = [byz] * self.f_real
     # 3. aggregation
-    defense = self._aggregate(honests + attacks)
+    defense = fused_defense if fused_defense is not None else self._aggregate(honests + attacks)
     # 4. momentum of the update
     if self.momentum_at == "server":
       self.server_momentum = defense          # no clone, as attack.py:835

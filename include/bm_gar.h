@@ -191,6 +191,19 @@ int bm_momentum_stats(const float* const* sampled, int ks, float* const* buffers
                       float* honest_avg, float* byz_out, float scale, int attack_kind, double* out6,
                       void* ws, void* stream);
 
+/* The same first pass followed by a coordinate-wise rule over the h updated buffers and n_byz copies of byz_out, i.e.
+ * defense_out = GAR(honests + [byz] * n_byz, f = rule_f) of attack.py:821 for rule_op = BM_OP_MEDIAN / TRMEAN / PHOCAS /
+ * MEAMED (aggregators/median.py:39, trmean.py:33,81-109), with the results of bm_momentum_stats + bm_colwise (same
+ * bits).  For the median and the trimmed mean over ks = h = 20 buffers and 1..6 Byzantine copies (n = 21..26: the
+ * reference's n = 25, f = 5 among them) the rule runs INSIDE the first pass, on the values it already holds in
+ * registers: the rule's own pass over the n rows disappears (26 of the 97 row passes of such a step).  Any other
+ * shape runs the two kernels one after the other.  byz_out and defense_out must be non-NULL, attack_kind without
+ * BM_ATTACK_DIRECTION. */
+int bm_momentum_stats_colwise(const float* const* sampled, int ks, float* const* buffers, int h, int64_t d,
+                              float mu, float one_minus_damp, const float* clip_factors, float* sampled_avg,
+                              float* honest_avg, float* byz_out, float scale, int attack_kind, int rule_op,
+                              int rule_f, int n_byz, float* defense_out, double* out6, void* ws, void* stream);
+
 /* out[i] = b * q[i] + a * (p_scale[i] * p[i]) for k vectors (p_scale: DEVICE array of k floats or NULL;
  * entries of q may be one shared vector; out[i] may alias p[i]).  Every momentum placement of the loop:
  * worker (attack.py:800-804), server (:805-808), update (:838-839), Nesterov look-ahead (:762,767). */

@@ -78,6 +78,13 @@ def test_new_entry_points_validate_arguments_without_gpu(lib):
   assert lib.bm_study_stats(None, None, None, None, 0, None, None, None, None, 5, 0.9, 0.0, None, None, 0, rows, rows,
                             None) == _lib.EINVAL  # curv_mode out of range
   assert lib.bm_row_sqnorms(rows, 0, 10, None, None, None) == _lib.EINVAL
+  out6 = (ctypes.c_double * 6)()
+  assert lib.bm_momentum_stats_colwise(rows, 4, rows, 4, 10, 0.9, 0.1, None, None, None, rows, 1.0, 0, 0, 0, 0, rows,
+                                       out6, rows, None) == _lib.EINVAL   # no Byzantine copy
+  assert lib.bm_momentum_stats_colwise(rows, 4, rows, 4, 10, 0.9, 0.1, None, None, None, rows, 1.0, 16, 0, 0, 1, rows,
+                                       out6, rows, None) == _lib.EINVAL   # direction-only attack vector
+  assert lib.bm_momentum_stats_colwise(rows, 4, rows, 4, 10, 0.9, 0.1, None, None, None, rows, 1.0, 0, 1, 3, 1, rows,
+                                       out6, rows, None) == _lib.EINVAL   # trmean with n = 5 < 2 f + 1
   assert lib.bm_pairwise_sqdist_shard(rows, 3, 10, 5, None, None, None) == _lib.EINVAL  # d_total < d
   assert lib.bm_workspace_bytes(_lib.WS_STUDY, 1, 1000) > 0
   assert b"RCCL" in lib.bm_error_string(_lib.ENOCOMM) and b"RCCL" in lib.bm_error_string(_lib.ECOMM)

@@ -106,13 +106,23 @@ def test_full_size_c5_steady_state_curvature(bm):
   sigmas = torch.linspace(0.5, 1.5, h).tolist()
   for it in range(P + 4):
     sampled = [drift + s * torch.randn(d, device=DEV, generator=gen) for s in sigmas]
-    step.run(sampled)
+    defense = step.run(sampled)
     got = step.floats()
     for b, g in zip(ref_bufs, sampled):
       b.mul_(mu).add_(g, alpha=1.0 - damp)
     if it in (0, P + 3):
       for a, b in zip(step.buffers, ref_bufs):
         assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max())
+    if it == 0:  # the rule rode along with the first pass (fused kernel, burst form): it must be the median of
+      # the step's own buffers and five copies of its Byzantine vector, bit for bit
+      h_avg = step.buffers[0].clone()
+      for bb in step.buffers[1:]:
+        h_avg.add_(bb)
+      h_avg.div_(torch.full_like(h_avg, float(h)))
+      byz = h_avg + 1.1 * (-h_avg)
+      want = torch.stack(list(step.buffers) + [byz] * f).median(dim=0).values
+      assert torch.equal(defense, want)
+      del want, h_avg, byz
     s_avg = sampled[0].clone()
     for r in sampled[1:]:
       s_avg.add_(r)
@@ -287,9 +297,10 @@ def test_momentum_stats_burst_form_at_short_lengths():
   import sys
   from tests.test_gpu_parity_r2 import ROOT
   env = dict(os.environ, BM_STEP_BURST="1", PYTHONPATH=ROOT)
-  out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity_r2.py"), "-q", "-x",
+  out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity_r2.py"),
+                        os.path.join(ROOT, "tests", "test_gpu_parity_r3.py"), "-q", "-x",
                         "-m", "gpu", "-k", "test_momentum_stats_kernel_tiers or test_step_all_placements or "
-                        "test_single_call_step_equals_python_sequence"],
+                        "test_single_call_step_equals_python_sequence or test_first_pass_with_the_rule_riding_along"],
                        capture_output=True, text=True, env=env, cwd=ROOT, timeout=1200)
   assert out.returncode == 0, (out.stdout[-3000:], out.stderr[-2000:])
 
@@ -397,3 +408,43 @@ def test_rows_from_the_package_allocator(bm):
   # successive allocations continue the skew sequence: the rows of a second stack do not line up with the first one's
   again = alloc_rows(n, 1 << 20, DEV)
   assert (again[0].data_ptr() - slab[0].data_ptr()) % (2 << 20) != 0
+
+
+def test_first_pass_with_the_rule_riding_along(bm):
+  """bm_momentum_stats_colwise against bm_momentum_stats + bm_colwise on clones: same bits in the buffers, the two
+  averages, the Byzantine vector, the six statistics and the aggregated vector — for the shapes with a fused
+  instance (ks = h = 20, 1..6 Byzantine copies, median / trmean, with and without clipping factors, NaN / inf
+  columns, ragged tails) and for shapes that fall back to the two kernels (other row counts, phocas / meamed,
+  unaligned views)."""
+  gen = torch.Generator(device=DEV).manual_seed(17)
+  cases = [(20, 20, 5, "median", 0, 30011, 0, False), (20, 20, 5, "trmean", 5, 30011, 0, True),
+           (20, 20, 1, "trmean", 3, 4099, 0, False), (20, 20, 6, "median", 0, 1 << 20, 0, True),
+           (20, 20, 3, "trmean", 0, 65, 0, False), (20, 20, 5, "median", 0, 40002, 1, False),   # unaligned: fallback
+           (21, 20, 5, "median", 0, 10007, 0, False), (12, 12, 3, "trmean", 2, 10007, 0, False),
+           (20, 20, 7, "median", 0, 5003, 0, False), (20, 20, 5, "phocas", 5, 20011, 0, False),
+           (20, 20, 5, "meamed", 5, 20011, 0, True)]
+  for ks, h, nb, rule, f, d, off, clip in cases:
+    sampled = [torch.randn(d + off, device=DEV, generator=gen)[off:] for _ in range(ks)]
+    bufs = [torch.randn(d + off, device=DEV, generator=gen)[off:] for _ in range(h)]
+    if d > 100:
+      sampled[3][17] = float("nan")
+      sampled[5][40] = float("inf")
+      bufs[2][63] = float("-inf")
+    factors = None
+    if clip:
+      factors = torch.ones(64, device=DEV)
+      factors[1], factors[ks - 1] = 0.5, 0.25
+    for attack, scale in (("empire", 1.1), ("little", -1.5)):
+      b1 = [b.clone() for b in bufs]
+      b2 = [b.clone() for b in bufs]
+      s1, h1, z1, d1, o1 = bm.stats.momentum_stats_colwise(sampled, b1, 0.9, 0.1, factors, scale, attack, rule, f, nb)
+      s2, h2, z2, o2 = bm.stats.momentum_stats(sampled, b2, 0.9, 0.1, factors, scale, attack)
+      rows = b2 + [z2] * nb
+      d2 = bm.median(rows) if rule == "median" else getattr(bm, rule)(rows, f)
+      tag = (ks, h, nb, rule, f, d, off, clip, attack)
+      for x, y in zip(b1, b2):
+        assert same_bits(x, y), tag
+      assert same_bits(s1, s2) and same_bits(h1, h2) and same_bits(z1, z2), tag
+      assert same_bits(d1, d2), tag
+      a, b = o1.tolist(), o2.tolist()
+      assert all(x == y or (math.isnan(x) and math.isnan(y)) for x, y in zip(a, b)), (tag, a, b)
