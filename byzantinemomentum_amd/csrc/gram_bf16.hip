@@ -43,88 +43,15 @@
 //     krum.py:62 stable sort);
 //   * fp32 chains cover 32 coordinates, per-wave fp32 sums ~100 chunks, everything wider is fp64
 //     (workgroup, grid, GPUs) in a fixed order: deterministic, no atomics.
-#include "bm_common.h"
+#include "gram_split.h"
 
 namespace bm {
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-// row pointers travel through LDS as generic pointers; say "global" again so that the loads are
-// global_load (vmcnt only) and not flat_load (vmcnt + lgkmcnt, which would tie them to the LDS waits)
-typedef const float __attribute__((address_space(1)))* GlobalF;
-typedef f32x4 __attribute__((address_space(1))) GlobalF4;
 
 constexpr int kB3Waves = 4;      // waves per workgroup (they only meet in the final reduction)
 constexpr int kB3Chunk = 64;     // coordinates per wave and chunk: 256 B per row
 constexpr int kB3RowBytes = 128; // one row of one bf16 plane in LDS
 
 __host__ __device__ constexpr int b3_pairs(int rb) { return rb * (rb + 1) / 2; }
-__host__ __device__ inline int b3_tri_index(int i, int j, int n) { return i * n - (i * (i - 1)) / 2 + (j - i); }
-
-// two fp32 -> packed bf16 pair (round to nearest even): v_cvt_pk_bf16_f32
-__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
-  const f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ float bf16_lo(unsigned p) { return __builtin_bit_cast(float, p << 16); }
-__device__ __forceinline__ float bf16_hi(unsigned p) { return __builtin_bit_cast(float, p & 0xffff0000u); }
-
-// x = h + m + l exactly (h, m, l bf16): the subtractions are exact, the last residual has at most
-// 8 significant bits.
-__device__ __forceinline__ void split3(const f32x4 x, u32x2& h, u32x2& m, u32x2& l) {
-  h.x = pack_bf16(x.x, x.y);
-  h.y = pack_bf16(x.z, x.w);
-  const float r0 = x.x - bf16_lo(h.x), r1 = x.y - bf16_hi(h.x);
-  const float r2 = x.z - bf16_lo(h.y), r3 = x.w - bf16_hi(h.y);
-  m.x = pack_bf16(r0, r1);
-  m.y = pack_bf16(r2, r3);
-  const float s0 = r0 - bf16_lo(m.x), s1 = r1 - bf16_hi(m.x);
-  const float s2 = r2 - bf16_lo(m.y), s3 = r3 - bf16_hi(m.y);
-  l.x = pack_bf16(s0, s1);
-  l.y = pack_bf16(s2, s3);
-}
-
-// Two-plane form: x ~ h + m with h = rne_bf16(x) and m the remainder r = x - h rounded to bf16 STOCHASTICALLY:
-// the 16 discarded bits of r are compared with 16 pseudo-random bits that depend on the COORDINATE only
-// (integer add on the bit pattern, then truncation: the magnitude is rounded up with probability
-// discarded/2^16, so E[m] = r exactly).  What is dropped, l = r - m, then has zero mean and is independent from
-// one coordinate to the next BY CONSTRUCTION, whatever the data — with round-to-nearest the dropped part
-// is a deterministic function of the value, and rows with few distinct values (constant, sign, quantised or
-// sparsified gradients) turn the first-order error 2 sum_k (x_i - x_j)_k (l_i - l_j)_k of a squared distance
-// into a systematic term of relative size up to 2^-16 |x| / |x_i - x_j| (3e-5 ... 5e-4 for a pair just above
-// the accuracy gate) instead of a random walk sqrt(d) times smaller.  All rows share the dither of a
-// coordinate, so bitwise-equal rows still give bitwise-equal planes (exact ties survive), and rows that are
-// close get the same rounding direction most of the time (their l's largely cancel in l_i - l_j).
-__device__ __forceinline__ unsigned dither_pair(unsigned coord) {
-  // two 16-bit words for coordinates coord, coord + 1 from one 32-bit mix of the (even) coordinate index
-  unsigned z = coord * 0x9E3779B1u + 0x7F4A7C15u;
-  z ^= z >> 15;
-  z *= 0x85EBCA77u;
-  z ^= z >> 13;
-  z *= 0xC2B2AE3Du;
-  z ^= z >> 16;
-  return z;
-}
-__device__ __forceinline__ void split2_dithered(const f32x4 x, const unsigned d01, const unsigned d23, u32x2& h, u32x2& m) {
-  h.x = pack_bf16(x.x, x.y);
-  h.y = pack_bf16(x.z, x.w);
-  const unsigned b0 = __builtin_bit_cast(unsigned, x.x - bf16_lo(h.x)) + (d01 & 0xffffu);
-  const unsigned b1 = __builtin_bit_cast(unsigned, x.y - bf16_hi(h.x)) + (d01 >> 16);
-  const unsigned b2 = __builtin_bit_cast(unsigned, x.z - bf16_lo(h.y)) + (d23 & 0xffffu);
-  const unsigned b3 = __builtin_bit_cast(unsigned, x.w - bf16_hi(h.y)) + (d23 >> 16);
-  // upper halves of (b1, b0) -> one packed bf16 pair: bytes {b0.2, b0.3, b1.2, b1.3}
-  m.x = __builtin_amdgcn_perm(b1, b0, 0x07060302u);
-  m.y = __builtin_amdgcn_perm(b3, b2, 0x07060302u);
-}
-
-__device__ __forceinline__ f32x4 mfma_bf16(u32x4 a, u32x4 b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
-                                                 0, 0, 0);
-}
 
 // workgroups per CU by shape (3 leave 168 VGPRs, 2 leave 256); the host sizes its grid with the same function
 __host__ __device__ constexpr int b3_workgroups_per_cu(int K, int NPL) {
@@ -423,19 +350,23 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
 // Bitwise-equal rows (G_ii == G_jj == G_ij) are exact (d2 = 0) and never listed.
 constexpr int kSqThreads = 1024;
 constexpr int kArrivalSlot = 96;  // int slot of the 512-byte row-list area that counts the workgroups of the reduction
+// n rows in G (compact), n_full >= n rows in sq: rows n-1 .. n_full-1 of the full stack are ONE row of G (the aliased
+// Byzantine copies of a step: the Gram kernel contracted the row once); they are at distance exactly 0 of each other
+// and share every other distance, and if the gate lists one of them it lists them all.
 __device__ __forceinline__ void gram_to_sqdist(const double* __restrict__ gram, int n, double tau,
-                                               double* __restrict__ sq, int* __restrict__ sub, int* listed) {
+                                               double* __restrict__ sq, int* __restrict__ sub, int* listed, int n_full) {
   if (threadIdx.x < BM_MAX_ROWS) listed[threadIdx.x] = 0;
   __syncthreads();
-  for (int e = threadIdx.x; e < n * n; e += kSqThreads) {
-    const int i = e / n, j = e - i * n;
-    if (i == j) {
-      // a row with a non-finite coordinate is at non-finite distance of everything, itself
-      // included in the reference (x - x = nan); keep 0 on the diagonal, it is never read
+  for (int e = threadIdx.x; e < n_full * n_full; e += kSqThreads) {
+    const int i = e / n_full, j = e - i * n_full;
+    const int ci = i < n ? i : n - 1, cj = j < n ? j : n - 1;
+    if (ci == cj) {
+      // the diagonal (a row with a non-finite coordinate is at non-finite distance of everything, itself
+      // included in the reference, x - x = nan; keep 0, it is never read) and pairs of aliased copies
       sq[e] = 0.0;
       continue;
     }
-    const int lo = i < j ? i : j, hi = i < j ? j : i;
+    const int lo = ci < cj ? ci : cj, hi = ci < cj ? cj : ci;
     const double gii = gram[b3_tri_index(lo, lo, n)], gjj = gram[b3_tri_index(hi, hi, n)];
     const double gij = gram[b3_tri_index(lo, hi, n)];
     double v = (gii + gjj) - 2.0 * gij;
@@ -449,9 +380,11 @@ __device__ __forceinline__ void gram_to_sqdist(const double* __restrict__ gram, 
   }
   __syncthreads();
   if (threadIdx.x == 0 && sub != nullptr) {
+    bool alias_listed = false;
+    for (int r = n - 1; r < n_full; ++r) alias_listed |= listed[r] != 0;
     int count = 0;
-    for (int r = 0; r < n; ++r)
-      if (listed[r]) sub[1 + count++] = r;
+    for (int r = 0; r < n_full; ++r)
+      if (listed[r] || (alias_listed && r >= n - 1 && n_full > n)) sub[1 + count++] = r;
     sub[0] = count;
   }
 }
@@ -464,7 +397,7 @@ constexpr int kGramRedWaves = 16;  // 16 waves x 16 loads in flight: the sum is 
 static_assert(64 * kGramRedWaves == kSqThreads, "the last workgroup of the reduction runs gram_to_sqdist");
 __global__ __launch_bounds__(64 * kGramRedWaves) void gram_reduce_sqdist_kernel(
     const double* __restrict__ partial, int nblocks, int n, double* __restrict__ gram, double tau,
-    double* __restrict__ sq, int* __restrict__ sub) {
+    double* __restrict__ sq, int* __restrict__ sub, int n_full) {
   __shared__ double wsum[kGramRedWaves][64];
   __shared__ int listed[BM_MAX_ROWS];
   __shared__ int last;
@@ -486,22 +419,25 @@ __global__ __launch_bounds__(64 * kGramRedWaves) void gram_reduce_sqdist_kernel(
   }
   // arrival: release this workgroup's entries of G, take a ticket; the last ticket acquires everybody's
   if (!arrive_last(sub + kArrivalSlot, (int)gridDim.x, &last)) return;
-  gram_to_sqdist(gram, n, tau, sq, sub, listed);
+  gram_to_sqdist(gram, n, tau, sq, sub, listed, n_full);
   if (threadIdx.x == 0) {
     sub[kArrivalSlot] = 0;
     sub[kArrivalSlot + 1] = 0;  // arrival counter of the gated direct kernel (pairwise.hip), next on the stream
   }
 }
 
-// Fixed-order sum of the per-workgroup partial Gram matrices, then squared distances + accuracy flag.
-int gram_finish(const double* partial, int blocks, int n, double* gram, double* sq_nxn, int* sub, double tau,
+// Fixed-order sum of the per-workgroup partial Gram matrices (n rows), then the squared distances of the n_full >= n
+// rows of the stack (rows n-1 .. n_full-1 alias the last row of G) + accuracy flag.
+int gram_finish(const double* partial, int blocks, int n, int n_full, double* gram, double* sq_nxn, int* sub, double tau,
                 hipStream_t s) {
   const int64_t per_block = (int64_t)n * (n + 1) / 2;
   hipLaunchKernelGGL(gram_reduce_sqdist_kernel, dim3((int)((per_block + 63) / 64)), dim3(64 * kGramRedWaves), 0, s,
-                     partial, blocks, n, gram, tau, sq_nxn, sub);
+                     partial, blocks, n, gram, tau, sq_nxn, sub, n_full);
   BM_LAUNCH_CHECK();
   return 0;
 }
+
+int gram_arrival_slot() { return kArrivalSlot; }
 
 template <int K, int NPL>
 static int launch_gram3_planes(const RowTable& tab, int n, int64_t d, bool aligned, int centre, double* partial,

@@ -484,8 +484,9 @@ __global__ __launch_bounds__(kRankThreads) void krum_rank_kernel(const double* _
 }  // namespace bm
 
 namespace bm {
-int gram_finish(const double* partial, int blocks, int n, double* gram, double* sq_nxn, int* sub, double tau,
+int gram_finish(const double* partial, int blocks, int n, int n_full, double* gram, double* sq_nxn, int* sub, double tau,
                 hipStream_t s);
+int gram_arrival_slot();
 int gram3_partials(const float* const* rows, int n, int64_t d, int64_t d_total, double* partial, int* sub,
                    int* blocks_out, hipStream_t s);
 int64_t gram3_partial_doubles(int n);
@@ -563,10 +564,30 @@ extern "C" int bm_pairwise_sqdist_shard(const float* const* rows, int n, int64_t
   int rc = gram3_partials(rows, n, d, d_total, gram_partial, flag, &blocks, s);
   if (rc != 0) return rc;
   double* gram = gram_partial + gram3_partial_doubles(n);
-  rc = gram_finish(gram_partial, blocks, n, gram, sq_nxn, flag, tau, s);
+  rc = gram_finish(gram_partial, blocks, n, n, gram, sq_nxn, flag, tau, s);
   if (rc != 0 || tau <= 0.0) return rc;
   return pairwise_direct(rows, n, d, sq_nxn, direct_partial, flag, s);
 }
+
+namespace bm {
+// The tail of the distance pass for partial Gram matrices some other kernel has left in the workspace (step.hip: the
+// first pass of a step contracts its rows itself): `blocks` partials of nc(nc+1)/2 doubles at pairwise_gram_area(ws);
+// rows = the n_full rows of the stack, rows nc-1 .. n_full-1 being one row of G.  Same reduction, gate and exact pass
+// as bm_pairwise_sqdist.
+double* pairwise_gram_area(void* ws) { return reinterpret_cast<double*>(static_cast<char*>(ws) + 512); }
+int* pairwise_arrival_counter(void* ws) { return static_cast<int*>(ws) + gram_arrival_slot(); }
+int pairwise_from_gram_partials(const float* const* rows, int n_full, int nc, int blocks, int64_t d, double* sq_nxn,
+                                void* ws, hipStream_t s) {
+  int* flag = static_cast<int*>(ws);
+  double* gram_partial = pairwise_gram_area(ws);
+  double* direct_partial = gram_partial + pair_gram_doubles(n_full);
+  double* gram = gram_partial + gram3_partial_doubles(n_full);
+  const double tau = tuning().pair_tau;
+  int rc = gram_finish(gram_partial, blocks, nc, n_full, gram, sq_nxn, flag, tau, s);
+  if (rc != 0 || tau <= 0.0) return rc;
+  return pairwise_direct(rows, n_full, d, sq_nxn, direct_partial, flag, s);
+}
+}  // namespace bm
 
 extern "C" int bm_krum_rank(const double* sq_nxn, int n, int f, int m, int mode,
                             int32_t* order_out, double* scores_out, void* stream) {

@@ -123,17 +123,21 @@ extern "C" int bm_allgather_f32(bm_comm* comm, const float* mine, float* all, in
 namespace {
 constexpr int64_t kShardHeader = BM_MAX_ROWS * BM_MAX_ROWS * 8 + BM_MAX_ROWS * 4 + 256;
 
+// have_sq: the squared distances of the local shard are already at the head of ws (bm_momentum_stats_sqdist wrote them)
 int sharded_rank(bm_comm* comm, const float* const* rows, int n, int64_t d_local, int f, int m, int mode, void* ws,
-                 void* stream, double** sq_out, int32_t** order_out) {
+                 void* stream, double** sq_out, int32_t** order_out, bool have_sq = false) {
   char* base = static_cast<char*>(ws);
   double* sq = reinterpret_cast<double*>(base);
   int32_t* order = reinterpret_cast<int32_t*>(base + BM_MAX_ROWS * BM_MAX_ROWS * 8);
   void* pair_ws = base + kShardHeader;
-  // the precision plan of the distance pass follows the length of the WHOLE vector (all shards): shards are equal
-  // up to the 64-coordinate rounding of shard_bounds, d_local * ranks is the total to within that
-  const int64_t d_total = d_local * (int64_t)bm_comm_size(comm);
-  int rc = bm_pairwise_sqdist_shard(rows, n, d_local, d_total, sq, pair_ws, stream);
-  if (rc != 0) return rc;
+  int rc = 0;
+  if (!have_sq) {
+    // the precision plan of the distance pass follows the length of the WHOLE vector (all shards): shards are equal
+    // up to the 64-coordinate rounding of shard_bounds, d_local * ranks is the total to within that
+    const int64_t d_total = d_local * (int64_t)bm_comm_size(comm);
+    rc = bm_pairwise_sqdist_shard(rows, n, d_local, d_total, sq, pair_ws, stream);
+    if (rc != 0) return rc;
+  }
   rc = bm_allreduce_sum_f64(comm, sq, (int64_t)n * n, stream);
   if (rc != 0) return rc;
   rc = bm_krum_rank(sq, n, f, m, mode, order, nullptr, stream);
@@ -181,6 +185,31 @@ extern "C" int bm_sharded_bulyan(bm_comm* comm, const float* const* rows, int n,
                                      static_cast<hipStream_t>(stream)));
     if (rc != 0) return rc;
   }
+  if (d_local == 0) return 0;
+  return bm_bulyan_pass2(rows, n, order, f, m, d_local, out_local, stream);
+}
+
+// The same two rules when the squared distances of the local shard are already in the workspace
+// (bm_sharded_sq_slot(ws), written by bm_momentum_stats_sqdist with ws_pair = bm_sharded_pair_workspace(ws)).
+extern "C" double* bm_sharded_sq_slot(void* ws) { return static_cast<double*>(ws); }
+extern "C" void* bm_sharded_pair_workspace(void* ws) { return static_cast<char*>(ws) + kShardHeader; }
+
+extern "C" int bm_sharded_rule_from_sq(bm_comm* comm, int rule, const float* const* rows, int n, int64_t d_local, int f,
+                                       int m, float* out_local, int32_t* order_out, void* ws, void* stream) {
+  if (rows == nullptr || (out_local == nullptr && d_local > 0) || ws == nullptr || n < 1 || n > BM_MAX_ROWS ||
+      d_local < 0 || f < 0 || m < 1 || m > n || (rule != BM_RULE_KRUM && rule != BM_RULE_BULYAN))
+    return BM_EINVAL;
+  double* sq;
+  int32_t* order;
+  int rc = sharded_rank(comm, rows, n, d_local, f, m, rule == BM_RULE_KRUM ? BM_RANK_KRUM : BM_RANK_BULYAN, ws, stream,
+                        &sq, &order, true);
+  if (rc != 0) return rc;
+  if (order_out != nullptr) {
+    rc = bm::hip_code(hipMemcpyAsync(order_out, order, BM_MAX_ROWS * sizeof(int32_t), hipMemcpyDeviceToDevice,
+                                     static_cast<hipStream_t>(stream)));
+    if (rc != 0) return rc;
+  }
+  if (rule == BM_RULE_KRUM) return bm_selected_mean(rows, n, order, m, d_local, out_local, stream);
   if (d_local == 0) return 0;
   return bm_bulyan_pass2(rows, n, order, f, m, d_local, out_local, stream);
 }

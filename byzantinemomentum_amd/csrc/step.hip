@@ -15,6 +15,7 @@
 // table; reductions leave the kernel as fp64 per-workgroup partials and are finished in a fixed
 // order by a one-wave kernel: deterministic, no float atomics, no host synchronisation.
 #include "colwise_kernels.h"  // column_rule: the coordinate-wise rules on register-resident values
+#include "gram_split.h"       // bf16 planes + MFMA: the distance pass riding along with the first pass
 
 namespace bm {
 
@@ -204,6 +205,237 @@ __global__ __launch_bounds__(BURST ? kStepBurstBlock : kStepBlock) void momentum
     p[4] = r4;
     p[5] = (double)r5;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// First pass + squared distances (Krum / Bulyan steps).  The distance pass of those rules reads the h updated buffers
+// and the Byzantine vector — exactly what the first pass has just formed in registers.  This kernel contracts the
+// centred rows on the bf16 matrix cores where they are (gram_bf16.hip's scheme: two bf16 planes with a coordinate
+// dither, one accumulator per magnitude class, dithered fp32 running sums), so the 25 row passes of the stand-alone
+// distance kernel (of the 115 of a C5 step with Krum) are not made at all.
+//   * shape: ks = h = 20, NB = 1..6 Byzantine copies, 16-byte columns, burst form (one workgroup of 512 lanes per CU);
+//   * centre of the Gram: the honest average of the column (the first pass has it; it lies inside the honest stack);
+//   * rows: 20 buffers + ONE Byzantine row (the NB copies are identical: the host expands the 21 x 21 matrix);
+//   * a wave's iteration covers 256 coordinates, contracted in two halves of 128 through a wave-private LDS region
+//     [plane][32 rows][128 coordinates] (rows padded to 272 B: the ds_read_b128 fragment reads of 16 rows are
+//     conflict-free); rows 21..31 stay zero.
+// Everything else (momentum, statistics, averages, Byzantine vector, stores) is momentum_stats_kernel<20, 4, true, CLIP, true>
+// operation for operation: same bits.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kSgT = 20;                     // honest rows
+constexpr int kSgRows = 32;                  // LDS rows per plane (two 16-row blocks)
+constexpr int kSgRowBytes = 272;             // 128 coordinates x 2 B + 16 B of padding
+constexpr int kSgPlaneBytes = kSgRows * kSgRowBytes;
+constexpr int kSgWaveBytes = 2 * kSgPlaneBytes;
+constexpr int kSgWaves = kStepBurstBlock / 64;
+constexpr int kSgLds = kSgWaves * kSgWaveBytes;  // 139 264 B (the final reduction aliases it)
+constexpr int kSgN = kSgT + 1;                   // rows of the compact Gram
+
+template <bool CLIP>
+__global__ __launch_bounds__(kStepBurstBlock) void momentum_gram_kernel(
+    StepTable tab, uint32_t nvec, float mu, float omd, const float* __restrict__ clipf, float* __restrict__ s_avg_out,
+    float* __restrict__ h_avg_out, float* __restrict__ byz_out, float scale, int attack_kind, unsigned dither_seed,
+    double* __restrict__ partial, double* __restrict__ gram_partial, int* __restrict__ arrival) {
+  constexpr int T = kSgT, VEC = 4, BLOCK = kStepBurstBlock;
+  extern __shared__ __attribute__((aligned(16))) char sg_smem[];
+  __shared__ double red[BLOCK / 64];
+  __shared__ float mred[BLOCK / 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  char* wbase = sg_smem + wave * kSgWaveBytes;
+  // zero this wave's planes once (rows 21..31 are never written again)
+  for (int o = lane * 16; o < kSgWaveBytes; o += 64 * 16) *reinterpret_cast<f32x4*>(wbase + o) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+  if (blockIdx.x == 0 && tid == 0 && arrival != nullptr) *arrival = 0;  // see gram_reduce_sqdist_kernel
+  const float fks = (float)T, fh = (float)T;
+  float n2s = 0.0f, dvs = 0.0f, mxs = 0.0f, n2h = 0.0f, dvh = 0.0f, mxh = 0.0f;
+  bool nan_s = false, nan_h = false;
+  float outer[3][4];
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) outer[p][v] = 0.0f;
+  uint64_t kbase = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+  (void)tab;
+  const uint32_t span = gridDim.x * BLOCK;
+  const uint32_t iters = (nvec + span - 1) / span;
+  const uint32_t first = blockIdx.x * BLOCK + threadIdx.x;
+  // fragment read addresses: lane (i = l & 15, g = l >> 4) reads row 16 R + i, 8 consecutive coordinates 32 s + 8 g
+  const int li = lane & 15, lg = lane >> 4;
+  const int rd0 = li * kSgRowBytes + lg * 16;
+  const int wr0 = (lane & 31) * 8;  // this lane's 4 coordinates of its half: 8 B per plane and row
+  for (uint32_t it = 0; it < iters; ++it) {
+    const uint32_t v = it * span + first;
+    const bool live = v < nvec;
+    const uint32_t off = v * (uint32_t)(VEC * sizeof(float));
+    float b[T][VEC];
+    float sa[VEC], ha[VEC], bz[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) sa[c] = ha[c] = bz[c] = 0.0f;
+    asm volatile("" : "+s"(kbase));
+    if (live) {
+      float g[T][VEC];  // dead once the statistics of the sampled stack are formed
+      KargRowPtrs karg = (KargRowPtrs)kbase;
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
+        load_stream_off<VEC>(karg[i], off, g[i]);
+        load_stream_off<VEC>(karg[BM_MAX_ROWS + i], off, b[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < T; ++i) {
+        if constexpr (CLIP) {
+          const float cf = clipf[i];
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) g[i][c] *= cf;
+        }
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) b[i][c] = __builtin_fmaf(omd, g[i][c], mu * b[i][c]);
+      }
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) {
+        float s = g[0][c];
+#pragma unroll
+        for (int i = 1; i < T; ++i) s += g[i][c];
+        s = s / fks;
+        sa[c] = s;
+        n2s = __builtin_fmaf(s, s, n2s);
+        mxs = fmaxf(mxs, __builtin_fabsf(s));
+        nan_s |= (s != s);
+        float q = 0.0f;
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+          const float df = g[i][c] - s;
+          q = __builtin_fmaf(df, df, q);
+        }
+        dvs += q;
+        float t = b[0][c];
+#pragma unroll
+        for (int i = 1; i < T; ++i) t += b[i][c];
+        t = t / fh;
+        ha[c] = t;
+        n2h = __builtin_fmaf(t, t, n2h);
+        mxh = fmaxf(mxh, __builtin_fabsf(t));
+        nan_h |= (t != t);
+        float qh = 0.0f;
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+          const float df = b[i][c] - t;
+          qh = __builtin_fmaf(df, df, qh);
+        }
+        dvh += qh;
+        const float dir = ((attack_kind & 15) == BM_ATTACK_LITTLE) ? __builtin_sqrtf(qh / (fh - 1.0f)) : -t;
+        const float att = dir * scale;
+        bz[c] = (attack_kind & BM_ATTACK_DIRECTION) ? att : t + att;
+      }
+    }
+    // ---- the Gram of the centred rows (20 updated buffers + the Byzantine row), two halves of 128 coordinates ----
+    __builtin_amdgcn_sched_barrier(0);  // keep the two phases apart: interleaved, they do not fit the register file
+    {
+      const unsigned coord = v * 4u;
+      const unsigned d01 = dither_seed == ~0u ? 0x80008000u : dither_pair(coord + dither_seed);
+      const unsigned d23 = dither_seed == ~0u ? 0x80008000u : dither_pair(coord + 2u + dither_seed);
+      // a non-finite centre must not poison the other rows (a NaN row then shows up as NaN distances of that row only)
+      f32x4 ctr;
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) ctr[c] = (__builtin_fabsf(ha[c]) < __builtin_inff()) ? ha[c] : 0.0f;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        // dither of the running sums: one zero-mean number of 1..2 ulps per (wave iteration, half), see gram_bf16.hip
+        const unsigned z = dither_pair((v / 64u * 2u + (unsigned)half) * 2u + 0x3C6EF372u);
+        const float rc = (float)((int)(z & 0xffffu) + (int)(z >> 16) - 65536) * 0x1.0p-39f;
+        if ((lane >> 5) == half) {
+#pragma unroll
+          for (int r = 0; r <= T; ++r) {
+            f32x4 x;
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) x[c] = live ? ((r < T ? b[r < T ? r : 0][c] : bz[c]) - ctr[c]) : 0.0f;
+            u32x2 hp, mp;
+            split2_dithered(x, d01, d23, hp, mp);
+            *reinterpret_cast<u32x2*>(wbase + r * kSgRowBytes + wr0) = hp;
+            *reinterpret_cast<u32x2*>(wbase + kSgPlaneBytes + r * kSgRowBytes + wr0) = mp;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // one block pair at a time (16 accumulator registers in flight instead of 48; the fragments are read again
+        // for every pair they belong to: the LDS has the bandwidth, the register file has no room)
+        const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+        int p = 0;
+#pragma unroll
+        for (int I = 0; I < 2; ++I)
+#pragma unroll
+          for (int J = I; J < 2; ++J) {
+            f32x4 s0 = zero, s1 = zero, s2 = zero, s3 = zero;
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl) {
+              const int oi = rd0 + I * 16 * kSgRowBytes + sl * 64, oj = rd0 + J * 16 * kSgRowBytes + sl * 64;
+              const u32x4 fhi = *reinterpret_cast<const u32x4*>(wbase + oi);
+              const u32x4 fmi = *reinterpret_cast<const u32x4*>(wbase + kSgPlaneBytes + oi);
+              const u32x4 fhj = (I == J) ? fhi : *reinterpret_cast<const u32x4*>(wbase + oj);
+              const u32x4 fmj = (I == J) ? fmi : *reinterpret_cast<const u32x4*>(wbase + kSgPlaneBytes + oj);
+              s0 = mfma_bf16(fhi, fhj, s0);
+              s1 = mfma_bf16(fhi, fmj, s1);
+              s3 = mfma_bf16(fmi, fmj, s3);
+              s2 = mfma_bf16(fmi, fhj, s2);
+            }
+            const f32x4 t4 = s0 + ((s1 + s2) + s3);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) outer[p][q] = outer[p][q] + __builtin_fmaf(outer[p][q], rc, t4[q]);
+            ++p;
+          }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();  // burst form: loads + arithmetic, then the stores of the whole workgroup
+    asm volatile("" : "+s"(kbase));
+    if (live) {
+      KargRowPtrs karg = (KargRowPtrs)kbase;
+#pragma unroll
+      for (int i = 0; i < T; ++i) store_stream_off<VEC>(const_cast<float*>(karg[BM_MAX_ROWS + i]), off, b[i]);
+      if (s_avg_out != nullptr) store_stream_off<VEC>(s_avg_out, off, sa);
+      if (h_avg_out != nullptr) store_stream_off<VEC>(h_avg_out, off, ha);
+      store_stream_off<VEC>(byz_out, off, bz);
+    }
+  }
+  if (nan_s) mxs = __builtin_nanf("");
+  if (nan_h) mxh = __builtin_nanf("");
+  const double r0 = block_reduce_sum<BLOCK>((double)n2s, red);
+  const double r1 = block_reduce_sum<BLOCK>((double)dvs, red);
+  const double r3 = block_reduce_sum<BLOCK>((double)n2h, red);
+  const double r4 = block_reduce_sum<BLOCK>((double)dvh, red);
+  const float r2 = block_reduce_absmax<BLOCK>(mxs, mred);
+  const float r5 = block_reduce_absmax<BLOCK>(mxh, mred);
+  if (threadIdx.x == 0) {
+    double* p = partial + (int64_t)blockIdx.x * 6;
+    p[0] = r0;
+    p[1] = r1;
+    p[2] = (double)r2;
+    p[3] = r3;
+    p[4] = r4;
+    p[5] = (double)r5;
+  }
+  // ---- workgroup reduction of the partial Gram, fixed order; compact upper triangle of the 21 x 21 matrix ----
+  // C/D layout of the 16x16 MFMA: lane l, register v -> row 4*(l>>4)+v, column l&15.
+  double* gred = reinterpret_cast<double*>(sg_smem);  // [waves][256], aliases the planes
+  constexpr int per_block = kSgN * (kSgN + 1) / 2;
+  __syncthreads();
+  int p = 0;
+#pragma unroll
+  for (int I = 0; I < 2; ++I)
+#pragma unroll
+    for (int J = I; J < 2; ++J) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) gred[wave * 256 + (4 * lg + q) * 16 + li] = (double)outer[p][q];
+      __syncthreads();
+      if (tid < 256) {
+        const int rr = tid >> 4, cc = tid & 15;
+        double sum = gred[tid];
+#pragma unroll
+        for (int w = 1; w < kSgWaves; ++w) sum += gred[w * 256 + tid];
+        const int gi = 16 * I + rr, gj = 16 * J + cc;
+        if (gi <= gj && gj < kSgN) gram_partial[(int64_t)blockIdx.x * per_block + b3_tri_index(gi, gj, kSgN)] = sum;
+      }
+      __syncthreads();
+      ++p;
+    }
 }
 
 // Streaming form of the same pass, used above 20 rows (where the register-resident form would have to drop
@@ -603,6 +835,28 @@ static int launch_fused_rule_any(int op, int nb, const StepTable& tab, int64_t n
   return 0;
 }
 
+// Gram contribution of the d mod 4 trailing columns (at most 3) of the fused distance pass: one more partial block,
+// in fp64, centred on the honest average like the body.
+__global__ __launch_bounds__(256) void tail_gram_kernel(RowTable rows /* 20 buffers + byz, offset to the tail */,
+                                                        const float* __restrict__ h_avg_tail, int cols,
+                                                        double* __restrict__ block) {
+  const int t = threadIdx.x;
+  if (t >= kSgN * (kSgN + 1) / 2) return;
+  int i = 0, rem = t, len = kSgN;  // t -> (i, j), i <= j, row-major over the upper triangle
+  while (rem >= len) {
+    rem -= len;
+    --len;
+    ++i;
+  }
+  const int j = i + rem;
+  double acc = 0.0;
+  for (int c = 0; c < cols; ++c) {
+    const float ctr = (__builtin_fabsf(h_avg_tail[c]) < __builtin_inff()) ? h_avg_tail[c] : 0.0f;
+    acc += (double)(rows.p[i][c] - ctr) * (double)(rows.p[j][c] - ctr);
+  }
+  block[b3_tri_index(i, j, kSgN)] = acc;
+}
+
 static inline int vec_of(uintptr_t bits) { return (bits & 15u) == 0 ? 4 : ((bits & 7u) == 0 ? 2 : 1); }
 
 }  // namespace bm
@@ -725,6 +979,87 @@ extern "C" int bm_momentum_stats_colwise(const float* const* sampled, int ks, fl
   if (rule_op < 0) return BM_EINVAL;
   return bm::momentum_stats_impl(sampled, ks, buffers, h, d, mu, one_minus_damp, clip_factors, sampled_avg, honest_avg,
                                  byz_out, scale, attack_kind, out6, ws, stream, rule_op, rule_f, n_byz, defense_out);
+}
+
+namespace bm {
+double* pairwise_gram_area(void* ws);       // pairwise.hip
+int* pairwise_arrival_counter(void* ws);
+int pairwise_from_gram_partials(const float* const* rows, int n_full, int nc, int blocks, int64_t d, double* sq_nxn,
+                                void* ws, hipStream_t s);
+}
+
+extern "C" int bm_momentum_stats_sqdist(const float* const* sampled, int ks, float* const* buffers, int h, int64_t d,
+                                        int64_t d_total, float mu, float one_minus_damp, const float* clip_factors,
+                                        float* sampled_avg, float* honest_avg, float* byz_out, float scale,
+                                        int attack_kind, int n_byz, double* sq_nxn, double* out6, void* ws,
+                                        void* ws_pair, void* stream) {
+  using namespace bm;
+  const int n = h + n_byz;
+  if (sampled == nullptr || buffers == nullptr || out6 == nullptr || ws == nullptr || ws_pair == nullptr ||
+      sq_nxn == nullptr || h < 1 || ks < h || ks > BM_MAX_ROWS || n_byz < 1 || n > BM_MAX_ROWS || d < 0 || d_total < d ||
+      (attack_kind != BM_ATTACK_EMPIRE && attack_kind != BM_ATTACK_LITTLE) || (d > 0 && byz_out == nullptr))
+    return BM_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float* rows[BM_MAX_ROWS];
+  for (int i = 0; i < h; ++i) rows[i] = buffers[i];
+  for (int i = h; i < n; ++i) rows[i] = byz_out;
+  uintptr_t bits = reinterpret_cast<uintptr_t>(sampled_avg) | reinterpret_cast<uintptr_t>(honest_avg) |
+                   reinterpret_cast<uintptr_t>(byz_out);
+  for (int i = 0; i < ks; ++i) bits |= reinterpret_cast<uintptr_t>(sampled[i]);
+  for (int i = 0; i < h; ++i) bits |= reinterpret_cast<uintptr_t>(buffers[i]);
+  const int cus = compute_units();
+  const int64_t nvec = d / 4;
+  const bool fused = ks == kSgT && h == kSgT && n_byz <= 6 && vec_of(bits) == 4 && honest_avg != nullptr &&
+                     d <= kMaxColsPerLaunch && tuning().step_stream != 1 && tuning().pair_mode == 0 &&
+                     tuning().pair_planes != 3 && tuning().step_burst > 0 &&
+                     nvec / ((int64_t)cus * kStepBurstBlock) >= tuning().step_burst;
+  if (!fused) {  // the two passes one after the other: same results as the fused kernel up to the distances' rounding
+    int rc = bm_momentum_stats(sampled, ks, buffers, h, d, mu, one_minus_damp, clip_factors, sampled_avg, honest_avg,
+                               byz_out, scale, attack_kind, out6, ws, stream);
+    if (rc != 0) return rc;
+    return bm_pairwise_sqdist_shard(rows, n, d, d_total, sq_nxn, ws_pair, stream);
+  }
+  StepTable tab{};
+  for (int i = 0; i < ks; ++i) tab.g[i] = sampled[i];
+  for (int i = 0; i < h; ++i) tab.b[i] = buffers[i];
+  for (int i = ks; i < BM_MAX_ROWS; ++i) tab.g[i] = sampled[ks - 1];
+  for (int i = h; i < BM_MAX_ROWS; ++i) tab.b[i] = buffers[h - 1];
+  double* partial = static_cast<double*>(ws);
+  double* gram_partial = pairwise_gram_area(ws_pair);
+  constexpr int per_block = kSgN * (kSgN + 1) / 2;
+  auto kern = clip_factors != nullptr ? momentum_gram_kernel<true> : momentum_gram_kernel<false>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     kSgLds);
+  if (e != hipSuccess) return hip_code(e);
+  hipLaunchKernelGGL(kern, dim3(cus), dim3(kStepBurstBlock), kSgLds, s, tab, (uint32_t)nvec, mu, one_minus_damp,
+                     clip_factors, sampled_avg, honest_avg, byz_out, scale, attack_kind, (unsigned)tuning().pair_dither,
+                     partial, gram_partial, pairwise_arrival_counter(ws_pair));
+  BM_LAUNCH_CHECK();
+  int nparts = cus, blocks = cus;
+  const int64_t body = nvec * 4;
+  if (body < d) {  // at most 3 trailing columns: the scalar form of the first pass, and their Gram as one more block
+    StepTable tail = tab;
+    for (int i = 0; i < BM_MAX_ROWS; ++i) {
+      tail.g[i] += body;
+      tail.b[i] += body;
+    }
+    int grid = 1;
+    int rc = dispatch_momentum_stats<1>(tail, ks, h, d - body, mu, one_minus_damp, clip_factors,
+                                        sampled_avg ? sampled_avg + body : nullptr, honest_avg + body, byz_out + body,
+                                        scale, attack_kind, partial + (int64_t)nparts * 6, &grid, s);
+    if (rc != 0) return rc;
+    nparts += grid;
+    RowTable trows{};
+    for (int i = 0; i < h; ++i) trows.p[i] = buffers[i] + body;
+    trows.p[h] = byz_out + body;
+    hipLaunchKernelGGL(tail_gram_kernel, dim3(1), dim3(256), 0, s, trows, honest_avg + body, (int)(d - body),
+                       gram_partial + (int64_t)blocks * per_block);
+    BM_LAUNCH_CHECK();
+    blocks += 1;
+  }
+  hipLaunchKernelGGL(step_finish_kernel, dim3(1), dim3(kFinishThreads), 0, s, partial, nparts, out6);
+  BM_LAUNCH_CHECK();
+  return pairwise_from_gram_partials(rows, n, kSgN, blocks, d, sq_nxn, ws_pair, s);
 }
 
 extern "C" int bm_multi_fma3(float* const* out, const float* const* p, const float* const* q, int k, int64_t d,

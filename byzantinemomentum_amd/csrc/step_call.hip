@@ -144,29 +144,37 @@ extern "C" int bm_step_worker(bm_comm* comm, const bm_step_params* p, const floa
     clipf = sc->clipf;
   }
 
-  // ---- pass 1: momentum, statistics of the sampled and honest stacks, Byzantine vector; a coordinate-wise rule over
-  //      the buffers and the Byzantine copies rides along (inside the same kernel for median / trmean at h = 20) ----
+  // ---- pass 1: momentum, statistics of the sampled and honest stacks, Byzantine vector; what the rule needs rides
+  //      along: a coordinate-wise rule itself, or the distance pass of Krum / Bulyan (inside the same kernel at h = 20) ----
   const bool distance_rule_ = p->rule == BM_RULE_KRUM || p->rule == BM_RULE_BULYAN;
-  const bool rides_along = !distance_rule_ && fr >= 1;
-  if (rides_along) {
+  const bool rides_along = fr >= 1;  // the rule (or its distance pass) is fed from the first pass's registers
+  const float* rows[BM_MAX_ROWS];
+  for (int i = 0; i < h; ++i) rows[i] = buffers[i];
+  for (int i = h; i < n; ++i) rows[i] = byz_out;
+  const int m = p->m > 0 ? p->m : n - p->f_decl - 2;
+  if (rides_along && !distance_rule_) {
     const int op = p->rule == BM_RULE_MEDIAN ? BM_OP_MEDIAN
                    : p->rule == BM_RULE_TRMEAN ? BM_OP_TRMEAN : p->rule == BM_RULE_PHOCAS ? BM_OP_PHOCAS : BM_OP_MEAMED;
     rc = bm_momentum_stats_colwise(sampled, ks, buffers, h, d, p->mu, p->one_minus_damp, clipf, sampled_avg_out,
                                    honest_avg_out, byz_out, p->attack_scale, p->attack_kind, op, p->f_decl, fr,
                                    defense_out, sc->out6, base + lay.ws_step, stream);
+    if (rc != 0) return rc;
+  } else if (rides_along) {
+    // Krum / Bulyan: the squared distances of this shard come out of the first pass (the plan of the distance pass
+    // follows the length of the whole vector, d_local x ranks, as in bm_sharded_krum); then all-reduce -> rank -> rule
+    char* rule_ws = base + lay.ws_rule;
+    rc = bm_momentum_stats_sqdist(sampled, ks, buffers, h, d, d * (int64_t)bm_comm_size(comm), p->mu, p->one_minus_damp,
+                                  clipf, sampled_avg_out, honest_avg_out, byz_out, p->attack_scale, p->attack_kind, fr,
+                                  bm_sharded_sq_slot(rule_ws), sc->out6, base + lay.ws_step,
+                                  bm_sharded_pair_workspace(rule_ws), stream);
+    if (rc != 0) return rc;
+    rc = bm_sharded_rule_from_sq(comm, p->rule, rows, n, d, p->f_decl, m, defense_out, nullptr, rule_ws, stream);
+    if (rc != 0) return rc;
   } else {
     rc = bm_momentum_stats(sampled, ks, buffers, h, d, p->mu, p->one_minus_damp, clipf, sampled_avg_out, honest_avg_out,
-                           fr > 0 ? byz_out : nullptr, p->attack_scale, p->attack_kind, sc->out6, base + lay.ws_step,
-                           stream);
-  }
-  if (rc != 0) return rc;
-
-  // ---- the rule over honests + [byz] * f_real ----
-  if (!rides_along) {
-    const float* rows[BM_MAX_ROWS];
-    for (int i = 0; i < h; ++i) rows[i] = buffers[i];
-    for (int i = h; i < n; ++i) rows[i] = byz_out;
-    const int m = p->m > 0 ? p->m : n - p->f_decl - 2;
+                           nullptr, p->attack_scale, p->attack_kind, sc->out6, base + lay.ws_step, stream);
+    if (rc != 0) return rc;
+    // ---- the rule over the honest rows alone (no attack) ----
     switch (p->rule) {
       case BM_RULE_KRUM:
         rc = bm_sharded_krum(comm, rows, n, d, p->f_decl, m, defense_out, nullptr, base + lay.ws_rule, stream);

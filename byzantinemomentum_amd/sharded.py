@@ -145,6 +145,9 @@ class HipBackend:
   def momentum_stats_colwise(self, *args, **kwargs):
     return self.stats.momentum_stats_colwise(*args, **kwargs)
 
+  def momentum_stats_sqdist(self, *args, **kwargs):
+    return self.stats.momentum_stats_sqdist(*args, **kwargs)
+
   def multi_fma3(self, outs, ps, qs, a, b, p_scale=None):
     return self.stats.multi_fma3(outs, ps, qs, a, b, p_scale)
 
@@ -329,6 +332,18 @@ class ShardedAggregator:
     if self.single_call:
       return self.backend.sharded_rule("bulyan", self.native, local, f, m)
     order = self.backend.rank(self.global_sqdist(local), n, f, m, _lib.RANK_BULYAN)
+    return self.backend.bulyan_pass2(local, order, f, m)
+
+  def rule_from_sq(self, name, local, local_sq, f, m=None):
+    """Multi-Krum / Bulyan when the squared distances of the local shard are already known (the first pass of a step
+    produced them, stats.momentum_stats_sqdist): all-reduce, rank, average / pass 2."""
+    n = len(local)
+    if m is None:
+      m = n - f - 2
+    sq = self._all_reduce(local_sq)  # in place: a fresh tensor per call
+    order = self.backend.rank(sq, n, f, m, _lib.RANK_KRUM if name == "krum" else _lib.RANK_BULYAN)
+    if name == "krum":
+      return self.backend.selected_mean(local, order, m)
     return self.backend.bulyan_pass2(local, order, f, m)
 
   def aksel(self, local, f, mode="mid"):

@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from . import gars
 
-__all__ = ["compute_avg_dev_max", "stack_stats_async", "study_dots", "study_stats", "multi_axpby", "row_sqnorms", "momentum_stats", "momentum_stats_colwise",
+__all__ = ["compute_avg_dev_max", "stack_stats_async", "study_dots", "study_stats", "multi_axpby", "row_sqnorms", "momentum_stats", "momentum_stats_colwise", "momentum_stats_sqdist",
            "multi_fma3", "clip_factors", "clip_factors_from_sq", "multi_scale", "clip_gradients", "l2_distance",
            "step_worker"]
 
@@ -194,6 +194,33 @@ def momentum_stats_colwise(sampled, buffers, mu, one_minus_damp, clip_factors_de
       _COLWISE_OPS[rule], int(f), int(n_byz), _ptr(defense), _ptr(out6), _ptr(ws), gars._stream(device)),
       "bm_momentum_stats_colwise")
   return s_avg, h_avg, byz, defense, out6
+
+
+def momentum_stats_sqdist(sampled, buffers, mu, one_minus_damp, clip_factors_dev, attack_scale, attack, n_byz,
+                          d_total=None):
+  """momentum_stats together with the n x n squared distances (n = len(buffers) + n_byz) of the updated buffers and
+  the Byzantine copies — contracted inside the same kernel at ks = h = 20 for long gradients
+  (bm_momentum_stats_sqdist).  Returns (sampled_avg, honest_avg, byz, sq, out6). No sync."""
+  ks, d, device = gars._validate(list(sampled))
+  h = gars._validate(list(buffers) + [sampled[0]])[0] - 1
+  if h < 1 or ks < h or n_byz < 1 or h + n_byz > _lib.MAX_ROWS:
+    raise gars.GarInputError("momentum_stats_sqdist needs 1 <= len(buffers) <= len(sampled), n_byz >= 1, at most 64 rows")
+  n = h + n_byz
+  lib = _lib.load()
+  s_avg, h_avg, byz = (torch.empty(d, dtype=torch.float32, device=device) for _ in range(3))
+  sq = torch.empty((n, n), dtype=torch.float64, device=device)
+  out6 = torch.empty(6, dtype=torch.float64, device=device)
+  ws = gars._workspace(device, _lib.WS_STEP, 1, d, "ws_step")
+  ws_pair = gars._workspace(device, _lib.WS_PAIRWISE, n, d, "ws_pair")
+  gars.invalidate_rank_cache()
+  with torch.cuda.device(device):
+    _lib.check(lib.bm_momentum_stats_sqdist(
+      _lib.pointer_table(sampled), ks, _lib.pointer_table(buffers), h, d, d if d_total is None else int(d_total),
+      ctypes.c_float(mu), ctypes.c_float(one_minus_damp),
+      _ptr(clip_factors_dev) if clip_factors_dev is not None else None, _ptr(s_avg), _ptr(h_avg), _ptr(byz),
+      ctypes.c_float(attack_scale), _attack_id(attack, False), int(n_byz), _ptr(sq), _ptr(out6), _ptr(ws), _ptr(ws_pair),
+      gars._stream(device)), "bm_momentum_stats_sqdist")
+  return s_avg, h_avg, byz, sq, out6
 
 
 def multi_fma3(outs, ps, qs, a, b, p_scale_dev=None):

@@ -178,7 +178,7 @@ class AggregationStep:
       agg.all_reduce_sum(sq)
       factors = ops.clip_factors_from_sq(sq, ks, self.clip)
     # 1.+2. momentum, attack vector, sampled/honest statistics
-    fused_defense = None
+    fused_defense, fused_sq = None, None
     if self.momentum_at == "worker":
       if self.buffers is None:
         self.buffers = self._new_rows(h, sampled[0], zero=True)
@@ -187,6 +187,12 @@ class AggregationStep:
       if fused_rule:  # first pass + coordinate-wise rule in one call (one kernel for median / trmean at h = 20)
         s_avg, h_avg, byz, fused_defense, out6 = ops.momentum_stats_colwise(
           sampled, self.buffers, self.mu, omd, factors, self.factor, self.attack, self.gar, self.f_decl, self.f_real)
+      elif (self.attack_evals is None and self.f_real >= 1 and self.gar in ("krum", "bulyan")
+            and not (set(self.gar_args) - {"m"}) and hasattr(ops, "momentum_stats_sqdist")):
+        # first pass + the distance pass of the rule in one call (one kernel at h = 20 for long gradients)
+        s_avg, h_avg, byz, fused_sq, out6 = ops.momentum_stats_sqdist(
+          sampled, self.buffers, self.mu, omd, factors, self.factor, self.attack, self.f_real,
+          d_total=sampled[0].shape[0] * agg.world_size)
       elif self.attack_evals is None:
         s_avg, h_avg, byz, out6 = ops.momentum_stats(sampled, self.buffers, self.mu, omd, factors, self.factor, self.attack)
       else:  # the attack direction alone; the Byzantine vector follows the factor search
@@ -219,7 +225,12 @@ class AggregationStep:
       ops.multi_fma3([byz], [h_avg], [direction], 1.0, self.last_factor)
     attacks = [byz] * self.f_real
     # 3. aggregation
-    defense = fused_defense if fused_defense is not None else self._aggregate(honests + attacks)
+    if fused_defense is not None:
+      defense = fused_defense
+    elif fused_sq is not None:
+      defense = agg.rule_from_sq(self.gar, honests + attacks, fused_sq, self.f_decl, self.gar_args.get("m"))
+    else:
+      defense = self._aggregate(honests + attacks)
     # 4. momentum of the update
     if self.momentum_at == "server":
       self.server_momentum = defense          # no clone, as attack.py:835

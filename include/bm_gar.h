@@ -204,6 +204,20 @@ int bm_momentum_stats_colwise(const float* const* sampled, int ks, float* const*
                               float* honest_avg, float* byz_out, float scale, int attack_kind, int rule_op,
                               int rule_f, int n_byz, float* defense_out, double* out6, void* ws, void* stream);
 
+/* The same first pass together with the squared distances of the n = h + n_byz rows (the h updated buffers and n_byz
+ * copies of byz_out) that Krum / Bulyan / Brute rank next (attack.py:821 with a distance-based rule and worker momentum):
+ * sq_nxn as bm_pairwise_sqdist_shard(rows, n, d, d_total, ...) would give it.  For ks = h = 20, 1..6 Byzantine copies
+ * and gradients long enough for the burst form, the centred rows are contracted on the matrix cores INSIDE the first
+ * pass, from the registers that hold them: the distance pass never re-reads the n rows (25 of the 115 row passes of
+ * such a step).  The distances then differ from the stand-alone pass by its rounding (another centre, another
+ * order: both within 1e-5 of fp64); everything else has the bits of bm_momentum_stats.  Any other shape runs the two
+ * passes one after the other.  ws: bm_workspace_bytes(BM_WS_STEP); ws_pair: bm_workspace_bytes(BM_WS_PAIRWISE, n, d).
+ * attack_kind without BM_ATTACK_DIRECTION. */
+int bm_momentum_stats_sqdist(const float* const* sampled, int ks, float* const* buffers, int h, int64_t d,
+                             int64_t d_total, float mu, float one_minus_damp, const float* clip_factors,
+                             float* sampled_avg, float* honest_avg, float* byz_out, float scale, int attack_kind,
+                             int n_byz, double* sq_nxn, double* out6, void* ws, void* ws_pair, void* stream);
+
 /* out[i] = b * q[i] + a * (p_scale[i] * p[i]) for k vectors (p_scale: DEVICE array of k floats or NULL;
  * entries of q may be one shared vector; out[i] may alias p[i]).  Every momentum placement of the loop:
  * worker (attack.py:800-804), server (:805-808), update (:838-839), Nesterov look-ahead (:762,767). */
@@ -252,6 +266,14 @@ int bm_sharded_krum(bm_comm* comm, const float* const* rows, int n, int64_t d_lo
                     float* out_local, int32_t* order_out, void* ws, void* stream);
 int bm_sharded_bulyan(bm_comm* comm, const float* const* rows, int n, int64_t d_local, int f, int m,
                       float* out_local, int32_t* order_out, void* ws, void* stream);
+
+/* The tail of bm_sharded_krum / bm_sharded_bulyan (all-reduce -> rank -> selected mean / pass 2) when the squared
+ * distances of the local shard are already in the workspace: bm_momentum_stats_sqdist wrote them to
+ * bm_sharded_sq_slot(ws), using bm_sharded_pair_workspace(ws) as its ws_pair.  rule: BM_RULE_KRUM or BM_RULE_BULYAN. */
+double* bm_sharded_sq_slot(void* ws);
+void* bm_sharded_pair_workspace(void* ws);
+int bm_sharded_rule_from_sq(bm_comm* comm, int rule, const float* const* rows, int n, int64_t d_local, int f, int m,
+                            float* out_local, int32_t* order_out, void* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * One simulation step with worker-side momentum (attack.py:786-868) as ONE call on the caller's stream:

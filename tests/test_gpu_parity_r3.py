@@ -448,3 +448,78 @@ def test_first_pass_with_the_rule_riding_along(bm):
       assert same_bits(d1, d2), tag
       a, b = o1.tolist(), o2.tolist()
       assert all(x == y or (math.isnan(x) and math.isnan(y)) for x, y in zip(a, b)), (tag, a, b)
+
+
+@pytest.mark.parametrize("d", [D_WRN, 4300800 + 2])
+def test_first_pass_with_the_distance_pass_riding_along(bm, d):
+  """bm_momentum_stats_sqdist at sizes where the fused kernel runs (ks = h = 20, 5 Byzantine copies; the second size
+  has a two-column tail): buffers, averages, Byzantine vector and statistics with the bits of bm_momentum_stats, the
+  25 x 25 squared distances within 1e-5 (relative to themselves) of fp64 direct differences on the same GPU, exact zeros
+  among the Byzantine copies and bitwise-equal rows for them, selections of Krum and Bulyan equal to the stand-alone
+  pass; with and without clipping factors, both attacks."""
+  h, nb = 20, 5
+  n = h + nb
+  gen = torch.Generator(device=DEV).manual_seed(23)
+  drift = 0.1 * torch.randn(d, device=DEV, generator=gen)
+  sampled = [drift + s * torch.randn(d, device=DEV, generator=gen) for s in torch.linspace(0.5, 1.5, h).tolist()]
+  bufs = [0.3 * drift + 0.05 * torch.randn(d, device=DEV, generator=gen) for _ in range(h)]
+  factors = torch.ones(64, device=DEV)
+  factors[1], factors[h - 1] = 0.5, 0.25
+  for attack, scale, clip in (("empire", 1.1, None), ("little", -1.5, factors)):
+    b1 = [b.clone() for b in bufs]
+    b2 = [b.clone() for b in bufs]
+    s1, h1, z1, sq, o1 = bm.stats.momentum_stats_sqdist(sampled, b1, 0.99, 0.01, clip, scale, attack, nb)
+    s2, h2, z2, o2 = bm.stats.momentum_stats(sampled, b2, 0.99, 0.01, clip, scale, attack)
+    for x, y in zip(b1, b2):
+      assert torch.equal(x, y)
+    assert torch.equal(s1, s2) and torch.equal(h1, h2) and torch.equal(z1, z2)
+    assert o1.tolist() == o2.tolist()
+    rows = b2 + [z2] * nb
+    got = sq.cpu().numpy()
+    want = sqdist_f64_on_gpu(rows)
+    assert np.array_equal(got, got.T) and not got.diagonal().any()
+    pos = want > 0
+    assert not got[~pos].any()
+    rel = np.abs(got - want)[pos] / want[pos]
+    assert rel.max() <= 1e-5, (attack, d, rel.max())
+    for a in range(h + 1, n):
+      assert np.array_equal(got[h, :h], got[a, :h])
+    ref = bm.gars.pairwise_sqdist(rows).cpu().numpy()
+    for f in (5,):
+      scores = O.krum_scores(np.sqrt(got), f)
+      scores_ref = O.krum_scores(np.sqrt(ref), f)
+      m = n - f - 2
+      assert sorted(O._stable_order(scores)[:m]) == sorted(O._stable_order(scores_ref)[:m])
+    del rows, want
+
+
+@pytest.mark.parametrize("gar", ["krum", "bulyan", "median", "trmean"])
+def test_step_with_the_rule_fed_from_the_first_pass(bm, gar):
+  """n = 25, f = 5, d = 4 300 802 (the fused kernels run: 20 honest workers, long enough for the burst form, a
+  two-column tail): the single-call step and the kernel-by-kernel sequence give the same bits, and both match the
+  independent loop of tests/step_reference.py (oracle arithmetic on the CPU) over three steps."""
+  from byzantinemomentum_amd.step import AggregationStep
+  from tests.step_reference import ReferenceLoop, assert_floats_close
+  n, f, d = 25, 5, 4300802
+  h = n - f
+  kw = dict(gar=gar, momentum=0.9, dampening=0.9, attack="empire", attack_factor=1.1, nb_past=2)
+  one = AggregationStep(n, f, f, single_call=True, **kw)
+  seq = AggregationStep(n, f, f, single_call=False, **kw)
+  ref = ReferenceLoop(n, f, f, gar, "worker", 0.9, 0.9, "empire", 1.1, None, 2)
+  gen = torch.Generator().manual_seed(5)
+  drift = 0.2 * torch.randn(d, generator=gen)
+  for it in range(3):
+    sampled = [drift + (0.5 + 0.05 * i) * torch.randn(d, generator=gen) for i in range(h)]
+    want_def, want_upd, want = ref.step(sampled)
+    dev = [g.to(DEV) for g in sampled]
+    a = one.run([g.clone() for g in dev])
+    b = seq.run([g.clone() for g in dev])
+    assert torch.equal(a, b), (gar, it)
+    for x, y in zip(one.buffers, seq.buffers):
+      assert torch.equal(x, y)
+    fa, fb = one.floats(), seq.floats()
+    for key in fb:
+      assert fa[key] == fb[key] or (math.isnan(fa[key]) and math.isnan(fb[key])), (gar, it, key)
+    scale = float(torch.stack(sampled).abs().max())
+    assert float((a.cpu() - want_def).abs().max()) <= 4e-6 * scale, (gar, it)
+    assert_floats_close(fa, want, tag=(gar, it), tol=1e-5)
