@@ -526,13 +526,15 @@ def step_algorithmic_bytes(d, n, f, gar):
   """4-byte units of d per step as THIS implementation moves them (lists the
   reference's 103 + rule + 3 + 29): fused first pass = sampled + buffers read, buffers written, three
   d-vectors written (ks + 2h + 3 = 63); the rule — for the median / trimmed mean it rides along with the first pass on
-  the values that pass holds in registers and costs its output vector only (1), for Krum / Bulyan the distance pass
-  over n rows and the average of m (+ 1 written); the study block in one pass (bm_study_stats): sampled avg, honest
+  the values that pass holds in registers and costs its output vector only (1); for Krum / Bulyan the distance pass
+  rides along (no byte of its own) and the average of the m selected rows / pass 2 remains (m + 1); the study block in one pass (bm_study_stats): sampled avg, honest
   avg, defense, Byzantine vector, newest past, curvature combination C and the past average that leaves the deque
   read, C written (8) — round 2 spent 15 there (attack stats 2, defense stats 1, dots 6, two passes of 3 over C)."""
   h = n - f
   m = n - f - 2
-  gar_units = {"krum": n + m + 1, "bulyan": n + m + 1, "median": 1, "trmean": 1}.get(gar, n + 1)
+  # Krum / Bulyan: the distance pass rides along with the first pass too (the rows are contracted from its registers);
+  # what is left of the rule is the average of the m selected rows / pass 2 over the m ranked rows, + 1 written
+  gar_units = {"krum": m + 1, "bulyan": m + 1, "median": 1, "trmean": 1}.get(gar, n + 1)
   return 4 * d * ((h + 2 * h + 3) + gar_units + 8)
 
 

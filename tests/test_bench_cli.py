@@ -64,6 +64,6 @@ def test_step_byte_model():
   bench = load_bench()
   d, n, f = 1000, 25, 5
   h, m = 20, 18
-  assert bench.step_algorithmic_bytes(d, n, f, "krum") == 4 * d * ((3 * h + 3) + (n + m + 1) + 8)
+  assert bench.step_algorithmic_bytes(d, n, f, "krum") == 4 * d * ((3 * h + 3) + (m + 1) + 8)  # the distance pass rides along
   assert bench.step_algorithmic_bytes(d, n, f, "median") == 4 * d * ((3 * h + 3) + 1 + 8)  # the rule rides along
   assert bench.entry(2.0, 4_000_000_000)["gbps"] == pytest.approx(2000.0)
