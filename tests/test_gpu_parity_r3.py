@@ -491,6 +491,26 @@ def test_first_pass_with_the_distance_pass_riding_along(bm, d):
       m = n - f - 2
       assert sorted(O._stable_order(scores)[:m]) == sorted(O._stable_order(scores_ref)[:m])
     del rows, want
+  if d != D_WRN:  # non-finite coordinates: the rows that hold them are at non-finite distance of everything (krum.py:46-47
+    # turns that into +inf), every other distance is untouched — as in the stand-alone pass
+    sampled[3][17] = float("nan")
+    bufs[2][4000000] = float("inf")
+    b1 = [b.clone() for b in bufs]
+    s1, h1, z1, sq, o1 = bm.stats.momentum_stats_sqdist(sampled, b1, 0.99, 0.01, None, 1.1, "empire", nb)
+    got = sq.cpu().numpy()
+    rows = b1 + [z1] * nb
+    ref = bm.gars.pairwise_sqdist(rows).cpu().numpy()
+    bad_rows = [2, 3] + list(range(h, n))  # the Byzantine vector inherits both through the honest average
+    ok = [i for i in range(n) if i not in bad_rows]
+    for i in range(n):
+      for j in range(n):
+        if i == j:
+          continue
+        if i in ok and j in ok:
+          assert math.isfinite(got[i, j]) and abs(got[i, j] - ref[i, j]) <= 1e-5 * ref[i, j], (i, j, got[i, j], ref[i, j])
+        elif not (i >= h and j >= h):
+          assert not math.isfinite(got[i, j]) or not math.isfinite(ref[i, j]) or abs(got[i, j] - ref[i, j]) <= 1e-5 * ref[i, j], (i, j)
+    assert bm.gars.krum_selection(rows, 5) is not None
 
 
 @pytest.mark.parametrize("gar", ["krum", "bulyan", "median", "trmean"])
