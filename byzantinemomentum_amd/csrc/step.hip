@@ -222,35 +222,42 @@ __global__ __launch_bounds__(BURST ? kStepBurstBlock : kStepBlock) void momentum
 // Everything else (momentum, statistics, averages, Byzantine vector, stores) is momentum_stats_kernel<20, 4, true, CLIP, true>
 // operation for operation: same bits.
 // ---------------------------------------------------------------------------------------------------
-constexpr int kSgT = 20;                     // honest rows
-constexpr int kSgRows = 32;                  // LDS rows per plane (two 16-row blocks)
 constexpr int kSgRowBytes = 272;             // 128 coordinates x 2 B + 16 B of padding
-constexpr int kSgPlaneBytes = kSgRows * kSgRowBytes;
-constexpr int kSgWaveBytes = 2 * kSgPlaneBytes;
 constexpr int kSgWaves = kStepBurstBlock / 64;
-constexpr int kSgLds = kSgWaves * kSgWaveBytes;  // 139 264 B (the final reduction aliases it)
-constexpr int kSgN = kSgT + 1;                   // rows of the compact Gram
+template <int TT>
+struct SgShape {                             // TT honest rows (20: n = 25, f = 5; 14: n = 25, f = 11)
+  static constexpr int N = TT + 1;           // rows of the compact Gram: the buffers and ONE Byzantine row
+  static constexpr int RB = (N + 15) / 16;   // 16-row blocks
+  static constexpr int NP = RB * (RB + 1) / 2;
+  static constexpr int kRows = 16 * RB;      // LDS rows per plane
+  static constexpr int kPlaneBytes = kRows * kSgRowBytes;
+  static constexpr int kWaveBytes = 2 * kPlaneBytes;
+  static constexpr int kRedBytes = kSgWaves * 256 * 8;  // the final reduction aliases the planes
+  static constexpr int kLds = kSgWaves * kWaveBytes > kRedBytes ? kSgWaves * kWaveBytes : kRedBytes;  // 139 264 B at TT = 20
+};
 
-template <bool CLIP>
+template <int TT, bool CLIP>
 __global__ __launch_bounds__(kStepBurstBlock) void momentum_gram_kernel(
     StepTable tab, uint32_t nvec, float mu, float omd, const float* __restrict__ clipf, float* __restrict__ s_avg_out,
     float* __restrict__ h_avg_out, float* __restrict__ byz_out, float scale, int attack_kind, unsigned dither_seed,
     double* __restrict__ partial, double* __restrict__ gram_partial, int* __restrict__ arrival) {
-  constexpr int T = kSgT, VEC = 4, BLOCK = kStepBurstBlock;
+  using SG = SgShape<TT>;
+  constexpr int T = TT, VEC = 4, BLOCK = kStepBurstBlock;
+  constexpr int kSgPlaneBytes = SG::kPlaneBytes, kSgWaveBytes = SG::kWaveBytes, kSgN = SG::N, RB = SG::RB, NP = SG::NP;
   extern __shared__ __attribute__((aligned(16))) char sg_smem[];
   __shared__ double red[BLOCK / 64];
   __shared__ float mred[BLOCK / 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   char* wbase = sg_smem + wave * kSgWaveBytes;
-  // zero this wave's planes once (rows 21..31 are never written again)
+  // zero this wave's planes once (the rows past the Byzantine one are never written again)
   for (int o = lane * 16; o < kSgWaveBytes; o += 64 * 16) *reinterpret_cast<f32x4*>(wbase + o) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   if (blockIdx.x == 0 && tid == 0 && arrival != nullptr) *arrival = 0;  // see gram_reduce_sqdist_kernel
   const float fks = (float)T, fh = (float)T;
   float n2s = 0.0f, dvs = 0.0f, mxs = 0.0f, n2h = 0.0f, dvh = 0.0f, mxh = 0.0f;
   bool nan_s = false, nan_h = false;
-  float outer[3][4];
+  float outer[NP][4];
 #pragma unroll
-  for (int p = 0; p < 3; ++p)
+  for (int p = 0; p < NP; ++p)
 #pragma unroll
     for (int v = 0; v < 4; ++v) outer[p][v] = 0.0f;
   uint64_t kbase = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
@@ -359,9 +366,9 @@ __global__ __launch_bounds__(kStepBurstBlock) void momentum_gram_kernel(
         const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
         int p = 0;
 #pragma unroll
-        for (int I = 0; I < 2; ++I)
+        for (int I = 0; I < RB; ++I)
 #pragma unroll
-          for (int J = I; J < 2; ++J) {
+          for (int J = I; J < RB; ++J) {
             f32x4 s0 = zero, s1 = zero, s2 = zero, s3 = zero;
 #pragma unroll
             for (int sl = 0; sl < 4; ++sl) {
@@ -419,9 +426,9 @@ __global__ __launch_bounds__(kStepBurstBlock) void momentum_gram_kernel(
   __syncthreads();
   int p = 0;
 #pragma unroll
-  for (int I = 0; I < 2; ++I)
+  for (int I = 0; I < RB; ++I)
 #pragma unroll
-    for (int J = I; J < 2; ++J) {
+    for (int J = I; J < RB; ++J) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) gred[wave * 256 + (4 * lg + q) * 16 + li] = (double)outer[p][q];
       __syncthreads();
@@ -688,7 +695,7 @@ static int launch_momentum_stats_stream(const StepTable& tab, int ks, int h, int
 }
 
 // Forms by (ks, h): the register-resident kernel holds 2 * T * VEC values per lane; without row predicates (ks == h == T,
-// T = 8, 12, 20) it fits two waves per SIMD up to T = 20, with them up to T = 12; every other shape takes the streaming
+// T = 8, 12, 14, 20) it fits two waves per SIMD up to T = 20, with them up to T = 12; every other shape takes the streaming
 // form, whose footprint does not depend on the number of rows.
 template <int VEC>
 static int dispatch_momentum_stats(const StepTable& tab, int ks, int h, int64_t nvec, float mu, float omd,
@@ -700,7 +707,8 @@ static int dispatch_momentum_stats(const StepTable& tab, int ks, int h, int64_t 
   if (tuning().step_stream != 1) {
     if (t <= 8) return launch_momentum_stats<8, VEC>(BM_STEP_ARGS);
     if (t <= 12) return launch_momentum_stats<12, VEC>(BM_STEP_ARGS);
-    if (ks == 20 && h == 20) return launch_momentum_stats<20, VEC>(BM_STEP_ARGS);
+    if (ks == 14 && h == 14) return launch_momentum_stats<14, VEC>(BM_STEP_ARGS);  // n = 25, f = 11 (reproduce.py:181)
+    if (ks == 20 && h == 20) return launch_momentum_stats<20, VEC>(BM_STEP_ARGS);  // n = 25, f = 5
   }
   if (t <= 20) return launch_momentum_stats_stream<20, VEC>(BM_STEP_ARGS);
   if (t <= 40) return launch_momentum_stats_stream<40, VEC>(BM_STEP_ARGS);
@@ -777,72 +785,71 @@ __global__ __launch_bounds__(64) void clip_factors_kernel(const double* __restri
 // First pass + coordinate-wise rule in one kernel (median / trimmed mean over the h = 20 updated buffers and 1..6
 // copies of the Byzantine vector: the C5 shape and its neighbours).  Returns false when no instance fits.
 // ---------------------------------------------------------------------------
-constexpr int kFusedT = 20;
-template <int RULE, int NB, bool CLIP>
+template <int T, int RULE, int NB, bool CLIP>
 static void launch_fused_rule(const StepTable& tab, int64_t nvec, float mu, float omd, const float* clipf, float* s_avg,
                               float* h_avg, float* byz, float scale, int kind, double* partial, int rule_f,
                               float* defense, int* grid_io, hipStream_t s) {
-  constexpr int N = kFusedT + NB;
+  constexpr int N = T + NB;
   const int keep = (RULE == BM_OP_TRMEAN) ? (N - 2 * rule_f) : N;
   const float inv_keep = 1.0f / (float)(keep > 0 ? keep : 1);
   const int cus = compute_units();
   const int64_t burst_iters = nvec / ((int64_t)cus * kStepBurstBlock);
   if (tuning().step_burst > 0 && burst_iters >= tuning().step_burst && cus < *grid_io) {
     *grid_io = cus;
-    hipLaunchKernelGGL((momentum_stats_kernel<kFusedT, 4, true, CLIP, true, RULE, NB>), dim3(cus), dim3(kStepBurstBlock), 0,
-                       s, tab, kFusedT, kFusedT, (uint32_t)nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial,
+    hipLaunchKernelGGL((momentum_stats_kernel<T, 4, true, CLIP, true, RULE, NB>), dim3(cus), dim3(kStepBurstBlock), 0,
+                       s, tab, T, T, (uint32_t)nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial,
                        rule_f, inv_keep, defense);
   } else {
-    hipLaunchKernelGGL((momentum_stats_kernel<kFusedT, 4, true, CLIP, false, RULE, NB>), dim3(*grid_io), dim3(kStepBlock), 0,
-                       s, tab, kFusedT, kFusedT, (uint32_t)nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial,
+    hipLaunchKernelGGL((momentum_stats_kernel<T, 4, true, CLIP, false, RULE, NB>), dim3(*grid_io), dim3(kStepBlock), 0,
+                       s, tab, T, T, (uint32_t)nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial,
                        rule_f, inv_keep, defense);
   }
 }
 
-template <int RULE, int NB>
+template <int T, int RULE, int NB>
 static void launch_fused_rule_clip(const StepTable& tab, int64_t nvec, float mu, float omd, const float* clipf,
                                    float* s_avg, float* h_avg, float* byz, float scale, int kind, double* partial,
                                    int rule_f, float* defense, int* grid_io, hipStream_t s) {
   if (clipf != nullptr)
-    launch_fused_rule<RULE, NB, true>(tab, nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial, rule_f, defense, grid_io, s);
+    launch_fused_rule<T, RULE, NB, true>(tab, nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial, rule_f, defense, grid_io, s);
   else
-    launch_fused_rule<RULE, NB, false>(tab, nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial, rule_f, defense, grid_io, s);
+    launch_fused_rule<T, RULE, NB, false>(tab, nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial, rule_f, defense, grid_io, s);
 }
 
+// instances: 20 honest rows + 1..6 Byzantine copies (n = 21..26: the reference's n = 25, f = 5) and 14 + 11 (n = 25, f = 11)
 static bool fused_rule_instance(int ks, int h, int nb, int op) {
-  return ks == kFusedT && h == kFusedT && nb >= 1 && nb <= 6 && (op == BM_OP_MEDIAN || op == BM_OP_TRMEAN) &&
-         tuning().step_stream != 1;
+  if ((op != BM_OP_MEDIAN && op != BM_OP_TRMEAN) || tuning().step_stream == 1 || ks != h) return false;
+  return (h == 20 && nb >= 1 && nb <= 6) || (h == 14 && nb == 11);
 }
 
-static int launch_fused_rule_any(int op, int nb, const StepTable& tab, int64_t nvec, float mu, float omd,
+static int launch_fused_rule_any(int op, int h, int nb, const StepTable& tab, int64_t nvec, float mu, float omd,
                                  const float* clipf, float* s_avg, float* h_avg, float* byz, float scale, int kind,
                                  double* partial, int rule_f, float* defense, int* grid_io, hipStream_t s) {
 #define BM_FUSED_ARGS tab, nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial, rule_f, defense, grid_io, s
-#define BM_FUSED_NB(NBV)                                                        \
-  case NBV:                                                                     \
+#define BM_FUSED_CASE(TV, NBV)                                                  \
+  if (h == TV && nb == NBV) {                                                   \
     if (op == BM_OP_MEDIAN)                                                     \
-      launch_fused_rule_clip<BM_OP_MEDIAN, NBV>(BM_FUSED_ARGS);                 \
+      launch_fused_rule_clip<TV, BM_OP_MEDIAN, NBV>(BM_FUSED_ARGS);             \
     else                                                                        \
-      launch_fused_rule_clip<BM_OP_TRMEAN, NBV>(BM_FUSED_ARGS);                 \
-    break;
-  switch (nb) {
-    BM_FUSED_NB(1) BM_FUSED_NB(2) BM_FUSED_NB(3) BM_FUSED_NB(4) BM_FUSED_NB(5) BM_FUSED_NB(6)
-    default: return BM_EINVAL;
+      launch_fused_rule_clip<TV, BM_OP_TRMEAN, NBV>(BM_FUSED_ARGS);             \
+    BM_LAUNCH_CHECK();                                                          \
+    return 0;                                                                   \
   }
-#undef BM_FUSED_NB
+  BM_FUSED_CASE(20, 1) BM_FUSED_CASE(20, 2) BM_FUSED_CASE(20, 3) BM_FUSED_CASE(20, 4) BM_FUSED_CASE(20, 5)
+  BM_FUSED_CASE(20, 6) BM_FUSED_CASE(14, 11)
+#undef BM_FUSED_CASE
 #undef BM_FUSED_ARGS
-  BM_LAUNCH_CHECK();
-  return 0;
+  return BM_EINVAL;
 }
 
 // Gram contribution of the d mod 4 trailing columns (at most 3) of the fused distance pass: one more partial block,
 // in fp64, centred on the honest average like the body.
-__global__ __launch_bounds__(256) void tail_gram_kernel(RowTable rows /* 20 buffers + byz, offset to the tail */,
+__global__ __launch_bounds__(256) void tail_gram_kernel(RowTable rows /* the buffers + byz, offset to the tail */, int nrows,
                                                         const float* __restrict__ h_avg_tail, int cols,
                                                         double* __restrict__ block) {
   const int t = threadIdx.x;
-  if (t >= kSgN * (kSgN + 1) / 2) return;
-  int i = 0, rem = t, len = kSgN;  // t -> (i, j), i <= j, row-major over the upper triangle
+  if (t >= nrows * (nrows + 1) / 2) return;
+  int i = 0, rem = t, len = nrows;  // t -> (i, j), i <= j, row-major over the upper triangle
   while (rem >= len) {
     rem -= len;
     --len;
@@ -854,7 +861,7 @@ __global__ __launch_bounds__(256) void tail_gram_kernel(RowTable rows /* 20 buff
     const float ctr = (__builtin_fabsf(h_avg_tail[c]) < __builtin_inff()) ? h_avg_tail[c] : 0.0f;
     acc += (double)(rows.p[i][c] - ctr) * (double)(rows.p[j][c] - ctr);
   }
-  block[b3_tri_index(i, j, kSgN)] = acc;
+  block[b3_tri_index(i, j, nrows)] = acc;
 }
 
 static inline int vec_of(uintptr_t bits) { return (bits & 15u) == 0 ? 4 : ((bits & 7u) == 0 ? 2 : 1); }
@@ -915,7 +922,7 @@ static int momentum_stats_impl(const float* const* sampled, int ks, float* const
     if (fused) {
       const int64_t nvec = dp / 4;
       int grid = stream_grid(nvec, kStepBlock, cap);
-      rc = launch_fused_rule_any(rule_op, nb, piece, nvec, mu, one_minus_damp, clip_factors, sa, ha, bz, scale,
+      rc = launch_fused_rule_any(rule_op, h, nb, piece, nvec, mu, one_minus_damp, clip_factors, sa, ha, bz, scale,
                                  attack_kind, partial + (int64_t)nparts * 6, rule_f, defense_out + lo, &grid, s);
       if (rc != 0) return rc;
       nparts += grid;
@@ -1009,7 +1016,8 @@ extern "C" int bm_momentum_stats_sqdist(const float* const* sampled, int ks, flo
   for (int i = 0; i < h; ++i) bits |= reinterpret_cast<uintptr_t>(buffers[i]);
   const int cus = compute_units();
   const int64_t nvec = d / 4;
-  const bool fused = ks == kSgT && h == kSgT && n_byz <= 6 && vec_of(bits) == 4 && honest_avg != nullptr &&
+  const bool shape_ok = ks == h && ((h == 20 && n_byz <= 6) || (h == 14 && n_byz == 11));  // n = 25 with f = 5 / 11, and neighbours
+  const bool fused = shape_ok && vec_of(bits) == 4 && honest_avg != nullptr &&
                      d <= kMaxColsPerLaunch && tuning().step_stream != 1 && tuning().pair_mode == 0 &&
                      tuning().pair_planes != 3 && tuning().step_burst > 0 &&
                      nvec / ((int64_t)cus * kStepBurstBlock) >= tuning().step_burst;
@@ -1026,12 +1034,21 @@ extern "C" int bm_momentum_stats_sqdist(const float* const* sampled, int ks, flo
   for (int i = h; i < BM_MAX_ROWS; ++i) tab.b[i] = buffers[h - 1];
   double* partial = static_cast<double*>(ws);
   double* gram_partial = pairwise_gram_area(ws_pair);
-  constexpr int per_block = kSgN * (kSgN + 1) / 2;
-  auto kern = clip_factors != nullptr ? momentum_gram_kernel<true> : momentum_gram_kernel<false>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     kSgLds);
+  const int nc = h + 1;  // rows of the compact Gram
+  const int per_block = nc * (nc + 1) / 2;
+  void (*kern)(StepTable, uint32_t, float, float, const float*, float*, float*, float*, float, int, unsigned, double*,
+               double*, int*);
+  int lds;
+  if (h == 20) {
+    kern = clip_factors != nullptr ? momentum_gram_kernel<20, true> : momentum_gram_kernel<20, false>;
+    lds = SgShape<20>::kLds;
+  } else {
+    kern = clip_factors != nullptr ? momentum_gram_kernel<14, true> : momentum_gram_kernel<14, false>;
+    lds = SgShape<14>::kLds;
+  }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   if (e != hipSuccess) return hip_code(e);
-  hipLaunchKernelGGL(kern, dim3(cus), dim3(kStepBurstBlock), kSgLds, s, tab, (uint32_t)nvec, mu, one_minus_damp,
+  hipLaunchKernelGGL(kern, dim3(cus), dim3(kStepBurstBlock), lds, s, tab, (uint32_t)nvec, mu, one_minus_damp,
                      clip_factors, sampled_avg, honest_avg, byz_out, scale, attack_kind, (unsigned)tuning().pair_dither,
                      partial, gram_partial, pairwise_arrival_counter(ws_pair));
   BM_LAUNCH_CHECK();
@@ -1052,14 +1069,14 @@ extern "C" int bm_momentum_stats_sqdist(const float* const* sampled, int ks, flo
     RowTable trows{};
     for (int i = 0; i < h; ++i) trows.p[i] = buffers[i] + body;
     trows.p[h] = byz_out + body;
-    hipLaunchKernelGGL(tail_gram_kernel, dim3(1), dim3(256), 0, s, trows, honest_avg + body, (int)(d - body),
+    hipLaunchKernelGGL(tail_gram_kernel, dim3(1), dim3(256), 0, s, trows, nc, honest_avg + body, (int)(d - body),
                        gram_partial + (int64_t)blocks * per_block);
     BM_LAUNCH_CHECK();
     blocks += 1;
   }
   hipLaunchKernelGGL(step_finish_kernel, dim3(1), dim3(kFinishThreads), 0, s, partial, nparts, out6);
   BM_LAUNCH_CHECK();
-  return pairwise_from_gram_partials(rows, n, kSgN, blocks, d, sq_nxn, ws_pair, s);
+  return pairwise_from_gram_partials(rows, n, nc, blocks, d, sq_nxn, ws_pair, s);
 }
 
 extern "C" int bm_multi_fma3(float* const* out, const float* const* p, const float* const* q, int k, int64_t d,

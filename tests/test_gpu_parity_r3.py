@@ -422,7 +422,9 @@ def test_first_pass_with_the_rule_riding_along(bm):
            (20, 20, 3, "trmean", 0, 65, 0, False), (20, 20, 5, "median", 0, 40002, 1, False),   # unaligned: fallback
            (21, 20, 5, "median", 0, 10007, 0, False), (12, 12, 3, "trmean", 2, 10007, 0, False),
            (20, 20, 7, "median", 0, 5003, 0, False), (20, 20, 5, "phocas", 5, 20011, 0, False),
-           (20, 20, 5, "meamed", 5, 20011, 0, True)]
+           (20, 20, 5, "meamed", 5, 20011, 0, True),
+           (14, 14, 11, "median", 0, 30011, 0, False), (14, 14, 11, "trmean", 11, 40003, 0, True),   # n = 25, f = 11
+           (14, 14, 10, "median", 0, 5003, 0, False)]                                                  # no instance: fallback
   for ks, h, nb, rule, f, d, off, clip in cases:
     sampled = [torch.randn(d + off, device=DEV, generator=gen)[off:] for _ in range(ks)]
     bufs = [torch.randn(d + off, device=DEV, generator=gen)[off:] for _ in range(h)]
@@ -450,14 +452,14 @@ def test_first_pass_with_the_rule_riding_along(bm):
       assert all(x == y or (math.isnan(x) and math.isnan(y)) for x, y in zip(a, b)), (tag, a, b)
 
 
-@pytest.mark.parametrize("d", [D_WRN, 4300800 + 2])
-def test_first_pass_with_the_distance_pass_riding_along(bm, d):
+@pytest.mark.parametrize("d,h,nb", [(D_WRN, 20, 5), (4300800 + 2, 20, 5), (4300800 + 2, 14, 11), (4300800, 20, 2)])
+def test_first_pass_with_the_distance_pass_riding_along(bm, d, h, nb):
   """bm_momentum_stats_sqdist at sizes where the fused kernel runs (ks = h = 20, 5 Byzantine copies; the second size
   has a two-column tail): buffers, averages, Byzantine vector and statistics with the bits of bm_momentum_stats, the
   25 x 25 squared distances within 1e-5 (relative to themselves) of fp64 direct differences on the same GPU, exact zeros
   among the Byzantine copies and bitwise-equal rows for them, selections of Krum and Bulyan equal to the stand-alone
-  pass; with and without clipping factors, both attacks."""
-  h, nb = 20, 5
+  pass; with and without clipping factors, both attacks.  Shapes: n = 25 with f = 5 and with f = 11 (reproduce.py:181),
+  and 20 + 2."""
   n = h + nb
   gen = torch.Generator(device=DEV).manual_seed(23)
   drift = 0.1 * torch.randn(d, device=DEV, generator=gen)
@@ -485,13 +487,13 @@ def test_first_pass_with_the_distance_pass_riding_along(bm, d):
     for a in range(h + 1, n):
       assert np.array_equal(got[h, :h], got[a, :h])
     ref = bm.gars.pairwise_sqdist(rows).cpu().numpy()
-    for f in (5,):
+    for f in (min(nb, (n - 3) // 2),):
       scores = O.krum_scores(np.sqrt(got), f)
       scores_ref = O.krum_scores(np.sqrt(ref), f)
       m = n - f - 2
       assert sorted(O._stable_order(scores)[:m]) == sorted(O._stable_order(scores_ref)[:m])
     del rows, want
-  if d != D_WRN:  # non-finite coordinates: the rows that hold them are at non-finite distance of everything (krum.py:46-47
+  if d != D_WRN and (h, nb) == (20, 5):  # non-finite coordinates: the rows that hold them are at non-finite distance of everything (krum.py:46-47
     # turns that into +inf), every other distance is untouched — as in the stand-alone pass
     sampled[3][17] = float("nan")
     bufs[2][4000000] = float("inf")
@@ -513,14 +515,14 @@ def test_first_pass_with_the_distance_pass_riding_along(bm, d):
     assert bm.gars.krum_selection(rows, 5) is not None
 
 
-@pytest.mark.parametrize("gar", ["krum", "bulyan", "median", "trmean"])
-def test_step_with_the_rule_fed_from_the_first_pass(bm, gar):
-  """n = 25, f = 5, d = 4 300 802 (the fused kernels run: 20 honest workers, long enough for the burst form, a
+@pytest.mark.parametrize("gar,f", [("krum", 5), ("bulyan", 5), ("median", 5), ("trmean", 5), ("krum", 11), ("trmean", 11)])
+def test_step_with_the_rule_fed_from_the_first_pass(bm, gar, f):
+  """n = 25, f = 5 or 11, d = 4 300 802 (the fused kernels run: 20 / 14 honest workers, long enough for the burst form, a
   two-column tail): the single-call step and the kernel-by-kernel sequence give the same bits, and both match the
   independent loop of tests/step_reference.py (oracle arithmetic on the CPU) over three steps."""
   from byzantinemomentum_amd.step import AggregationStep
   from tests.step_reference import ReferenceLoop, assert_floats_close
-  n, f, d = 25, 5, 4300802
+  n, d = 25, 4300802
   h = n - f
   kw = dict(gar=gar, momentum=0.9, dampening=0.9, attack="empire", attack_factor=1.1, nb_past=2)
   one = AggregationStep(n, f, f, single_call=True, **kw)
