@@ -195,7 +195,7 @@ int bm_momentum_stats(const float* const* sampled, int ks, float* const* buffers
  * defense_out = GAR(honests + [byz] * n_byz, f = rule_f) of attack.py:821 for rule_op = BM_OP_MEDIAN / TRMEAN / PHOCAS /
  * MEAMED (aggregators/median.py:39, trmean.py:33,81-109), with the results of bm_momentum_stats + bm_colwise (same
  * bits).  For the median and the trimmed mean over ks = h = 20 buffers and 1..6 Byzantine copies (n = 21..26: the
- * reference's n = 25, f = 5 among them) the rule runs INSIDE the first pass, on the values it already holds in
+ * reference's n = 25, f = 5 among them), or 14 buffers and 11 copies (its n = 25, f = 11), the rule runs INSIDE the first pass, on the values it already holds in
  * registers: the rule's own pass over the n rows disappears (26 of the 97 row passes of such a step).  Any other
  * shape runs the two kernels one after the other.  byz_out and defense_out must be non-NULL, attack_kind without
  * BM_ATTACK_DIRECTION. */
@@ -206,8 +206,8 @@ int bm_momentum_stats_colwise(const float* const* sampled, int ks, float* const*
 
 /* The same first pass together with the squared distances of the n = h + n_byz rows (the h updated buffers and n_byz
  * copies of byz_out) that Krum / Bulyan / Brute rank next (attack.py:821 with a distance-based rule and worker momentum):
- * sq_nxn as bm_pairwise_sqdist_shard(rows, n, d, d_total, ...) would give it.  For ks = h = 20, 1..6 Byzantine copies
- * and gradients long enough for the burst form, the centred rows are contracted on the matrix cores INSIDE the first
+ * sq_nxn as bm_pairwise_sqdist_shard(rows, n, d, d_total, ...) would give it.  For ks = h = 20 with 1..6 Byzantine
+ * copies (or 14 with 11) and gradients long enough for the burst form, the centred rows are contracted on the matrix cores INSIDE the first
  * pass, from the registers that hold them: the distance pass never re-reads the n rows (25 of the 115 row passes of
  * such a step).  The distances then differ from the stand-alone pass by its rounding (another centre, another
  * order: both within 1e-5 of fp64); everything else has the bits of bm_momentum_stats.  Any other shape runs the two

@@ -515,11 +515,12 @@ def test_first_pass_with_the_distance_pass_riding_along(bm, d, h, nb):
     assert bm.gars.krum_selection(rows, 5) is not None
 
 
-@pytest.mark.parametrize("gar,f", [("krum", 5), ("bulyan", 5), ("median", 5), ("trmean", 5), ("krum", 11), ("trmean", 11)])
+@pytest.mark.parametrize("gar,f", [("krum", 5), ("bulyan", 5), ("median", 5), ("krum", 11), ("trmean", 11)])
 def test_step_with_the_rule_fed_from_the_first_pass(bm, gar, f):
   """n = 25, f = 5 or 11, d = 4 300 802 (the fused kernels run: 20 / 14 honest workers, long enough for the burst form, a
   two-column tail): the single-call step and the kernel-by-kernel sequence give the same bits, and both match the
-  independent loop of tests/step_reference.py (oracle arithmetic on the CPU) over three steps."""
+  independent loop of tests/step_reference.py (oracle arithmetic on the CPU) over two steps (the second with a
+  non-zero momentum buffer and a past average)."""
   from byzantinemomentum_amd.step import AggregationStep
   from tests.step_reference import ReferenceLoop, assert_floats_close
   n, d = 25, 4300802
@@ -530,7 +531,7 @@ def test_step_with_the_rule_fed_from_the_first_pass(bm, gar, f):
   ref = ReferenceLoop(n, f, f, gar, "worker", 0.9, 0.9, "empire", 1.1, None, 2)
   gen = torch.Generator().manual_seed(5)
   drift = 0.2 * torch.randn(d, generator=gen)
-  for it in range(3):
+  for it in range(2):
     sampled = [drift + (0.5 + 0.05 * i) * torch.randn(d, generator=gen) for i in range(h)]
     want_def, want_upd, want = ref.step(sampled)
     dev = [g.to(DEV) for g in sampled]
