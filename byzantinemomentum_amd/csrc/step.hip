@@ -229,11 +229,14 @@ struct SgShape {                             // TT honest rows (20: n = 25, f = 
   static constexpr int N = TT + 1;           // rows of the compact Gram: the buffers and ONE Byzantine row
   static constexpr int RB = (N + 15) / 16;   // 16-row blocks
   static constexpr int NP = RB * (RB + 1) / 2;
-  static constexpr int kRows = 16 * RB;      // LDS rows per plane
+  static constexpr int kRows = N + 1;         // LDS rows per plane: the N rows and one row of zeros that stands for
+                                             // rows N .. 16 RB - 1 of the last block (never written, read as zeros)
   static constexpr int kPlaneBytes = kRows * kSgRowBytes;
   static constexpr int kWaveBytes = 2 * kPlaneBytes;
-  static constexpr int kRedBytes = kSgWaves * 256 * 8;  // the final reduction aliases the planes
-  static constexpr int kLds = kSgWaves * kWaveBytes > kRedBytes ? kSgWaves * kWaveBytes : kRedBytes;  // 139 264 B at TT = 20
+  static constexpr int kAccBytes = NP * 4 * kStepBurstBlock * 4;  // the running sums of the Gram, [NP * 4][512 lanes] floats
+  static constexpr int kRedBytes = kSgWaves * 256 * 8;            // the final reduction aliases the planes
+  static constexpr int kPlanes = kSgWaves * kWaveBytes > kRedBytes ? kSgWaves * kWaveBytes : kRedBytes;
+  static constexpr int kLds = kPlanes + kAccBytes;                // 95 744 + 24 576 B at TT = 20
 };
 
 template <int TT, bool CLIP>
@@ -255,11 +258,11 @@ __global__ __launch_bounds__(kStepBurstBlock) void momentum_gram_kernel(
   const float fks = (float)T, fh = (float)T;
   float n2s = 0.0f, dvs = 0.0f, mxs = 0.0f, n2h = 0.0f, dvh = 0.0f, mxh = 0.0f;
   bool nan_s = false, nan_h = false;
-  float outer[NP][4];
+  // the running sums of the Gram live in LDS ([NP * 4][512] floats, one column per lane: conflict-free), not in 4 NP
+  // registers that would be carried through the first half of the loop body, where the 40 loads are in flight
+  float* acc_lds = reinterpret_cast<float*>(sg_smem + SG::kPlanes) + tid;
 #pragma unroll
-  for (int p = 0; p < NP; ++p)
-#pragma unroll
-    for (int v = 0; v < 4; ++v) outer[p][v] = 0.0f;
+  for (int p = 0; p < NP * 4; ++p) acc_lds[p * BLOCK] = 0.0f;
   uint64_t kbase = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
   (void)tab;
   const uint32_t span = gridDim.x * BLOCK;
@@ -268,6 +271,8 @@ __global__ __launch_bounds__(kStepBurstBlock) void momentum_gram_kernel(
   // fragment read addresses: lane (i = l & 15, g = l >> 4) reads row 16 R + i, 8 consecutive coordinates 32 s + 8 g
   const int li = lane & 15, lg = lane >> 4;
   const int rd0 = li * kSgRowBytes + lg * 16;
+  // last block: rows N .. 16 RB - 1 are the one row of zeros at index N
+  const int rd_last = ((16 * (RB - 1) + li < kSgN) ? (16 * (RB - 1) + li) : kSgN) * kSgRowBytes + lg * 16;
   const int wr0 = (lane & 31) * 8;  // this lane's 4 coordinates of its half: 8 B per plane and row
   for (uint32_t it = 0; it < iters; ++it) {
     const uint32_t v = it * span + first;
@@ -372,7 +377,8 @@ __global__ __launch_bounds__(kStepBurstBlock) void momentum_gram_kernel(
             f32x4 s0 = zero, s1 = zero, s2 = zero, s3 = zero;
 #pragma unroll
             for (int sl = 0; sl < 4; ++sl) {
-              const int oi = rd0 + I * 16 * kSgRowBytes + sl * 64, oj = rd0 + J * 16 * kSgRowBytes + sl * 64;
+              const int oi = (I == RB - 1 ? rd_last : rd0 + I * 16 * kSgRowBytes) + sl * 64;
+              const int oj = (J == RB - 1 ? rd_last : rd0 + J * 16 * kSgRowBytes) + sl * 64;
               const u32x4 fhi = *reinterpret_cast<const u32x4*>(wbase + oi);
               const u32x4 fmi = *reinterpret_cast<const u32x4*>(wbase + kSgPlaneBytes + oi);
               const u32x4 fhj = (I == J) ? fhi : *reinterpret_cast<const u32x4*>(wbase + oj);
@@ -384,7 +390,10 @@ __global__ __launch_bounds__(kStepBurstBlock) void momentum_gram_kernel(
             }
             const f32x4 t4 = s0 + ((s1 + s2) + s3);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) outer[p][q] = outer[p][q] + __builtin_fmaf(outer[p][q], rc, t4[q]);
+            for (int q = 0; q < 4; ++q) {
+              const float o = acc_lds[(p * 4 + q) * BLOCK];
+              acc_lds[(p * 4 + q) * BLOCK] = o + __builtin_fmaf(o, rc, t4[q]);
+            }
             ++p;
           }
         __builtin_amdgcn_wave_barrier();
@@ -423,6 +432,11 @@ __global__ __launch_bounds__(kStepBurstBlock) void momentum_gram_kernel(
   // C/D layout of the 16x16 MFMA: lane l, register v -> row 4*(l>>4)+v, column l&15.
   double* gred = reinterpret_cast<double*>(sg_smem);  // [waves][256], aliases the planes
   constexpr int per_block = kSgN * (kSgN + 1) / 2;
+  float outer[NP][4];
+#pragma unroll
+  for (int pp = 0; pp < NP; ++pp)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) outer[pp][q] = acc_lds[(pp * 4 + q) * BLOCK];
   __syncthreads();
   int p = 0;
 #pragma unroll
