@@ -41,8 +41,8 @@ __device__ __forceinline__ float trimmed_sum(const float (&x)[N], int f) {
 }
 
 // Per-column rule on N register-resident values.  `lds` points at this lane's slot of a
-// [N][kColBlock] scratch array (only used by the closest-to-centre rules).
-template <int N, int OP>
+// [N][STRIDE] scratch array, STRIDE = lanes of the workgroup (only used by the closest-to-centre rules).
+template <int N, int OP, int STRIDE = kColBlock>
 __device__ __forceinline__ float column_rule(float (&x)[N], int f, float inv_keep, float* lds) {
   const float kNaN = __builtin_nanf("");
   const float kInf = __builtin_inff();
@@ -86,17 +86,17 @@ __device__ __forceinline__ float column_rule(float (&x)[N], int f, float inv_kee
       }
       const int m = N - f;
 #pragma unroll
-      for (int i = 0; i < N; ++i) lds[i * kColBlock] = x[i];
+      for (int i = 0; i < N; ++i) lds[i * STRIDE] = x[i];
       // "t is farther than t+m" forces the window to start after t; the last such t decides
       // (with duplicated values the predicate is not monotone, so take the max, not the count).
       int s = 0;
       for (int t = 0; t < f; ++t) {
-        const float dl = __builtin_fabsf(lds[t * kColBlock] - c);
-        const float dh = __builtin_fabsf(lds[(t + m) * kColBlock] - c);
+        const float dl = __builtin_fabsf(lds[t * STRIDE] - c);
+        const float dh = __builtin_fabsf(lds[(t + m) * STRIDE] - c);
         s = (dl > dh) ? (t + 1) : s;
       }
       float wsum = 0.0f;
-      for (int i = 0; i < m; ++i) wsum += lds[(s + i) * kColBlock];
+      for (int i = 0; i < m; ++i) wsum += lds[(s + i) * STRIDE];
       const float r = div_small_int(wsum, (float)m, inv_keep);
       return (c != c || nan_count > f) ? kNaN : r;
     }

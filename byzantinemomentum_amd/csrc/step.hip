@@ -61,7 +61,7 @@ __device__ __forceinline__ float block_reduce_absmax(float m, float* lds) {
 // (saddr form, no 64-bit VALU arithmetic).  The 2T row pointers are NOT kept in SGPRs across the loop (80 of them
 // at T = 20: round 2's kernel spilled 322 SGPRs to VGPR lanes): each use fetches its pointer from the kernarg
 // segment with a scalar load behind an opaque copy of the segment address, so nothing is hoisted.
-//   RULE   -1, or BM_OP_MEDIAN / BM_OP_TRMEAN: the coordinate-wise rule over the T updated buffers and NB copies of the
+//   RULE   -1, or BM_OP_MEDIAN / TRMEAN / PHOCAS / MEAMED: the coordinate-wise rule over the T updated buffers and NB copies of the
 //          Byzantine vector (attack.py:821 with a coordinate-wise GAR) is applied to the values this pass already
 //          holds in registers and written to defense_out: the rule's own pass over the n rows (n + 1 of the 97 row
 //          passes of a C5 step with the median) disappears.  Same network, same operations, same bits as bm_colwise.
@@ -77,6 +77,9 @@ __global__ __launch_bounds__(BURST ? kStepBurstBlock : kStepBlock) void momentum
   constexpr int BLOCK = BURST ? kStepBurstBlock : kStepBlock;
   __shared__ double red[BLOCK / 64];
   __shared__ float mred[BLOCK / 64];
+  // the closest-to-centre rules search their window in a per-lane LDS column ([T + NB][BLOCK] floats: 51 KB at 512 lanes)
+  constexpr bool kRuleLds = (RULE == BM_OP_PHOCAS || RULE == BM_OP_MEAMED);
+  __shared__ float rule_scratch[kRuleLds ? (T + NB) * BLOCK : 1];
   const float fks = (float)(EXACT ? T : ks_rt), fh = (float)(EXACT ? T : h_rt);
   float n2s = 0.0f, dvs = 0.0f, mxs = 0.0f, n2h = 0.0f, dvh = 0.0f, mxh = 0.0f;
   bool nan_s = false, nan_h = false;
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(BURST ? kStepBurstBlock : kStepBlock) void momentum
           for (int i = 0; i < T; ++i) x[i] = b[i][c];
 #pragma unroll
           for (int i = 0; i < NB; ++i) x[T + i] = bz[c];
-          df[c] = column_rule<T + NB, RULE>(x, rule_f, rule_inv_keep, nullptr);
+          df[c] = column_rule<T + NB, RULE, BLOCK>(x, rule_f, rule_inv_keep, rule_scratch + (kRuleLds ? threadIdx.x : 0));
         }
       }
     }
@@ -804,7 +807,7 @@ static void launch_fused_rule(const StepTable& tab, int64_t nvec, float mu, floa
                               float* h_avg, float* byz, float scale, int kind, double* partial, int rule_f,
                               float* defense, int* grid_io, hipStream_t s) {
   constexpr int N = T + NB;
-  const int keep = (RULE == BM_OP_TRMEAN) ? (N - 2 * rule_f) : N;
+  const int keep = (RULE == BM_OP_TRMEAN) ? (N - 2 * rule_f) : ((RULE == BM_OP_PHOCAS || RULE == BM_OP_MEAMED) ? (N - rule_f) : N);
   const float inv_keep = 1.0f / (float)(keep > 0 ? keep : 1);
   const int cus = compute_units();
   const int64_t burst_iters = nvec / ((int64_t)cus * kStepBurstBlock);
@@ -832,7 +835,9 @@ static void launch_fused_rule_clip(const StepTable& tab, int64_t nvec, float mu,
 
 // instances: 20 honest rows + 1..6 Byzantine copies (n = 21..26: the reference's n = 25, f = 5) and 14 + 11 (n = 25, f = 11)
 static bool fused_rule_instance(int ks, int h, int nb, int op) {
-  if ((op != BM_OP_MEDIAN && op != BM_OP_TRMEAN) || tuning().step_stream == 1 || ks != h) return false;
+  if ((op != BM_OP_MEDIAN && op != BM_OP_TRMEAN && op != BM_OP_PHOCAS && op != BM_OP_MEAMED) || tuning().step_stream == 1 ||
+      ks != h)
+    return false;
   return (h == 20 && nb >= 1 && nb <= 6) || (h == 14 && nb == 11);
 }
 
@@ -844,8 +849,12 @@ static int launch_fused_rule_any(int op, int h, int nb, const StepTable& tab, in
   if (h == TV && nb == NBV) {                                                   \
     if (op == BM_OP_MEDIAN)                                                     \
       launch_fused_rule_clip<TV, BM_OP_MEDIAN, NBV>(BM_FUSED_ARGS);             \
-    else                                                                        \
+    else if (op == BM_OP_TRMEAN)                                                \
       launch_fused_rule_clip<TV, BM_OP_TRMEAN, NBV>(BM_FUSED_ARGS);             \
+    else if (op == BM_OP_PHOCAS)                                                \
+      launch_fused_rule_clip<TV, BM_OP_PHOCAS, NBV>(BM_FUSED_ARGS);             \
+    else                                                                        \
+      launch_fused_rule_clip<TV, BM_OP_MEAMED, NBV>(BM_FUSED_ARGS);             \
     BM_LAUNCH_CHECK();                                                          \
     return 0;                                                                   \
   }

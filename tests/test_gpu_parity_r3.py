@@ -413,9 +413,9 @@ def test_rows_from_the_package_allocator(bm):
 def test_first_pass_with_the_rule_riding_along(bm):
   """bm_momentum_stats_colwise against bm_momentum_stats + bm_colwise on clones: same bits in the buffers, the two
   averages, the Byzantine vector, the six statistics and the aggregated vector — for the shapes with a fused
-  instance (ks = h = 20, 1..6 Byzantine copies, median / trmean, with and without clipping factors, NaN / inf
-  columns, ragged tails) and for shapes that fall back to the two kernels (other row counts, phocas / meamed,
-  unaligned views)."""
+  instance (ks = h = 20 with 1..6 Byzantine copies or 14 with 11; median / trmean / phocas / meamed, with and without
+  clipping factors, NaN / inf columns, ragged tails) and for shapes that fall back to the two kernels (other row
+  counts, unaligned views)."""
   gen = torch.Generator(device=DEV).manual_seed(17)
   cases = [(20, 20, 5, "median", 0, 30011, 0, False), (20, 20, 5, "trmean", 5, 30011, 0, True),
            (20, 20, 1, "trmean", 3, 4099, 0, False), (20, 20, 6, "median", 0, 1 << 20, 0, True),
@@ -424,6 +424,8 @@ def test_first_pass_with_the_rule_riding_along(bm):
            (20, 20, 7, "median", 0, 5003, 0, False), (20, 20, 5, "phocas", 5, 20011, 0, False),
            (20, 20, 5, "meamed", 5, 20011, 0, True),
            (14, 14, 11, "median", 0, 30011, 0, False), (14, 14, 11, "trmean", 11, 40003, 0, True),   # n = 25, f = 11
+           (14, 14, 11, "phocas", 11, 30011, 0, False), (14, 14, 11, "meamed", 11, 1 << 20, 0, True),
+           (20, 20, 5, "phocas", 5, (1 << 20) + 3, 0, True),
            (14, 14, 10, "median", 0, 5003, 0, False)]                                                  # no instance: fallback
   for ks, h, nb, rule, f, d, off, clip in cases:
     sampled = [torch.randn(d + off, device=DEV, generator=gen)[off:] for _ in range(ks)]
