@@ -534,7 +534,7 @@ def step_algorithmic_bytes(d, n, f, gar):
   m = n - f - 2
   # Krum / Bulyan: the distance pass rides along with the first pass too (the rows are contracted from its registers);
   # what is left of the rule is the average of the m selected rows / pass 2 over the m ranked rows, + 1 written
-  gar_units = {"krum": m + 1, "bulyan": m + 1, "median": 1, "trmean": 1}.get(gar, n + 1)
+  gar_units = {"krum": m + 1, "bulyan": m + 1, "median": 1, "trmean": 1, "phocas": 1, "meamed": 1}.get(gar, n + 1)
   return 4 * d * ((h + 2 * h + 3) + gar_units + 8)
 
 

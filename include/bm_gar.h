@@ -194,7 +194,7 @@ int bm_momentum_stats(const float* const* sampled, int ks, float* const* buffers
 /* The same first pass followed by a coordinate-wise rule over the h updated buffers and n_byz copies of byz_out, i.e.
  * defense_out = GAR(honests + [byz] * n_byz, f = rule_f) of attack.py:821 for rule_op = BM_OP_MEDIAN / TRMEAN / PHOCAS /
  * MEAMED (aggregators/median.py:39, trmean.py:33,81-109), with the results of bm_momentum_stats + bm_colwise (same
- * bits).  For the median and the trimmed mean over ks = h = 20 buffers and 1..6 Byzantine copies (n = 21..26: the
+ * bits).  For the four rules over ks = h = 20 buffers and 1..6 Byzantine copies (n = 21..26: the
  * reference's n = 25, f = 5 among them), or 14 buffers and 11 copies (its n = 25, f = 11), the rule runs INSIDE the first pass, on the values it already holds in
  * registers: the rule's own pass over the n rows disappears (26 of the 97 row passes of such a step).  Any other
  * shape runs the two kernels one after the other.  byz_out and defense_out must be non-NULL, attack_kind without
