@@ -23,7 +23,7 @@ const Tuning& tuning() {
 }
 }  // namespace bm
 
-extern "C" int bm_abi_version(void) { return 13; }
+extern "C" int bm_abi_version(void) { return 14; }
 
 extern "C" const char* bm_error_string(int code) {
   if (code == 0) return "success";

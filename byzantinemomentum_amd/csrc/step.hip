@@ -68,12 +68,15 @@ __device__ __forceinline__ float block_reduce_absmax(float m, float* lds) {
 typedef const float* __attribute__((address_space(4))) const* KargRowPtrs;
 constexpr int kStepBurstBlock = 512;
 
-template <int T, int VEC, bool EXACT, bool CLIP, bool BURST, int RULE = -1, int NB = 0>
+//   NOMOM  no momentum buffers: the honest rows ARE the sampled rows (momentum at the update, attack.py:809-810): nothing
+//          is loaded from or stored to the buffer table, both triples of statistics are those of the one stack
+template <int T, int VEC, bool EXACT, bool CLIP, bool BURST, int RULE = -1, int NB = 0, bool NOMOM = false>
 __global__ __launch_bounds__(BURST ? kStepBurstBlock : kStepBlock) void momentum_stats_kernel(
     StepTable tab, int ks_rt, int h_rt, uint32_t nvec, float mu, float omd, const float* __restrict__ clipf,
     float* __restrict__ s_avg_out, float* __restrict__ h_avg_out, float* __restrict__ byz_out, float scale,
     int attack_kind, double* __restrict__ partial, int rule_f, float rule_inv_keep, float* __restrict__ defense_out) {
   static_assert(RULE < 0 || (EXACT && NB >= 1), "the fused rule needs the row count at compile time");
+  static_assert(!NOMOM || (EXACT && !CLIP), "without buffers: same stack, clipped in place beforehand");
   constexpr int BLOCK = BURST ? kStepBurstBlock : kStepBlock;
   __shared__ double red[BLOCK / 64];
   __shared__ float mred[BLOCK / 64];
@@ -109,7 +112,9 @@ __global__ __launch_bounds__(BURST ? kStepBurstBlock : kStepBlock) void momentum
 #pragma unroll
       for (int i = 0; i < T; ++i) {
         if (i < ks) load_stream_off<VEC>(karg[i], off, g[i]);
-        if (i < h) load_stream_off<VEC>(karg[BM_MAX_ROWS + i], off, b[i]);
+        if constexpr (!NOMOM) {
+          if (i < h) load_stream_off<VEC>(karg[BM_MAX_ROWS + i], off, b[i]);
+        }
       }
       // clip, then momentum: gmtm.mul_(mu).add_(grad, alpha=1-damp) = fma(1-damp, grad, round(mu*gmtm))
 #pragma unroll
@@ -123,7 +128,7 @@ __global__ __launch_bounds__(BURST ? kStepBurstBlock : kStepBlock) void momentum
         }
         if (i < h) {
 #pragma unroll
-          for (int c = 0; c < VEC; ++c) b[i][c] = __builtin_fmaf(omd, g[i][c], mu * b[i][c]);
+          for (int c = 0; c < VEC; ++c) b[i][c] = NOMOM ? g[i][c] : __builtin_fmaf(omd, g[i][c], mu * b[i][c]);
         }
       }
 #pragma unroll
@@ -182,9 +187,11 @@ __global__ __launch_bounds__(BURST ? kStepBurstBlock : kStepBlock) void momentum
     asm volatile("" : "+s"(kbase));
     if (live) {
       KargRowPtrs karg = (KargRowPtrs)kbase;
+      if constexpr (!NOMOM) {
 #pragma unroll
-      for (int i = 0; i < T; ++i)
-        if (i < h) store_stream_off<VEC>(const_cast<float*>(karg[BM_MAX_ROWS + i]), off, b[i]);
+        for (int i = 0; i < T; ++i)
+          if (i < h) store_stream_off<VEC>(const_cast<float*>(karg[BM_MAX_ROWS + i]), off, b[i]);
+      }
       if (s_avg_out != nullptr) store_stream_off<VEC>(s_avg_out, off, sa);
       if (h_avg_out != nullptr) store_stream_off<VEC>(h_avg_out, off, ha);
       if (byz_out != nullptr) store_stream_off<VEC>(byz_out, off, bz);
@@ -242,7 +249,7 @@ struct SgShape {                             // TT honest rows (20: n = 25, f = 
   static constexpr int kLds = kPlanes + kAccBytes;                // 95 744 + 24 576 B at TT = 20
 };
 
-template <int TT, bool CLIP>
+template <int TT, bool CLIP, bool NOMOM = false>
 __global__ __launch_bounds__(kStepBurstBlock) void momentum_gram_kernel(
     StepTable tab, uint32_t nvec, float mu, float omd, const float* __restrict__ clipf, float* __restrict__ s_avg_out,
     float* __restrict__ h_avg_out, float* __restrict__ byz_out, float scale, int attack_kind, unsigned dither_seed,
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(kStepBurstBlock) void momentum_gram_kernel(
 #pragma unroll
       for (int i = 0; i < T; ++i) {
         load_stream_off<VEC>(karg[i], off, g[i]);
-        load_stream_off<VEC>(karg[BM_MAX_ROWS + i], off, b[i]);
+        if constexpr (!NOMOM) load_stream_off<VEC>(karg[BM_MAX_ROWS + i], off, b[i]);
       }
 #pragma unroll
       for (int i = 0; i < T; ++i) {
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(kStepBurstBlock) void momentum_gram_kernel(
           for (int c = 0; c < VEC; ++c) g[i][c] *= cf;
         }
 #pragma unroll
-        for (int c = 0; c < VEC; ++c) b[i][c] = __builtin_fmaf(omd, g[i][c], mu * b[i][c]);
+        for (int c = 0; c < VEC; ++c) b[i][c] = NOMOM ? g[i][c] : __builtin_fmaf(omd, g[i][c], mu * b[i][c]);
       }
 #pragma unroll
       for (int c = 0; c < VEC; ++c) {
@@ -407,8 +414,10 @@ __global__ __launch_bounds__(kStepBurstBlock) void momentum_gram_kernel(
     asm volatile("" : "+s"(kbase));
     if (live) {
       KargRowPtrs karg = (KargRowPtrs)kbase;
+      if constexpr (!NOMOM) {
 #pragma unroll
-      for (int i = 0; i < T; ++i) store_stream_off<VEC>(const_cast<float*>(karg[BM_MAX_ROWS + i]), off, b[i]);
+        for (int i = 0; i < T; ++i) store_stream_off<VEC>(const_cast<float*>(karg[BM_MAX_ROWS + i]), off, b[i]);
+      }
       if (s_avg_out != nullptr) store_stream_off<VEC>(s_avg_out, off, sa);
       if (h_avg_out != nullptr) store_stream_off<VEC>(h_avg_out, off, ha);
       store_stream_off<VEC>(byz_out, off, bz);
@@ -802,7 +811,7 @@ __global__ __launch_bounds__(64) void clip_factors_kernel(const double* __restri
 // First pass + coordinate-wise rule in one kernel (median / trimmed mean over the h = 20 updated buffers and 1..6
 // copies of the Byzantine vector: the C5 shape and its neighbours).  Returns false when no instance fits.
 // ---------------------------------------------------------------------------
-template <int T, int RULE, int NB, bool CLIP>
+template <int T, int RULE, int NB, bool CLIP, bool NOMOM = false>
 static void launch_fused_rule(const StepTable& tab, int64_t nvec, float mu, float omd, const float* clipf, float* s_avg,
                               float* h_avg, float* byz, float scale, int kind, double* partial, int rule_f,
                               float* defense, int* grid_io, hipStream_t s) {
@@ -813,11 +822,11 @@ static void launch_fused_rule(const StepTable& tab, int64_t nvec, float mu, floa
   const int64_t burst_iters = nvec / ((int64_t)cus * kStepBurstBlock);
   if (tuning().step_burst > 0 && burst_iters >= tuning().step_burst && cus < *grid_io) {
     *grid_io = cus;
-    hipLaunchKernelGGL((momentum_stats_kernel<T, 4, true, CLIP, true, RULE, NB>), dim3(cus), dim3(kStepBurstBlock), 0,
+    hipLaunchKernelGGL((momentum_stats_kernel<T, 4, true, CLIP, true, RULE, NB, NOMOM>), dim3(cus), dim3(kStepBurstBlock), 0,
                        s, tab, T, T, (uint32_t)nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial,
                        rule_f, inv_keep, defense);
   } else {
-    hipLaunchKernelGGL((momentum_stats_kernel<T, 4, true, CLIP, false, RULE, NB>), dim3(*grid_io), dim3(kStepBlock), 0,
+    hipLaunchKernelGGL((momentum_stats_kernel<T, 4, true, CLIP, false, RULE, NB, NOMOM>), dim3(*grid_io), dim3(kStepBlock), 0,
                        s, tab, T, T, (uint32_t)nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial,
                        rule_f, inv_keep, defense);
   }
@@ -826,8 +835,10 @@ static void launch_fused_rule(const StepTable& tab, int64_t nvec, float mu, floa
 template <int T, int RULE, int NB>
 static void launch_fused_rule_clip(const StepTable& tab, int64_t nvec, float mu, float omd, const float* clipf,
                                    float* s_avg, float* h_avg, float* byz, float scale, int kind, double* partial,
-                                   int rule_f, float* defense, int* grid_io, hipStream_t s) {
-  if (clipf != nullptr)
+                                   int rule_f, float* defense, int* grid_io, hipStream_t s, bool nomom) {
+  if (nomom)
+    launch_fused_rule<T, RULE, NB, false, true>(tab, nvec, mu, omd, nullptr, s_avg, h_avg, byz, scale, kind, partial, rule_f, defense, grid_io, s);
+  else if (clipf != nullptr)
     launch_fused_rule<T, RULE, NB, true>(tab, nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial, rule_f, defense, grid_io, s);
   else
     launch_fused_rule<T, RULE, NB, false>(tab, nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial, rule_f, defense, grid_io, s);
@@ -843,8 +854,9 @@ static bool fused_rule_instance(int ks, int h, int nb, int op) {
 
 static int launch_fused_rule_any(int op, int h, int nb, const StepTable& tab, int64_t nvec, float mu, float omd,
                                  const float* clipf, float* s_avg, float* h_avg, float* byz, float scale, int kind,
-                                 double* partial, int rule_f, float* defense, int* grid_io, hipStream_t s) {
-#define BM_FUSED_ARGS tab, nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial, rule_f, defense, grid_io, s
+                                 double* partial, int rule_f, float* defense, int* grid_io, hipStream_t s,
+                                 bool nomom = false) {
+#define BM_FUSED_ARGS tab, nvec, mu, omd, clipf, s_avg, h_avg, byz, scale, kind, partial, rule_f, defense, grid_io, s, nomom
 #define BM_FUSED_CASE(TV, NBV)                                                  \
   if (h == TV && nb == NBV) {                                                   \
     if (op == BM_OP_MEDIAN)                                                     \
@@ -1100,6 +1112,117 @@ extern "C" int bm_momentum_stats_sqdist(const float* const* sampled, int ks, flo
   hipLaunchKernelGGL(step_finish_kernel, dim3(1), dim3(kFinishThreads), 0, s, partial, nparts, out6);
   BM_LAUNCH_CHECK();
   return pairwise_from_gram_partials(rows, n, nc, blocks, d, sq_nxn, ws_pair, s);
+}
+
+// ---------------------------------------------------------------------------
+// The same two fusions without momentum buffers: the honest rows are the sampled rows themselves (momentum at the
+// update — the reference's default placement — attack.py:809-810,837-839).  out6[0..2] = out6[3..5] = the statistics
+// of the one stack.
+// ---------------------------------------------------------------------------
+namespace bm {
+static int stack_stats_plain(const float* const* rows, int k, int64_t d, float* avg_out, float* byz_out, float scale,
+                             int attack_kind, double* out6, void* ws, void* stream) {
+  int rc = bm_stack_stats(rows, k, d, avg_out, byz_out, scale, attack_kind, out6 + 3, ws, stream);
+  if (rc != 0) return rc;
+  return hip_code(hipMemcpyAsync(out6, out6 + 3, 3 * sizeof(double), hipMemcpyDeviceToDevice,
+                                 static_cast<hipStream_t>(stream)));
+}
+static bool nomom_shape(int k, int nb) { return (k == 20 && nb >= 1 && nb <= 6) || (k == 14 && nb == 11); }
+}  // namespace bm
+
+extern "C" int bm_stack_stats_colwise(const float* const* rows, int k, int64_t d, float* avg_out, float* byz_out,
+                                      float scale, int attack_kind, int rule_op, int rule_f, int n_byz,
+                                      float* defense_out, double* out6, void* ws, void* stream) {
+  using namespace bm;
+  const int n = k + n_byz;
+  if (rows == nullptr || out6 == nullptr || ws == nullptr || k < 1 || n_byz < 1 || n > BM_MAX_ROWS || d < 0 ||
+      (attack_kind != BM_ATTACK_EMPIRE && attack_kind != BM_ATTACK_LITTLE) ||
+      (rule_op != BM_OP_MEDIAN && rule_op != BM_OP_TRMEAN && rule_op != BM_OP_PHOCAS && rule_op != BM_OP_MEAMED) ||
+      (rule_op != BM_OP_MEDIAN && (rule_f < 0 || n < 2 * rule_f + 1)) ||
+      (d > 0 && (avg_out == nullptr || byz_out == nullptr || defense_out == nullptr)))
+    return BM_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  uintptr_t bits = reinterpret_cast<uintptr_t>(avg_out) | reinterpret_cast<uintptr_t>(byz_out) |
+                   reinterpret_cast<uintptr_t>(defense_out);
+  for (int i = 0; i < k; ++i) bits |= reinterpret_cast<uintptr_t>(rows[i]);
+  const bool fused = nomom_shape(k, n_byz) && vec_of(bits) == 4 && d % 4 == 0 && d > 0 && d <= kMaxColsPerLaunch &&
+                     tuning().step_stream != 1;
+  if (fused) {
+    StepTable tab{};
+    for (int i = 0; i < BM_MAX_ROWS; ++i) {
+      tab.g[i] = rows[i < k ? i : k - 1];
+      tab.b[i] = nullptr;  // never dereferenced without momentum
+    }
+    double* partial = static_cast<double*>(ws);
+    const int64_t nvec = d / 4;
+    int grid = stream_grid(nvec, kStepBlock, 2047);
+    int rc = launch_fused_rule_any(rule_op, k, n_byz, tab, nvec, 0.0f, 1.0f, nullptr, nullptr, avg_out, byz_out, scale,
+                                   attack_kind, partial, rule_f, defense_out, &grid, s, true);
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL(step_finish_kernel, dim3(1), dim3(kFinishThreads), 0, s, partial, grid, out6);
+    BM_LAUNCH_CHECK();
+    return 0;
+  }
+  int rc = stack_stats_plain(rows, k, d, avg_out, byz_out, scale, attack_kind, out6, ws, stream);
+  if (rc != 0 || d == 0) return rc;
+  const float* all[BM_MAX_ROWS];
+  for (int i = 0; i < k; ++i) all[i] = rows[i];
+  for (int i = k; i < n; ++i) all[i] = byz_out;
+  return bm_colwise(rule_op, all, n, d, rule_f, defense_out, stream);
+}
+
+extern "C" int bm_stack_stats_sqdist(const float* const* rows, int k, int64_t d, int64_t d_total, float* avg_out,
+                                     float* byz_out, float scale, int attack_kind, int n_byz, double* sq_nxn,
+                                     double* out6, void* ws, void* ws_pair, void* stream) {
+  using namespace bm;
+  const int n = k + n_byz;
+  if (rows == nullptr || out6 == nullptr || ws == nullptr || ws_pair == nullptr || sq_nxn == nullptr || k < 1 ||
+      n_byz < 1 || n > BM_MAX_ROWS || d < 0 || d_total < d ||
+      (attack_kind != BM_ATTACK_EMPIRE && attack_kind != BM_ATTACK_LITTLE) ||
+      (d > 0 && (avg_out == nullptr || byz_out == nullptr)))
+    return BM_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const float* all[BM_MAX_ROWS];
+  for (int i = 0; i < k; ++i) all[i] = rows[i];
+  for (int i = k; i < n; ++i) all[i] = byz_out;
+  uintptr_t bits = reinterpret_cast<uintptr_t>(avg_out) | reinterpret_cast<uintptr_t>(byz_out);
+  for (int i = 0; i < k; ++i) bits |= reinterpret_cast<uintptr_t>(rows[i]);
+  const int cus = compute_units();
+  const int64_t nvec = d / 4;
+  const bool fused = nomom_shape(k, n_byz) && vec_of(bits) == 4 && d % 4 == 0 && d <= kMaxColsPerLaunch &&
+                     tuning().step_stream != 1 && tuning().pair_mode == 0 && tuning().pair_planes != 3 &&
+                     tuning().step_burst > 0 && nvec / ((int64_t)cus * kStepBurstBlock) >= tuning().step_burst;
+  if (!fused) {
+    int rc = stack_stats_plain(rows, k, d, avg_out, byz_out, scale, attack_kind, out6, ws, stream);
+    if (rc != 0) return rc;
+    return bm_pairwise_sqdist_shard(all, n, d, d_total, sq_nxn, ws_pair, stream);
+  }
+  StepTable tab{};
+  for (int i = 0; i < BM_MAX_ROWS; ++i) {
+    tab.g[i] = rows[i < k ? i : k - 1];
+    tab.b[i] = nullptr;
+  }
+  double* partial = static_cast<double*>(ws);
+  double* gram_partial = pairwise_gram_area(ws_pair);
+  void (*kern)(StepTable, uint32_t, float, float, const float*, float*, float*, float*, float, int, unsigned, double*,
+               double*, int*);
+  int lds;
+  if (k == 20) {
+    kern = momentum_gram_kernel<20, false, true>;
+    lds = SgShape<20>::kLds;
+  } else {
+    kern = momentum_gram_kernel<14, false, true>;
+    lds = SgShape<14>::kLds;
+  }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  if (e != hipSuccess) return hip_code(e);
+  hipLaunchKernelGGL(kern, dim3(cus), dim3(kStepBurstBlock), lds, s, tab, (uint32_t)nvec, 0.0f, 1.0f, nullptr, nullptr,
+                     avg_out, byz_out, scale, attack_kind, (unsigned)tuning().pair_dither, partial, gram_partial,
+                     pairwise_arrival_counter(ws_pair));
+  BM_LAUNCH_CHECK();
+  hipLaunchKernelGGL(step_finish_kernel, dim3(1), dim3(kFinishThreads), 0, s, partial, cus, out6);
+  BM_LAUNCH_CHECK();
+  return pairwise_from_gram_partials(all, n, k + 1, cus, d, sq_nxn, ws_pair, s);
 }
 
 extern "C" int bm_multi_fma3(float* const* out, const float* const* p, const float* const* q, int k, int64_t d,

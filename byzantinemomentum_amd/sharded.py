@@ -145,6 +145,12 @@ class HipBackend:
   def momentum_stats_colwise(self, *args, **kwargs):
     return self.stats.momentum_stats_colwise(*args, **kwargs)
 
+  def stack_stats_colwise(self, *args, **kwargs):
+    return self.stats.stack_stats_colwise(*args, **kwargs)
+
+  def stack_stats_sqdist(self, *args, **kwargs):
+    return self.stats.stack_stats_sqdist(*args, **kwargs)
+
   def momentum_stats_sqdist(self, *args, **kwargs):
     return self.stats.momentum_stats_sqdist(*args, **kwargs)
 

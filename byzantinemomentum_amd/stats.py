@@ -14,7 +14,7 @@ import torch
 from . import _lib
 from . import gars
 
-__all__ = ["compute_avg_dev_max", "stack_stats_async", "study_dots", "study_stats", "multi_axpby", "row_sqnorms", "momentum_stats", "momentum_stats_colwise", "momentum_stats_sqdist",
+__all__ = ["compute_avg_dev_max", "stack_stats_async", "study_dots", "study_stats", "multi_axpby", "row_sqnorms", "momentum_stats", "momentum_stats_colwise", "momentum_stats_sqdist", "stack_stats_colwise", "stack_stats_sqdist",
            "multi_fma3", "clip_factors", "clip_factors_from_sq", "multi_scale", "clip_gradients", "l2_distance",
            "step_worker"]
 
@@ -221,6 +221,46 @@ def momentum_stats_sqdist(sampled, buffers, mu, one_minus_damp, clip_factors_dev
       ctypes.c_float(attack_scale), _attack_id(attack, False), int(n_byz), _ptr(sq), _ptr(out6), _ptr(ws), _ptr(ws_pair),
       gars._stream(device)), "bm_momentum_stats_sqdist")
   return s_avg, h_avg, byz, sq, out6
+
+
+def stack_stats_colwise(rows, attack_scale, attack, rule, f, n_byz):
+  """stack_stats (average, Byzantine vector, statistics) followed by a coordinate-wise rule over the rows and `n_byz`
+  copies of the Byzantine vector — ONE pass over the rows at k = 20 (1..6 copies) or 14 (11 copies)
+  (bm_stack_stats_colwise: the honest rows of `--momentum-at update`).  Returns (avg, byz, defense, out6). No sync."""
+  k, d, device = gars._validate(list(rows))
+  if n_byz < 1:
+    raise gars.GarInputError("stack_stats_colwise needs n_byz >= 1")
+  lib = _lib.load()
+  avg, byz, defense = (torch.empty(d, dtype=torch.float32, device=device) for _ in range(3))
+  out6 = torch.empty(6, dtype=torch.float64, device=device)
+  ws = gars._workspace(device, _lib.WS_STEP, 1, d, "ws_step")
+  with torch.cuda.device(device):
+    _lib.check(lib.bm_stack_stats_colwise(_lib.pointer_table(rows), k, d, _ptr(avg), _ptr(byz),
+                                          ctypes.c_float(attack_scale), _attack_id(attack, False), _COLWISE_OPS[rule],
+                                          int(f), int(n_byz), _ptr(defense), _ptr(out6), _ptr(ws),
+                                          gars._stream(device)), "bm_stack_stats_colwise")
+  return avg, byz, defense, out6
+
+
+def stack_stats_sqdist(rows, attack_scale, attack, n_byz, d_total=None):
+  """stack_stats together with the n x n squared distances (n = len(rows) + n_byz) of the rows and the Byzantine
+  copies, in one pass at k = 20 / 14 for long gradients (bm_stack_stats_sqdist).  Returns (avg, byz, sq, out6)."""
+  k, d, device = gars._validate(list(rows))
+  if n_byz < 1 or k + n_byz > _lib.MAX_ROWS:
+    raise gars.GarInputError("stack_stats_sqdist needs n_byz >= 1 and at most 64 rows")
+  n = k + n_byz
+  lib = _lib.load()
+  avg, byz = (torch.empty(d, dtype=torch.float32, device=device) for _ in range(2))
+  sq = torch.empty((n, n), dtype=torch.float64, device=device)
+  out6 = torch.empty(6, dtype=torch.float64, device=device)
+  ws = gars._workspace(device, _lib.WS_STEP, 1, d, "ws_step")
+  ws_pair = gars._workspace(device, _lib.WS_PAIRWISE, n, d, "ws_pair")
+  with torch.cuda.device(device):
+    _lib.check(lib.bm_stack_stats_sqdist(_lib.pointer_table(rows), k, d, d if d_total is None else int(d_total),
+                                         _ptr(avg), _ptr(byz), ctypes.c_float(attack_scale), _attack_id(attack, False),
+                                         int(n_byz), _ptr(sq), _ptr(out6), _ptr(ws), _ptr(ws_pair),
+                                         gars._stream(device)), "bm_stack_stats_sqdist")
+  return avg, byz, sq, out6
 
 
 def multi_fma3(outs, ps, qs, a, b, p_scale_dev=None):

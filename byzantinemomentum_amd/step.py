@@ -213,11 +213,28 @@ class AggregationStep:
         ops.multi_fma3(honests, sampled[:h], [zero] * h, omd, self.mu)
       else:
         honests = sampled[:h]
-      if self.attack_evals is None:
+      # momentum at the update with every sampled gradient honest: the rule, or its distance pass, is fed from the pass
+      # that forms the statistics and the Byzantine vector (one pass over the rows at h = 20 / 14)
+      plain_update = (self.momentum_at == "update" and ks == h and self.attack_evals is None and self.f_real >= 1)
+      if plain_update and not self.gar_args and self.gar in ("median", "trmean", "phocas", "meamed") \
+         and hasattr(ops, "stack_stats_colwise"):
+        h_avg, byz, fused_defense, o6 = ops.stack_stats_colwise(honests, self.factor, self.attack, self.gar, self.f_decl,
+                                                                self.f_real)
+        h_out3 = o6[3:]
+      elif plain_update and self.gar in ("krum", "bulyan") and not (set(self.gar_args) - {"m"}) \
+          and hasattr(ops, "stack_stats_sqdist"):
+        h_avg, byz, fused_sq, o6 = ops.stack_stats_sqdist(honests, self.factor, self.attack, self.f_real,
+                                                          d_total=sampled[0].shape[0] * agg.world_size)
+        h_out3 = o6[3:]
+      elif self.attack_evals is None:
         h_avg, h_out3, byz = ops.stack_stats(honests, scale=self.factor, attack=self.attack)
       else:
         h_avg, h_out3, byz = ops.stack_stats(honests, scale=1.0, attack=self.attack, direction=True)
-      s_avg, s_out3 = ops.stack_stats(sampled)
+      if self.momentum_at == "update" and ks == h:
+        # the honest stack IS the sampled stack (attack.py:809-810): one pass gives both sets of statistics
+        s_avg, s_out3 = h_avg, h_out3
+      else:
+        s_avg, s_out3 = ops.stack_stats(sampled)
     if self.attack_evals is not None and self.f_real > 0:
       direction = byz
       self.last_factor = self._search_factor(honests, h_avg, direction)

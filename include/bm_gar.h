@@ -218,6 +218,21 @@ int bm_momentum_stats_sqdist(const float* const* sampled, int ks, float* const* 
                              float* sampled_avg, float* honest_avg, float* byz_out, float scale, int attack_kind,
                              int n_byz, double* sq_nxn, double* out6, void* ws, void* ws_pair, void* stream);
 
+/* The same two fusions when there are no momentum buffers: the honest rows are the k sampled rows themselves, as with
+ * `--momentum-at update` (the reference's default placement, attack.py:809-810,837-839).  bm_stack_stats (average,
+ * Byzantine vector, statistics; tools/pytorch.py:97-125, attacks/identical.py:63-86) together with
+ *   bm_stack_stats_colwise: defense_out = rule(rows + [byz] * n_byz, f = rule_f), the rule of bm_colwise;
+ *   bm_stack_stats_sqdist : sq_nxn = the squared distances of rows + [byz] * n_byz (n = k + n_byz).
+ * For k = 20 with 1..6 Byzantine copies, or 14 with 11, 16-byte aligned rows and d a multiple of 4 (for the distances
+ * also: gradients long enough for the burst form) it is ONE pass over the k rows; otherwise the stand-alone kernels
+ * run one after the other.  out6[0..2] = out6[3..5] = { sum avg^2, sum_i |row_i - avg|^2, max|avg| }. */
+int bm_stack_stats_colwise(const float* const* rows, int k, int64_t d, float* avg_out, float* byz_out, float scale,
+                           int attack_kind, int rule_op, int rule_f, int n_byz, float* defense_out, double* out6,
+                           void* ws, void* stream);
+int bm_stack_stats_sqdist(const float* const* rows, int k, int64_t d, int64_t d_total, float* avg_out, float* byz_out,
+                          float scale, int attack_kind, int n_byz, double* sq_nxn, double* out6, void* ws,
+                          void* ws_pair, void* stream);
+
 /* out[i] = b * q[i] + a * (p_scale[i] * p[i]) for k vectors (p_scale: DEVICE array of k floats or NULL;
  * entries of q may be one shared vector; out[i] may alias p[i]).  Every momentum placement of the loop:
  * worker (attack.py:800-804), server (:805-808), update (:838-839), Nesterov look-ahead (:762,767). */

@@ -553,3 +553,45 @@ def test_step_with_the_rule_fed_from_the_first_pass(bm, gar, f):
     # one by one) — at most a handful of columns, every other column within the tolerance
     assert bad <= (20 if gar == "bulyan" else 0), (gar, it, bad)
     assert_floats_close(fa, want, tag=(gar, it), tol=1e-5)
+
+
+@pytest.mark.parametrize("gar,f", [("median", 5), ("krum", 5), ("meamed", 11), ("krum", 11)])
+def test_update_placement_with_the_rule_fed_from_the_statistics_pass(bm, gar, f):
+  """`--momentum-at update` (the reference's default), n = 25, d = 4 300 800: the rule (or its distance pass) rides along
+  with the pass that forms the statistics and the Byzantine vector of the sampled stack; two steps against the independent
+  loop of tests/step_reference.py, and the fused entry points against the stand-alone kernels."""
+  from byzantinemomentum_amd.step import AggregationStep
+  from tests.step_reference import ReferenceLoop, assert_floats_close
+  n, d = 25, 4300800
+  h = n - f
+  step = AggregationStep(n, f, f, gar=gar, momentum=0.9, dampening=0.9, momentum_at="update", attack="little",
+                         attack_factor=1.5, nb_past=2)
+  ref = ReferenceLoop(n, f, f, gar, "update", 0.9, 0.9, "little", 1.5, None, 2)
+  gen = torch.Generator().manual_seed(6)
+  drift = 0.2 * torch.randn(d, generator=gen)
+  for it in range(2):
+    sampled = [drift + (0.5 + 0.05 * i) * torch.randn(d, generator=gen) for i in range(h)]
+    want_def, want_upd, want = ref.step(sampled)
+    dev = [g.to(DEV) for g in sampled]
+    got = step.run(dev)
+    scale = float(torch.stack(sampled).abs().max())
+    assert float((got.cpu() - want_def).abs().max()) <= 4e-6 * scale, (gar, it)
+    assert float((step.update_gradient().cpu() - want_upd).abs().max()) <= 4e-6 * scale, (gar, it)
+    assert_floats_close(step.floats(), want, tag=(gar, it), tol=1e-5)
+  # the entry points against the stand-alone kernels, same rows
+  if gar in ("median", "meamed"):
+    avg, byz, defense, o6 = bm.stats.stack_stats_colwise(dev, 1.5, "little", gar, f, f)
+    avg2, o3, byz2 = bm.stats.stack_stats_async(dev, scale=1.5, attack="little")
+    assert torch.equal(avg, avg2) and torch.equal(byz, byz2)
+    want_d = bm.median(dev + [byz2] * f) if gar == "median" else bm.meamed(dev + [byz2] * f, f)
+    assert torch.equal(defense, want_d)
+  else:
+    avg, byz, sq, o6 = bm.stats.stack_stats_sqdist(dev, 1.5, "little", f)
+    avg2, o3, byz2 = bm.stats.stack_stats_async(dev, scale=1.5, attack="little")
+    assert torch.equal(avg, avg2) and torch.equal(byz, byz2)
+    ref_sq = sqdist_f64_on_gpu(dev + [byz2] * f)
+    got_sq = sq.cpu().numpy()
+    pos = ref_sq > 0
+    assert not got_sq[~pos].any() and (np.abs(got_sq - ref_sq)[pos] / ref_sq[pos]).max() <= 1e-5
+  a, b = o6.tolist(), o3.tolist()
+  assert a[:3] == a[3:] and all(abs(x - y) <= 1e-6 * abs(y) for x, y in zip(a[3:], b))
