@@ -615,6 +615,21 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
     out[f"step_c5_{gar}"] = entry(ms, step_algorithmic_bytes(d, n, f, gar),
                                   config=f"full step mirror, rule {gar}, n={n}, f={f}, d={d}, one GPU")
     del runner
+  if "BM_BENCH_CHILD" not in os.environ:
+    # the same step with the momentum at the update, the reference's default placement (attack.py:809-810,837-839): the
+    # honest rows are the sampled rows, statistics + Byzantine vector + rule (or its distance pass) are one pass over them
+    for gar in ("krum", "median"):
+      runner = AggregationStep(n, f, f, gar=gar, momentum=0.99, dampening=0.99, momentum_at="update", attack_factor=1.1,
+                               nb_past=25)
+
+      def one_update(i):
+        runner.run(sets[i & 1])
+        runner.floats()
+      ms = timed_loop(one_update, 8, 27, timer, "step_update_" + gar)
+      units = (h + 3 if gar == "median" else h + 2 + (n - f - 2) + 1) + 3 + 8  # first pass (+ average of m rows), update momentum, study block
+      out[f"step_c5_update_{gar}"] = entry(ms, 4 * d * units,
+                                           config=f"full step mirror, momentum at the update, rule {gar}, n={n}, f={f}, d={d}, one GPU")
+      del runner
   if cpu_baseline and c3_sample is not None:  # last: host threads busy with it must not sit next to a GPU measurement
     base = cpu_baseline_distance(c3_sample, 12, "krum", 1 << 18)
     base["value"] *= (1 << 18) / D_RESNET18  # the sample IS 2^18 coordinates long: scale to the C3 length
