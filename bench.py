@@ -565,7 +565,7 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
   from byzantinemomentum_amd.step import AggregationStep
   out = {}
   d = D_RESNET18
-  c3_sample = None
+  c3_sample = c4_sample = None
   for name, n, f in (("krum_c3", 51, 12), ("bulyan_c4_1gpu", 25, 5)):
     m = n - f - 2
     stacks = make_stacks(n, f, d, device, 2, 4321, aliased)
@@ -582,6 +582,8 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
       if cpu_baseline:
         c3_sample = [g[:1 << 18].clone() for g in stacks[0]]  # kept for the CPU baseline at the very end
     else:
+      if cpu_baseline:
+        c4_sample = [g[:1 << 18].clone() for g in stacks[0]]
       # the other rules of aggregators/ on the C2 / C4 shape (n = 25, f = 5, d = 11.2 M)
       c = (n + 1) // 2
       ms_a = timed_loop(lambda i: bm.aksel(stacks[i & 1], f), 12, 3, timer, "aksel_c2")
@@ -635,6 +637,11 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
     base["value"] *= (1 << 18) / D_RESNET18  # the sample IS 2^18 coordinates long: scale to the C3 length
     base["sample"] += f" (C3: n=51, f=12, d={D_RESNET18})"
     out["krum_c3"]["cpu_baseline"] = base
+  if cpu_baseline and c4_sample is not None:
+    base = cpu_baseline_distance(c4_sample, 5, "bulyan", 1 << 18)
+    base["value"] *= (1 << 18) / D_RESNET18
+    base["sample"] += f" (C4: n=25, f=5, d={D_RESNET18})"
+    out["bulyan_c4_1gpu"]["cpu_baseline"] = base
   return out
 
 
