@@ -87,6 +87,78 @@ def test_brute_select_random_matrices_against_exhaustive_search():
         assert rc == 0 and sel == best
 
 
+def _reference_selection(dist, n, f):
+  """The loop of aggregators/brute.py:47-68 on a distance matrix: running maximum from 0, subsets touching a non-finite
+  distance dropped, first subset of strictly smallest diameter."""
+  best, best_d = None, None
+  for sub in itertools.combinations(range(n), n - f):
+    diam, ok = 0., True
+    for x, y in itertools.combinations(sub, 2):
+      v = dist[x, y]
+      if not math.isfinite(v):
+        ok = False
+        break
+      if v > diam:
+        diam = v
+    if ok and (best is None or diam < best_d):
+      best, best_d = list(sub), diam
+  return best
+
+
+def test_brute_select_every_small_shape_with_ties_zeros_and_non_finite_distances():
+  """bm_brute_select answers from the threshold graphs of the distances (smallest diameter by bisection, then the
+  lexicographically first subset) instead of enumerating subsets: every (n, f) up to n = 11 — f = 0 and n - f = 1
+  included — on integer grids (exact ties), coincident points (zero distances), inf / NaN entries."""
+  rng = np.random.default_rng(11)
+  for trial in range(400):
+    n = int(rng.integers(1, 12))
+    f = int(rng.integers(0, n))
+    kind = trial % 4
+    if kind == 0:
+      pts = rng.integers(0, 4, size=(n, 2)).astype(np.float64)
+    elif kind == 2:
+      pts = rng.integers(0, 2, size=(n, 1)).astype(np.float64)
+    else:
+      pts = rng.standard_normal((n, 3))
+    dist = np.sqrt(((pts[:, None] - pts[None]) ** 2).sum(-1))
+    if kind == 3:
+      for _ in range(int(rng.integers(0, 4))):
+        i, j = rng.integers(0, n, 2)
+        if i != j:
+          dist[i, j] = dist[j, i] = rng.choice([math.inf, math.nan])
+    want = _reference_selection(dist, n, f)
+    rc, sel = _brute_select(dist, n, f)
+    if want is None:
+      assert rc != 0, (n, f)
+    else:
+      assert rc == 0 and sel == want, (n, f, kind)
+
+
+@pytest.mark.parametrize("n,f", [(25, 5), (25, 11), (51, 12), (51, 24), (64, 31)])
+def test_brute_select_at_sizes_the_reference_cannot_enumerate(n, f):
+  """C(51, 12) = 1.6e11 subsets: the reference's loop never ends there.  A planted answer: n - f rows
+  within a ball of diameter < 1, the other f at distance > 5 from everything (ties and the lexicographic rule are
+  pinned on the small shapes above)."""
+  rng = np.random.default_rng(n * 100 + f)
+  k = n - f
+  inside = sorted(rng.permutation(n)[:k].tolist())
+  pts = np.zeros((n, 8))
+  for i in range(n):
+    if i in inside:
+      v = rng.standard_normal(8)
+      pts[i] = 0.45 * rng.random() * v / np.linalg.norm(v)
+    else:
+      v = rng.standard_normal(8)
+      pts[i] = (6.0 + 3.0 * rng.random()) * v / np.linalg.norm(v) + 20.0 * (i + 1)
+  dist = np.sqrt(((pts[:, None] - pts[None]) ** 2).sum(-1))
+  rc, sel = _brute_select(dist, n, f)
+  assert rc == 0 and sel == inside
+  # non-finite rows beyond the budget: no subset is left
+  dist[:, :f + 1] = math.nan
+  dist[:f + 1, :] = math.nan
+  assert _brute_select(dist, n, f)[0] != 0
+
+
 @pytest.mark.reference
 def test_reference_discovers_native_package():
   """`import aggregators` of the UNMODIFIED reference with the repo on PYTHONPATH registers the
