@@ -581,6 +581,12 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
         out["attack_search_c3_krum"] = attack_search(bm, stacks[0][:n - f], n, f, d)
       if cpu_baseline:
         c3_sample = [g[:1 << 18].clone() for g in stacks[0]]  # kept for the CPU baseline at the very end
+      # Brute at the same shape: C(51, 12) = 1.6e11 subsets, which the reference's loop (brute.py:47-68) cannot enumerate;
+      # bm_brute_select answers from the threshold graphs of the distances
+      ms_b = timed_loop(lambda i: bm.brute(stacks[i & 1], f), 6, 2, timer, "brute_c3")
+      out["brute_c3"] = entry(ms_b, 4 * d * n + 4 * d * (n - f + 1),
+                              config=f"brute.py:32-80, n={n}, f={f} (1.6e11 subsets: not enumerable; the subset of "
+                                     f"smallest diameter from the device's distances on the host, one synchronisation), d={d}")
     else:
       if cpu_baseline:
         c4_sample = [g[:1 << 18].clone() for g in stacks[0]]

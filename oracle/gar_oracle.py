@@ -41,7 +41,8 @@ import numpy as np
 import torch
 
 __all__ = ["pairwise_distances", "krum_scores", "krum_order", "krum", "bulyan_order", "bulyan", "median",
-           "trmean", "phocas", "meamed", "closest_window", "brute_selection", "brute", "aksel_order", "aksel",
+           "trmean", "phocas", "meamed", "closest_window", "brute_selection", "brute_selection_from_distances",
+           "brute_selection_is_the_references", "brute", "aksel_order", "aksel",
            "average", "cge", "compute_avg_dev_max", "study_block", "worker_momentum", "make_stack"]
 
 
@@ -226,19 +227,86 @@ def closest_window(g, keep, centre):
 def brute_selection(gradients, f, precision="f32"):
   """First subset (lexicographic order) of n-f rows with the strictly smallest diameter; subsets
   touching a non-finite distance are skipped (brute.py:47-68)."""
-  n = len(gradients)
   dist = pairwise_distances(gradients, precision, clamp_nonfinite=False)
-  best, best_diam = None, None
-  for subset in itertools.combinations(range(n), n - f):
-    sub = dist[np.ix_(subset, subset)]
-    if not np.isfinite(sub).all():
-      continue
-    diam = float(sub.max()) if len(subset) > 1 else 0.0
-    if best is None or diam < best_diam:
-      best, best_diam = subset, diam
+  best = brute_selection_from_distances(dist, f)
   if best is None:
     raise AssertionError("too many non-finite gradients")
-  return list(best)
+  return best
+
+
+def brute_selection_from_distances(dist, f):
+  """The loop of brute.py:47-68 on an n x n distance matrix (entries [x, y], x < y): running maximum from 0.,
+  a subset is dropped at its first non-finite distance, first subset of strictly smallest diameter."""
+  n = dist.shape[0]
+  best, best_diam = None, None
+  for subset in itertools.combinations(range(n), n - f):
+    diam, finite = 0., True
+    for x, y in itertools.combinations(subset, 2):
+      v = dist[x, y]
+      if not math.isfinite(v):
+        finite = False
+        break
+      if v > diam:
+        diam = v
+    if finite and (best is None or diam < best_diam):
+      best, best_diam = list(subset), diam
+  return best
+
+
+def brute_selection_is_the_references(dist, f, selection):
+  """Would brute.py:47-68 return `selection` on this distance matrix?  Decided WITHOUT enumerating the C(n, f)
+  subsets (1.6e11 at n = 51, f = 12), so that answers at such shapes can be checked at all: with D the diameter of
+  `selection`,
+    (1) every distance inside it is finite;
+    (2) no subset of n-f rows has all its distances finite and < D   (strictly smallest);
+    (3) for every position i and every row c below selection[i] (above selection[i-1]) no subset of finite diameter
+        <= D starts with selection[:i] + [c]                          (first in lexicographic order).
+  (2) and (3) ask whether a graph on the rows — pairs at finite distance < D, resp. <= D — holds a set of mutually
+  adjacent rows of a given size among given candidates, i.e. whether its complement has a vertex cover within a
+  budget <= f: decided by branching on an uncovered pair (one of its two ends must go), 2^f leaves at most.
+  Test infrastructure like the rest of this module; deliberately a different search from the product's
+  (csrc/api.cpp branches on the row with most non-neighbours and bisects over the distances)."""
+  n = dist.shape[0]
+  k = n - f
+  sel = list(selection)
+  if len(sel) != k or sorted(set(sel)) != sel or (sel and (sel[0] < 0 or sel[-1] >= n)):
+    return False
+  diam = 0.
+  for x, y in itertools.combinations(sel, 2):
+    v = dist[x, y]
+    if not math.isfinite(v):
+      return False
+    diam = max(diam, v)
+
+  def adjacent(x, y, strict):
+    v = dist[min(x, y), max(x, y)]
+    return math.isfinite(v) and (v < diam if strict else v <= diam)
+
+  def holds(cand, need, strict):
+    """`need` mutually adjacent rows among the list `cand`?"""
+    if len(cand) < need:
+      return False
+    if need <= 1:
+      return True
+    for i, x in enumerate(cand):
+      for y in cand[i + 1:]:
+        if not adjacent(x, y, strict):
+          if len(cand) == need:
+            return False
+          return holds([c for c in cand if c != x], need, strict) or holds([c for c in cand if c != y], need, strict)
+    return True
+
+  if diam > 0. and holds(list(range(n)), k, True):
+    return False
+  prefix, floor = [], 0
+  for i, s_i in enumerate(sel):
+    for c in range(floor, s_i):
+      cand = [r for r in range(c + 1, n) if all(adjacent(r, q, False) for q in prefix + [c])]
+      if all(adjacent(c, q, False) for q in prefix) and holds(cand, k - i - 1, False):
+        return False
+    prefix.append(s_i)
+    floor = s_i + 1
+  return True
 
 
 def brute(gradients, f, precision="f32"):

@@ -598,3 +598,26 @@ def test_update_placement_with_the_rule_fed_from_the_statistics_pass(bm, gar, f)
     assert not got_sq[~pos].any() and (np.abs(got_sq - ref_sq)[pos] / ref_sq[pos]).max() <= 1e-5
   a, b = o6.tolist(), o3.tolist()
   assert a[:3] == a[3:] and all(abs(x - y) <= 1e-6 * abs(y) for x, y in zip(a[3:], b))
+
+
+# ---------------------------------------------------------------------------- #
+# Brute at the C3 shape (brute.py:32-80): 1.6e11 subsets, which the reference's loop cannot finish
+
+@pytest.mark.parametrize("n,f,kind", [(51, 12, "hetero"), (25, 5, "hetero"), (25, 11, "tight")])
+def test_brute_at_shapes_beyond_enumeration(bm, n, f, kind):
+  """The selection on the device's distances is the one brute.py:47-68 would return on fp64 distances of the same
+  rows (first subset in lexicographic order of strictly smallest diameter; the f Byzantine rows are ONE aliased
+  tensor: exact zero distances and exact ties), decided by the oracle's checker without enumerating subsets — and,
+  at n = 25, f = 5, equal to the enumeration itself; the average has the bits of torch's sequential sum."""
+  from tests.test_gpu_parity_r2 import gpu_stack
+  d = D_RESNET18 if n == 51 else 2500003
+  rows, h = gpu_stack(kind, n, f, d, seed=77)
+  dist = np.sqrt(sqdist_f64_on_gpu(rows))
+  sel = bm.gars.brute_selection(rows, f)
+  assert O.brute_selection_is_the_references(dist, f, sel), sel
+  if (n, f) == (25, 5):
+    assert sel == O.brute_selection_from_distances(dist, f)
+  acc = torch.zeros(d, dtype=torch.float32, device=DEV)
+  for i in sel:
+    acc = acc + rows[i]
+  assert same_bits(bm.brute(rows, f), acc.cpu().div_(n - f))

@@ -134,6 +134,35 @@ def test_brute_select_every_small_shape_with_ties_zeros_and_non_finite_distances
       assert rc == 0 and sel == want, (n, f, kind)
 
 
+def _stack_distances(n, f, seed, d=2048):
+  """fp64 distances of a bench-like stack: honest rows N(mu, sigma_i^2), f Byzantine rows around -0.1 x their mean."""
+  rng = np.random.default_rng(seed)
+  h = n - f
+  mu = 0.1 * rng.standard_normal(d)
+  rows = [mu + s * rng.standard_normal(d) for s in np.linspace(0.5, 1.5, h)]
+  byz = -0.1 * np.mean(rows, axis=0)
+  rows += [byz + 0.3 * rng.standard_normal(d) for _ in range(f)]
+  x = np.array(rows)
+  return np.sqrt(((x[:, None] - x[None]) ** 2).sum(-1))
+
+
+@pytest.mark.parametrize("n,f,seed", [(25, 5, 0), (25, 5, 1), (25, 11, 2), (51, 12, 3), (51, 12, 4)])
+def test_brute_select_is_the_references_answer_at_the_bench_shapes(n, f, seed):
+  """The reference's own loop is the check at n = 25, f = 5 (53 130 subsets); beyond, the oracle's checker, which
+  decides the three defining properties (finite, strictly smallest diameter, first in lexicographic order) with
+  its own search."""
+  dist = _stack_distances(n, f, seed)
+  if seed % 2 == 1:  # exact ties: two aliased rows and a pair exactly as far apart as another one
+    dist[:, n - 1] = dist[:, n - 2]
+    dist[n - 1, :] = dist[n - 2, :]
+    dist[n - 2, n - 1] = dist[n - 1, n - 2] = dist[n - 1, n - 1] = 0.0
+  rc, sel = _brute_select(dist, n, f)
+  assert rc == 0
+  assert O.brute_selection_is_the_references(dist, f, sel)
+  if (n, f) == (25, 5):
+    assert sel == O.brute_selection_from_distances(dist, f)
+
+
 @pytest.mark.parametrize("n,f", [(25, 5), (25, 11), (51, 12), (51, 24), (64, 31)])
 def test_brute_select_at_sizes_the_reference_cannot_enumerate(n, f):
   """C(51, 12) = 1.6e11 subsets: the reference's loop never ends there.  A planted answer: n - f rows

@@ -2,8 +2,10 @@
 formulation the kernels implement must agree with the reference's topk formulation wherever the
 choice is not ambiguous, including stacks with duplicated (aliased) rows and infinities."""
 
+import itertools
 import math
 
+import numpy as np
 import pytest
 import torch
 
@@ -47,3 +49,24 @@ def test_krum_scores_are_invariant_to_aliasing_order():
   assert len(byz_scores) == 1
   pos = [order.index(i) for i in range(h, 13)]
   assert pos == sorted(pos) and pos[-1] - pos[0] == 2
+
+
+def test_brute_checker_accepts_exactly_the_enumerated_answer():
+  """`brute_selection_is_the_references` (decides, without enumerating subsets, whether brute.py:47-68 would return a
+  given selection — what makes answers at n = 51, f = 12 checkable) against the enumeration on every subset of small
+  shapes: ties on integer grids, zero distances, NaN entries."""
+  rng = np.random.default_rng(5)
+  for trial in range(120):
+    n = int(rng.integers(1, 9))
+    f = int(rng.integers(0, n))
+    kind = trial % 4
+    pts = rng.integers(0, 4, size=(n, 2)).astype(np.float64) if kind < 2 else rng.standard_normal((n, 2))
+    dist = np.sqrt(((pts[:, None] - pts[None]) ** 2).sum(-1))
+    if kind == 3:
+      for _ in range(int(rng.integers(0, 3))):
+        i, j = rng.integers(0, n, 2)
+        if i != j:
+          dist[i, j] = dist[j, i] = math.nan
+    want = O.brute_selection_from_distances(dist, f)
+    for sub in itertools.combinations(range(n), n - f):
+      assert O.brute_selection_is_the_references(dist, f, list(sub)) == (list(sub) == want), (n, f, sub, want)
