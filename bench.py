@@ -62,6 +62,9 @@ def parse():
   p.add_argument("--separate-rows", action="store_true",
                  help="allocate every synthetic gradient with its own torch.empty instead of byzantinemomentum_amd."
                       "layout.alloc_rows (rows of one allocation at a skewed stride): the placement A/B of DESIGN 3")
+  p.add_argument("--graph-replay", action="store_true",
+                 help="N > 1 (or one rank under torch.distributed.run): also time the sharded rule recorded into a HIP "
+                      "graph, one graph per synthetic stack (byzantinemomentum_amd/graphs.py) -> per_gar.<rule>_graph_replay")
   p.add_argument("--aliased-byz", action="store_true",
                  help="make the f Byzantine rows ONE aliased tensor as the reference's attacks do "
                       "(attacks/identical.py:86); they are then served from cache and the HBM traffic "
@@ -426,6 +429,28 @@ def main():
       dist.all_reduce(t, op=dist.ReduceOp.MAX)
       nbytes = 4 * d_total * (n + 1) if key != "allgather_output" else 4 * d_total
       per_gar[key] = entry(t.item(), nbytes, config=f"same shards, n={n}, total d={d_total}, max over ranks")
+    if args.graph_replay:
+      # the launch-bound regime: the whole aggregation — kernels and the all-reduce — as ONE graph launch.
+      # Every rank votes after its recording, so that no rank replays (and enters the collective) alone.
+      from byzantinemomentum_amd.graphs import GraphedCall
+      graphs, failure = None, None
+      try:
+        graphs = [GraphedCall(lambda s=s: rule(stacks[s], f)) for s in (0, 1)]
+      except Exception as err:  # noqa: BLE001
+        failure = repr(err)
+      vote = torch.tensor([0.0 if graphs is None else 1.0], dtype=torch.float64, device=device)
+      dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+      if vote.item() >= 1.0:
+        same = bool(torch.equal(graphs[0](), rule(stacks[0], f)))
+        ms_g = timed_loop(lambda i: graphs[i & 1](), 20, 3, timer, "x_graph")
+        t = torch.tensor([ms_g], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        per_gar[workload + "_graph_replay"] = dict(entry(t.item(), algo_bytes[workload],
+                                                         config=f"the same sharded rule replayed from a HIP graph, max over ranks"),
+                                                   same_bits_as_eager=same)
+      else:
+        per_gar[workload + "_graph_replay"] = {"error": failure or "the recording failed on another rank"}
+      del graphs
     del stacks
     torch.cuda.empty_cache()
     # worker-parallel production: every rank holds the FULL-length gradients of its own workers

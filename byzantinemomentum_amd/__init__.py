@@ -8,6 +8,7 @@ from . import _lib  # noqa: F401
 from . import gars  # noqa: F401
 from . import stats  # noqa: F401
 from . import layout  # noqa: F401
+from . import graphs  # noqa: F401
 from .gars import (median, trmean, phocas, meamed, krum, bulyan, brute, aksel, average, cge)  # noqa: F401
 from .stats import compute_avg_dev_max  # noqa: F401
 

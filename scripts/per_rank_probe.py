@@ -55,6 +55,29 @@ def main():
       gpu = sum(x.elapsed_time(y) for x, y in ev) / len(ev) * 1e3
       print(f"{name}: d_local={d} (1/{P} of {d_total}); one C call {a:.0f} us/agg wall, Python sequence + torch.distributed "
             f"{b:.0f} us/agg wall; GPU time of the single call {gpu:.0f} us (HIP events)", flush=True)
+      # the same single call recorded into a HIP graph (byzantinemomentum_amd/graphs.py), one graph per stack
+      from byzantinemomentum_amd.graphs import GraphedCall
+      try:
+        graphs = [GraphedCall(lambda s=s: native.bulyan(stacks[s], f)) for s in (0, 1)]
+        same = all(torch.equal(graphs[s](), native.bulyan(stacks[s], f)) for s in (0, 1))
+        c = wall_us(lambda i: graphs[i & 1]())
+        ev = []
+        for i in range(50):
+          e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+          e0.record(); graphs[i & 1](); e1.record(); ev.append((e0, e1))
+        torch.cuda.synchronize()
+        gpu_g = sum(x.elapsed_time(y) for x, y in ev) / len(ev) * 1e3
+        print(f"{name}: HIP graph replay of the single call {c:.0f} us/agg wall, {gpu_g:.0f} us GPU time (HIP events); "
+              f"same bits as the eager call: {same}", flush=True)
+        # and without any collective (what the launches alone cost): the unsharded rule on the same shard
+        eager = wall_us(lambda i: bm.bulyan(stacks[i & 1], f))
+        g1 = [GraphedCall(lambda s=s: bm.bulyan(stacks[s], f)) for s in (0, 1)]
+        rep = wall_us(lambda i: g1[i & 1]())
+        print(f"{name}: no collective: eager {eager:.0f} us/agg wall, graph replay {rep:.0f} us/agg wall", flush=True)
+      except Exception as err:  # noqa: BLE001
+        print(f"{name}: HIP graph capture failed: {err!r}", flush=True)
+      if "--only-c4" in sys.argv:
+        break
     else:
       gar = "krum" if "krum" in name else "median"
       h = n - f

@@ -621,3 +621,52 @@ def test_brute_at_shapes_beyond_enumeration(bm, n, f, kind):
   for i in sel:
     acc = acc + rows[i]
   assert same_bits(bm.brute(rows, f), acc.cpu().div_(n - f))
+
+
+# ---------------------------------------------------------------------------- #
+# HIP graphs of whole rules (the launch-bound regime of a rank of an 8-GPU job)
+
+def test_graphed_calls_replay_the_rules(bm):
+  """byzantinemomentum_amd.graphs.GraphedCall: a rule over a fixed set of row buffers recorded into a HIP graph gives,
+  at every replay, the bits of the eager call on the CURRENT contents of those buffers — also after the contents
+  changed, also with the ranking cache of gars.py warm (the recording must hold the distance pass, not a cached
+  ranking), and for the single-call sharded rules with their all-reduce inside (one-rank RCCL group, forced
+  collectives: what a rank of a multi-GPU job records)."""
+  import socket
+  import torch.distributed as dist
+  from byzantinemomentum_amd.graphs import GraphedCall
+  from byzantinemomentum_amd.sharded import ShardedAggregator
+  n, f, d = 25, 5, 1396800  # one rank's shard of C4 at 8 GPUs
+  gen = torch.Generator(device=DEV).manual_seed(12)
+  mu = 0.1 * torch.randn(d, device=DEV, generator=gen)
+  rows = [mu + s * torch.randn(d, device=DEV, generator=gen) for s in torch.linspace(0.5, 1.5, n).tolist()]
+  calls = {"bulyan": lambda: bm.bulyan(rows, f), "krum": lambda: bm.krum(rows, f), "median": lambda: bm.median(rows),
+           "trmean": lambda: bm.trmean(rows, f), "aksel": lambda: bm.aksel(rows, f)}
+  graphs = {}
+  for name, fn in calls.items():
+    fn()  # (warm ranking cache)
+    graphs[name] = GraphedCall(fn)
+  for round_ in range(3):
+    for name, fn in calls.items():
+      want = fn().clone()
+      got = graphs[name]()
+      assert torch.equal(got, want), (name, round_)
+    # other contents at the same addresses: the ranking changes (row 3 becomes an outlier, then row 7)
+    rows[3 + 4 * round_].mul_(4.0)
+    torch.cuda.synchronize()
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+  dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+  try:
+    agg = ShardedAggregator(force_collectives=True)
+    assert agg.native is not None and agg.single_call
+    g_b = GraphedCall(lambda: agg.bulyan(rows, f))
+    g_k = GraphedCall(lambda: agg.krum(rows, f))
+    for round_ in range(2):
+      assert torch.equal(g_b(), bm.bulyan(rows, f)) and torch.equal(g_k(), bm.krum(rows, f))
+      rows[11].mul_(-3.0)
+      torch.cuda.synchronize()
+  finally:
+    dist.destroy_process_group()

@@ -269,3 +269,11 @@ def test_alloc_rows_layout_on_cpu():
     layout.alloc_rows(0, 10, "cpu")
   with pytest.raises(ValueError):
     layout.alloc_rows(2, 10, "cpu", skew=100)
+
+
+def test_graphed_call_needs_a_gpu():
+  import byzantinemomentum_amd as bm
+  if torch.cuda.is_available():
+    pytest.skip("GPU present: covered by tests/test_gpu_parity_r3.py")
+  with pytest.raises(RuntimeError, match="HIP graphs"):
+    bm.graphs.GraphedCall(lambda: None)
