@@ -625,8 +625,8 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
       out["cge_c2"] = entry(ms_c, 4 * d * n + 4 * d * (n - f + 1), config=f"cge.py:28-57, n={n}, f={f}, d={d}")
       ms_b = timed_loop(lambda i: bm.brute(stacks[i & 1], f), 6, 2, timer, "brute_n25")
       out["brute_n25"] = entry(ms_b, 4 * d * n + 4 * d * (n - f + 1),
-                               config=f"brute.py:32-80, n={n}, f={f} (53 130 subsets searched on the host from the "
-                                      f"device's distances: one synchronisation), d={d}")
+                               config=f"brute.py:32-80, n={n}, f={f} (the first of the 53 130 subsets of smallest diameter, found "
+                                      f"on the host from the device's distances without enumerating them: one synchronisation), d={d}")
     del stacks
     torch.cuda.empty_cache()
   n, f, d = 25, 5, D_WRN
