@@ -9,14 +9,18 @@ HBM.  One "step" = one pass of the path over one batch = one median + one trimme
 other single-GPU configurations (C3 Multi-Krum n=51, C4 Bulyan n=25, C5 full step at d=36.5 M), each
 with its algorithmic bytes and fraction of the 8 TB/s HBM roofline (skip with --no-extras).
 
-N > 1 (one rank per GPU; `python bench.py --gpus N` re-executes itself under torch.distributed.run,
-and the driver's own torchrun launch is used as is): BASELINE.json configs[3] — Bulyan n=25, f=5 over a
-FIXED total d = 11 173 962 split across the ranks by shard_bounds ("strong" scaling), with the path's
-one exchange (the all-reduce of the 25x25 fp64 squared-distance partials over RCCL) inside the timed
-step; `value` = aggregations of the whole vector per second.  `per_gar` adds the communication-free
-coordinate-wise pair on the same shards and the optional all-gather of the output, and
-`single_gpu_same_workload` is the unsharded rule timed on rank 0 alone, so that the speed-up of this
-exact workload can be read off one line.
+N > 1 (one rank per GPU; `python bench.py --gpus N` re-executes itself under torch.distributed.run, and the driver's own
+torchrun launch is used as is): the SAME workload, the gradient dimension partitioned across the ranks: every rank
+holds a shard of 11 173 962 coordinates of the n = 25 gradients of an N x 11 173 962-coordinate vector ("weak" scaling:
+the work per GPU is that of the one-GPU line).  The coordinate-wise rules are independent per coordinate, so this
+path has no exchange step and no collective is issued inside the timed region; `value` = aggregations of an
+n = 25 x d = 11 173 962 stack per second over all ranks (the unit of the one-GPU line).  The path's one real exchange
+is measured in the same run, under `per_gar`: BASELINE.json configs[3] — Bulyan n=25, f=5 over a FIXED total
+d = 11 173 962 split across the ranks by shard_bounds ("strong" scaling), with the all-reduce of the 25x25 fp64
+squared-distance partials over RCCL inside the timed call (`bulyan_c4_sharded`, next to `single_gpu_same_workload`,
+the unsharded rule timed on rank 0 alone), the optional all-gather of the output, and the worker-parallel layout
+exchange.  `--workload bulyan|krum|step` makes the sharded rule / step the timed workload itself (strong scaling
+unless --scaling weak).
 
 The JSON line also carries `roofline` (algorithmic bytes / HIP-event time of the dominant kernel vs
 8 TB/s; `traffic` = HBM bytes per launch from rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this very
@@ -51,17 +55,23 @@ def parse():
   p.add_argument("--gpus", type=int, default=1)
   p.add_argument("--steps", type=int, default=50)
   p.add_argument("--warmup", type=int, default=5)
-  p.add_argument("--workload", default=None, choices=["colwise", "krum", "bulyan", "step"],
-                 help="default: colwise on one GPU, bulyan (dim-sharded, strong scaling) on several")
+  p.add_argument("--workload", default="colwise", choices=["colwise", "krum", "bulyan", "step"],
+                 help="default: colwise (BASELINE configs[1]) at every N; krum / bulyan / step: the dim-sharded rule or step")
+  p.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                 help="N > 1: weak = every rank holds --d coordinates (default for colwise, which has no exchange step), "
+                      "strong = --d coordinates in total, split by shard_bounds (default for krum / bulyan / step)")
   p.add_argument("--gar", default="krum", help="aggregation rule of --workload step")
   p.add_argument("--d", type=int, default=None, help="TOTAL number of coordinates (split across the ranks)")
-  p.add_argument("--weak", action="store_true", help="N > 1: keep d per GPU fixed instead of the total")
+  p.add_argument("--weak", action="store_true", help="same as --scaling weak")
   p.add_argument("--no-cpu-baseline", action="store_true")
   p.add_argument("--no-extras", action="store_true", help="N = 1: skip the per_gar measurements of C3/C4/C5")
   p.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 FETCH_SIZE/WRITE_SIZE passes")
   p.add_argument("--separate-rows", action="store_true",
                  help="allocate every synthetic gradient with its own torch.empty instead of byzantinemomentum_amd."
                       "layout.alloc_rows (rows of one allocation at a skewed stride): the placement A/B of DESIGN 3")
+  p.add_argument("--sharded-extras", action="store_true",
+                 help="one rank under torch.distributed.run: run the per_gar legs of the N > 1 line (sharded Bulyan with "
+                      "its all-reduce, all-gather, layout exchange) as well, so that their code is exercised on one GPU")
   p.add_argument("--graph-replay", action="store_true",
                  help="N > 1 (or one rank under torch.distributed.run): also time the sharded rule recorded into a HIP "
                       "graph, one graph per synthetic stack (byzantinemomentum_amd/graphs.py) -> per_gar.<rule>_graph_replay")
@@ -134,9 +144,11 @@ class KernelTimer:
     return sum(a.elapsed_time(b) for a, b in ps) / len(ps)
 
 
-def entry(ms, nbytes, **more):
+def entry(ms, nbytes, gpus=1, units=1, **more):
+  """One per_gar record: `nbytes` = algorithmic bytes moved by ALL `gpus` ranks in `ms`; `units` = aggregations (of the
+  metric's n x d stack) that completes; the roofline fraction is against the HBM peak of the GPUs involved."""
   return dict({"avg_ms": ms, "algorithmic_bytes": nbytes, "gbps": nbytes / ms / 1e6,
-               "frac_of_8TBps": nbytes / ms / 1e6 / HBM_PEAK_GBPS, "agg_per_s": 1e3 / ms}, **more)
+               "frac_of_8TBps": nbytes / ms / 1e6 / (HBM_PEAK_GBPS * gpus), "agg_per_s": units * 1e3 / ms}, **more)
 
 
 def timed_loop(fn, steps, warmup, timer, name):
@@ -273,6 +285,99 @@ def traffic_kernels(d2, d5):
 
 # ---------------------------------------------------------------------------- #
 
+def sharded_extras(bm, agg, dist, device, world, rank, timer, args, rule_name, d_total, extra, time_rule):
+  """The dim-sharded path with its one real exchange, on a FIXED vector of d_total coordinates split across the ranks by
+  shard_bounds (strong scaling): the rule in one C call with the all-reduce of the n x n fp64 partials inside
+  (BASELINE.json configs[3] for Bulyan), the optional all-gather of the output, the worker-parallel layout exchange, and
+  the unsharded rule on rank 0 alone for the speed-up of this exact workload.  Every figure is the max over the ranks.
+  Returns per_gar entries; `extra` receives single_gpu_same_workload."""
+  from byzantinemomentum_amd.sharded import owned_workers, shard_bounds
+  out = {}
+  n, f = (51, 12) if rule_name == "krum" else (25, 5)
+  m = n - f - 2
+  lo, hi = shard_bounds(d_total, world, rank)
+  stacks = make_stacks(n, f, hi - lo, device, 2, 4321 + rank, args.aliased_byz)
+  rule = agg.krum if rule_name == "krum" else agg.bulyan
+  rule_bytes = 4 * d_total * n + 4 * d_total * (m + 1)
+  tag = f"n={n}, f={f}, total d={d_total} over {world} ranks, max over ranks"
+
+  def over_ranks(ms):
+    t = torch.tensor([ms], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return t.item()
+
+  if time_rule:
+    # like the headline: W warm-up calls, then K calls between two barriers, wall clock, max over the ranks
+    for i in range(max(args.warmup, 3)):
+      rule(stacks[i & 1], f)
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+      rule(stacks[i & 1], f)
+    dist.barrier()
+    torch.cuda.synchronize()
+    ms = over_ranks((time.perf_counter() - t0) / args.steps * 1e3)
+    out[f"{rule_name}_{'c3' if rule_name == 'krum' else 'c4'}_sharded"] = entry(
+      ms, rule_bytes, gpus=world, config=f"{rule_name}, one C call per aggregation with the all-reduce of the {n}x{n} fp64 partial "
+                                         f"matrix inside ({'libbm_gar RCCL communicator' if agg.native is not None else 'torch.distributed'}), "
+                                         f"{tag}; wall clock of {args.steps} calls between barriers", scaling="strong")
+  result = rule(stacks[0], f)
+  ms3 = over_ranks(timed_loop(lambda i: agg.all_gather_output(result, d_total), 10, 2, timer, "x_allgather"))
+  out["allgather_output"] = entry(ms3, 4 * d_total, gpus=world, config=f"all-gather of the output slices, {tag}")
+  if args.graph_replay:
+    # the launch-bound regime (DESIGN 6): the whole aggregation — kernels and the all-reduce — as ONE graph launch.
+    # Every rank votes after its recording, so that no rank replays (and enters the collective) alone.
+    from byzantinemomentum_amd.graphs import GraphedCall
+    graphs, failure = None, None
+    try:
+      graphs = [GraphedCall(lambda s=s: rule(stacks[s], f)) for s in (0, 1)]
+    except Exception as err:  # noqa: BLE001
+      failure = repr(err)
+    vote = torch.tensor([0.0 if graphs is None else 1.0], dtype=torch.float64, device=device)
+    dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+    if vote.item() >= 1.0:
+      same = bool(torch.equal(graphs[0](), rule(stacks[0], f)))
+      ms_g = over_ranks(timed_loop(lambda i: graphs[i & 1](), 20, 3, timer, "x_graph"))
+      out[rule_name + "_graph_replay"] = dict(entry(ms_g, rule_bytes, gpus=world,
+                                                   config=f"the same sharded rule replayed from a HIP graph, {tag}"),
+                                              same_bits_as_eager=same)
+    else:
+      out[rule_name + "_graph_replay"] = {"error": failure or "the recording failed on another rank"}
+    del graphs
+  del stacks, result
+  torch.cuda.empty_cache()
+  # worker-parallel production (SURVEY 8e/f4): every rank holds the FULL-length gradients of its own workers
+  # (rank p runs workers p, p + P, ...); ONE all-to-all turns worker-major into dimension-major, then the rule
+  mine = owned_workers(n, world, rank)
+  gen = torch.Generator(device=device).manual_seed(999 + rank)
+  produced = new_rows(max(len(mine), 1), d_total, device)[:len(mine)]
+  for r in produced:
+    r.copy_(0.1 * torch.randn(d_total, device=device, generator=gen))
+  ms_a2a = over_ranks(timed_loop(lambda i: agg.to_dim_sharded(produced, n, d_total), 8, 2, timer, "x_a2a"))
+  ms_wp = over_ranks(timed_loop(lambda i: rule(agg.to_dim_sharded(produced, n, d_total), f), 8, 2, timer, "x_wp"))
+  sent = 4 * d_total * len(owned_workers(n, world, 0)) * (world - 1) // world
+  for key, val in (("layout_exchange", ms_a2a), (rule_name + "_from_worker_parallel", ms_wp)):
+    out[key] = dict(entry(val, 4 * d_total * n + (4 * d_total * (m + 1) if key != "layout_exchange" else 0), gpus=world,
+                          config=f"worker-major -> dimension-major by one all-to-all (RCCL), {tag}"
+                                 + ("" if key == "layout_exchange" else f", then {rule_name}")),
+                    bytes_sent_per_rank=sent)
+  del produced
+  torch.cuda.empty_cache()
+  single = None
+  if rank == 0:
+    full = make_stacks(n, f, d_total, device, 2, 4321, args.aliased_byz)
+    fn = bm.krum if rule_name == "krum" else bm.bulyan
+    single = timed_loop(lambda i: fn(full[i & 1], f), 10, 3, timer, "x_single")
+    del full
+    torch.cuda.empty_cache()
+  dist.barrier()
+  if rank == 0:
+    extra["single_gpu_same_workload"] = {"value": 1e3 / single, "unit": "agg/s", "ms": single,
+                                         "note": f"the unsharded {rule_name} on rank 0 alone, same total d = {d_total}"}
+  return out
+
+
 def main():
   global SEPARATE_ROWS
   args = parse()
@@ -311,12 +416,17 @@ def main():
   from byzantinemomentum_amd.sharded import ShardedAggregator, shard_bounds
   bm._lib.load()
 
-  workload = args.workload or ("colwise" if world == 1 else "bulyan")
-  d_total = args.d or (D_WRN if workload == "step" else D_RESNET18)
-  if world > 1 and args.weak:
-    d_total *= world
-  lo, hi = shard_bounds(d_total, world, rank)
-  d = hi - lo  # this rank's coordinates
+  workload = args.workload
+  # colwise has no exchange step: its shards are independent units, every rank gets the one-GPU workload ("weak");
+  # the distance-based rules and the step exchange statistics: a fixed vector split across the ranks ("strong")
+  scaling = args.scaling or ("weak" if (args.weak or workload == "colwise") else "strong")
+  base_d = args.d or (D_WRN if workload == "step" else D_RESNET18)
+  if scaling == "weak":
+    d_total, d = base_d * world, base_d  # every rank: base_d coordinates of a (base_d x world)-coordinate vector
+  else:
+    d_total = base_d
+    lo, hi = shard_bounds(d_total, world, rank)
+    d = hi - lo  # this rank's coordinates
   agg = ShardedAggregator(force_collectives=distributed)
   if distributed and agg.native is not None:
     # the library's own RCCL communicator must work on EVERY rank, or every rank leaves it together (a rank
@@ -347,7 +457,9 @@ def main():
   if workload == "colwise":
     n, f = 25, 5
     stacks = make_stacks(n, f, d, device, 2, 1234 + rank, args.aliased_byz)
-    aggs_per_step = 2
+    # the unit of the metric is one aggregation of an n x 11.2 M stack: with weak scaling every rank completes two per step
+    units = d_total // base_d if scaling == "weak" else 1
+    aggs_per_step = 2 * units
     algo_bytes = {"median": 4 * d_total * (n + 1), "trmean": 4 * d_total * (n + 1)}
 
     def step(i, timed):
@@ -358,7 +470,8 @@ def main():
       else:
         bm.median(st)
         bm.trmean(st, f)
-    workload_name = f"C2 colwise: median + trmean(f={f}), n={n}, total d={d_total}"
+    workload_name = (f"C2 colwise: median + trmean(f={f}), n={n}, total d={d_total}"
+                     + (f" = {world} shards of {d} coordinates, one per rank, no collective" if world > 1 else ""))
     dominant_kernel = "colwise_"  # colwise_kernel (plain form) or colwise_burst_kernel
   elif workload == "step":
     from byzantinemomentum_amd.step import AggregationStep
@@ -416,76 +529,31 @@ def main():
     elapsed = t.item()
 
   for name, nbytes in algo_bytes.items():
-    per_gar[name] = entry(timer.mean_ms(name), nbytes, config=workload_name)
-
-  # ---- N > 1: the same shards through the communication-free pair, the all-gather, one-GPU reference ----
-  if distributed and workload in ("bulyan", "krum"):  # (also one rank under torchrun: the same code path, testable on one GPU)
-    ms = timed_loop(lambda i: bm.median(stacks[i & 1]), 10, 2, timer, "x_median")
-    ms2 = timed_loop(lambda i: bm.trmean(stacks[i & 1], f), 10, 2, timer, "x_trmean")
-    out = rule(stacks[0], f)
-    ms3 = timed_loop(lambda i: agg.all_gather_output(out, d_total), 10, 2, timer, "x_allgather")
-    for key, val in (("median_sharded", ms), ("trmean_sharded", ms2), ("allgather_output", ms3)):
-      t = torch.tensor([val], dtype=torch.float64, device=device)
+    ms = timer.mean_ms(name)
+    if distributed:  # the slowest rank's kernel time
+      t = torch.tensor([ms], dtype=torch.float64, device=device)
       dist.all_reduce(t, op=dist.ReduceOp.MAX)
-      nbytes = 4 * d_total * (n + 1) if key != "allgather_output" else 4 * d_total
-      per_gar[key] = entry(t.item(), nbytes, config=f"same shards, n={n}, total d={d_total}, max over ranks")
-    if args.graph_replay:
-      # the launch-bound regime: the whole aggregation — kernels and the all-reduce — as ONE graph launch.
-      # Every rank votes after its recording, so that no rank replays (and enters the collective) alone.
-      from byzantinemomentum_amd.graphs import GraphedCall
-      graphs, failure = None, None
-      try:
-        graphs = [GraphedCall(lambda s=s: rule(stacks[s], f)) for s in (0, 1)]
-      except Exception as err:  # noqa: BLE001
-        failure = repr(err)
-      vote = torch.tensor([0.0 if graphs is None else 1.0], dtype=torch.float64, device=device)
-      dist.all_reduce(vote, op=dist.ReduceOp.MIN)
-      if vote.item() >= 1.0:
-        same = bool(torch.equal(graphs[0](), rule(stacks[0], f)))
-        ms_g = timed_loop(lambda i: graphs[i & 1](), 20, 3, timer, "x_graph")
-        t = torch.tensor([ms_g], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        per_gar[workload + "_graph_replay"] = dict(entry(t.item(), algo_bytes[workload],
-                                                         config=f"the same sharded rule replayed from a HIP graph, max over ranks"),
-                                                   same_bits_as_eager=same)
-      else:
-        per_gar[workload + "_graph_replay"] = {"error": failure or "the recording failed on another rank"}
-      del graphs
+      ms = t.item()
+    per_gar[name] = entry(ms, nbytes, gpus=world, units=aggs_per_step // 2 if workload == "colwise" else 1,
+                          config=workload_name)
+
+  # ---- N > 1: the path's real exchange (sharded Bulyan / Krum with its all-reduce), all-gather, layout exchange ----
+  # (also one rank under torchrun with --sharded-extras or --workload bulyan|krum: the same code path, testable on one GPU)
+  cpu_sample = None
+  if world == 1 and rank == 0 and not args.no_cpu_baseline and workload in ("bulyan", "krum"):
+    cpu_sample = [g[:min(d, 1 << 20)].clone() for g in stacks[0]]  # (the stacks go before the extras run)
+  if distributed and workload in ("bulyan", "krum"):
     del stacks
     torch.cuda.empty_cache()
-    # worker-parallel production: every rank holds the FULL-length gradients of its own workers
-    # (rank p runs workers p, p + P, ...); ONE all-to-all turns worker-major into dimension-major, then the rule
-    from byzantinemomentum_amd.sharded import owned_workers
-    mine = owned_workers(n, world, rank)
-    gen = torch.Generator(device=device).manual_seed(999 + rank)
-    produced = new_rows(max(len(mine), 1), d_total, device)[:len(mine)]
-    for r in produced:
-      r.copy_(0.1 * torch.randn(d_total, device=device, generator=gen))
-    ms_a2a = timed_loop(lambda i: agg.to_dim_sharded(produced, n, d_total), 8, 2, timer, "x_a2a")
-    ms_wp = timed_loop(lambda i: rule(agg.to_dim_sharded(produced, n, d_total), f), 8, 2, timer, "x_wp")
-    for key, val in (("layout_exchange", ms_a2a), (workload + "_from_worker_parallel", ms_wp)):
-      t = torch.tensor([val], dtype=torch.float64, device=device)
-      dist.all_reduce(t, op=dist.ReduceOp.MAX)
-      sent = 4 * d_total * len(owned_workers(n, world, 0)) * (world - 1) // world
-      per_gar[key] = dict(entry(t.item(), 4 * d_total * n + (4 * d_total * (m + 1) if key != "layout_exchange" else 0),
-                                config=f"worker-major -> dimension-major by one all-to-all (RCCL), n={n}, total d={d_total}, "
-                                       f"{world} ranks" + ("" if key == "layout_exchange" else f", then {workload}")),
-                          bytes_sent_per_rank=sent)
-    del produced
+    per_gar.update(sharded_extras(bm, agg, dist, device, world, rank, timer, args, workload, base_d, extra, time_rule=False))
+  elif distributed and workload == "colwise" and not args.no_extras and (world > 1 or args.sharded_extras):
+    del stacks
     torch.cuda.empty_cache()
-    single = None
-    if rank == 0:
-      full = make_stacks(n, f, d_total, device, 2, 4321, args.aliased_byz)
-      fn = bm.krum if workload == "krum" else bm.bulyan
-      single = timed_loop(lambda i: fn(full[i & 1], f), 10, 3, timer, "x_single")
-      del full
-    dist.barrier()
-    if rank == 0 and world > 1:
-      extra["single_gpu_same_workload"] = {"value": 1e3 / single, "unit": "agg/s", "ms": single,
-                                           "note": "the unsharded rule on rank 0 alone, same total d"}
+    per_gar.update(sharded_extras(bm, agg, dist, device, world, rank, timer, args, "bulyan", D_RESNET18, extra, time_rule=True))
+    stacks = None
 
   # ---- N = 1: the other single-GPU configurations, briefly ----
-  if world == 1 and workload == "colwise" and not args.no_extras and rank == 0:
+  if world == 1 and workload == "colwise" and not args.no_extras and rank == 0 and stacks is not None:
     first = stacks[0]
     if not args.no_cpu_baseline:
       extra["cpu_baseline"] = cpu_baseline_colwise(first, f)
@@ -493,16 +561,20 @@ def main():
     torch.cuda.empty_cache()
     per_gar.update(extras_single_gpu(bm, device, timer, args.aliased_byz, cpu_baseline=not args.no_cpu_baseline))
   elif world == 1 and rank == 0 and not args.no_cpu_baseline:
-    if workload == "colwise":
+    if workload == "colwise" and stacks is not None:
       extra["cpu_baseline"] = cpu_baseline_colwise(stacks[0], f)
-    elif workload in ("krum", "bulyan"):
-      extra["cpu_baseline"] = cpu_baseline_distance(stacks[0], f, workload, min(d, 1 << 20))  # bounded sample
+    elif cpu_sample is not None:
+      base = cpu_baseline_distance(cpu_sample, f, workload, len(cpu_sample[0]))  # bounded sample, scaled to d
+      base["value"] *= len(cpu_sample[0]) / d
+      base["sample"] += f" (then to d={d})"
+      extra["cpu_baseline"] = base
 
   if rank == 0:
     dominant = max(algo_bytes, key=lambda k: per_gar[k]["avg_ms"])
     dk = per_gar[dominant]
     traffic, per_kernel = None, None
-    if world == 1 and not args.no_traffic and "BM_BENCH_CHILD" not in os.environ:
+    # (not under torch.distributed.run: the child processes would inherit the launcher's rendezvous environment)
+    if world == 1 and not distributed and not args.no_traffic and "BM_BENCH_CHILD" not in os.environ:
       child = ["--workload", workload, "--gar", args.gar] + (["--d", str(args.d)] if args.d else []) + \
           (["--aliased-byz"] if args.aliased_byz else [])
       with_extras = workload == "colwise" and not args.no_extras and args.d is None
@@ -522,7 +594,7 @@ def main():
       "unit": "agg/s",
       "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
       "ms_per_step": elapsed / args.steps * 1e3,
-      "higher_is_better": True, "scaling": "weak" if (world > 1 and args.weak) else "strong", "vs_baseline": None,
+      "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
       "dtype": "f32", "data": "synthetic",
       "config": {"workload": workload_name, "n_workers": n, "f": f, "d_total": d_total, "d_per_gpu": d,
                  "byzantine_rows": "aliased" if args.aliased_byz else "distinct buffers",
