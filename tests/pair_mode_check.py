@@ -117,6 +117,10 @@ def check_stack(kind, n, f, d, seed):
     assert sorted(bm.gars.aksel_selection(dev, f)) == sorted(oa[:c]), (kind, n, "aksel selection")
   if n <= 13:
     assert bm.gars.brute_selection(dev, f) == O.brute_selection(rows, f, "f64"), (kind, n, "brute selection")
+  else:
+    # beyond enumeration (53 130 subsets at n = 25, 1.6e11 at n = 51): the oracle's checker decides whether brute.py:47-68
+    # would return this selection, on the distances the selection was made from (their accuracy is checked above)
+    assert O.brute_selection_is_the_references(sq.sqrt().numpy(), f, bm.gars.brute_selection(dev, f)), (kind, n, "brute")
   return rel
 
 
