@@ -260,21 +260,16 @@ def brute_select_host(dist_host, n, f):
 def brute_selection(gradients, f, **kwargs):
   """Index set (ascending) of the n-f rows of smallest diameter (aggregators/brute.py:32-68)."""
   n, d, device = _validate(gradients)
-  # brute keeps non-finite distances as they are and skips the subsets that contain one.  The subset search is host
-  # work: the n x n matrix comes back through page-locked memory (torch's caching host allocator: no staging copy,
-  # no allocation after the first call), one stream synchronisation, the square roots taken on the host
-  sq = pairwise_sqdist(gradients)
-  host = torch.empty((n, n), dtype=torch.float64, pin_memory=True)
-  host.copy_(sq, non_blocking=True)
-  torch.cuda.current_stream(device).synchronize()
-  return brute_select_host(host.sqrt_(), n, f)
+  # brute keeps non-finite distances as they are and skips the subsets that contain one
+  dist = pairwise_sqdist(gradients).sqrt().cpu().contiguous()  # the subset search is host work
+  return brute_select_host(dist, n, f)
 
 
 def brute(gradients, f, **kwargs):
   """Brute rule (aggregators/brute.py:70-80): mean of the minimum-diameter subset, index order."""
   n, d, device = _validate(gradients)
   sel = brute_selection(gradients, f)
-  idx = torch.tensor(sel, dtype=torch.int32).pin_memory().to(device, non_blocking=True)  # (stream-ordered before the mean)
+  idx = torch.tensor(sel, dtype=torch.int32, device=device)
   return selected_mean(gradients, idx, n - f)
 
 
