@@ -635,15 +635,17 @@ def step_algorithmic_bytes(d, n, f, gar):
   return 4 * d * ((h + 2 * h + 3) + gar_units + 8)
 
 
-def attack_search(bm, honests, n, f, d, evals=16):
+def attack_search(bm, honests, n, f, d, evals=16, gar="krum"):
   """The factor search of the "identical" attacks (attacks/identical.py:67-77, the reference's default
-  factor=-16) against Multi-Krum at C3: wall-clock of the whole search, scalar form (one distance pass over
-  h+2 rows, then host only) and the reference's form (the rule on the vectors once per evaluation)."""
+  factor=-16), wall-clock of the whole search in its two forms.  Against Multi-Krum (C3): scalar form (one distance
+  pass over h+2 rows, then host only) and the reference's form (the rule on the vectors once per evaluation).
+  Against the median (C2 shape): every candidate as the middle of (candidate, lo, hi), lo / hi being two order
+  statistics of the honest rows formed once per search (the key stays `scalar_form_ms`), and the reference's form."""
   from byzantinemomentum_amd.step import AggregationStep
   avg, _, direction = bm.stats.stack_stats_async(honests, scale=1.0, attack="empire", direction=True)
-  res = {"config": f"empire against krum, n={n}, f={f}, d={d}, {evals} evaluations, one GPU"}
+  res = {"config": f"empire against {gar}, n={n}, f={f}, d={d}, {evals} evaluations, one GPU"}
   for mode, reps in (("auto", 10), ("generic", 3)):
-    runner = AggregationStep(n, f, f, gar="krum", attack_evals=evals, line_search=mode, nb_past=0)
+    runner = AggregationStep(n, f, f, gar=gar, attack_evals=evals, line_search=mode, nb_past=0)
     runner._search_factor(honests, avg, direction)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -687,6 +689,8 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
     else:
       if cpu_baseline:
         c4_sample = [g[:1 << 18].clone() for g in stacks[0]]
+      if "BM_BENCH_CHILD" not in os.environ:  # (the PMC child keeps the per-launch traffic of the C2 column kernel clean)
+        out["attack_search_c2_median"] = attack_search(bm, stacks[0][:n - f], n, f, d, gar="median")
       # the other rules of aggregators/ on the C2 / C4 shape (n = 25, f = 5, d = 11.2 M)
       c = (n + 1) // 2
       ms_a = timed_loop(lambda i: bm.aksel(stacks[i & 1], f), 12, 3, timer, "aksel_c2")

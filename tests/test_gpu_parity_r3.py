@@ -670,3 +670,40 @@ def test_graphed_calls_replay_the_rules(bm):
       torch.cuda.synchronize()
   finally:
     dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------- #
+# The factor search against the median from two order statistics of the honest rows
+
+@pytest.mark.parametrize("n,f,d,attack,negative", [(25, 5, 1000003, "empire", False), (25, 11, 262144, "little", True),
+                                                   (11, 2, 8400000, "empire", False)])
+def test_median_factor_search_from_two_order_statistics_on_gpu(bm, n, f, d, attack, negative):
+  """attacks/identical.py:67-77 against the median: `auto` takes every candidate as the middle of (candidate, lo, hi)
+  (step.py), `generic` runs the median over the n rows once per evaluation like the reference.  Same candidates and
+  the same objective at each, bit for bit — unaligned length, the burst form of the column kernel (8.4 M
+  coordinates), columns with ties and a NaN."""
+  from byzantinemomentum_amd.step import AggregationStep
+  h = n - f
+  gen = torch.Generator(device=DEV).manual_seed(31)
+  base = 0.2 * torch.randn(d, device=DEV, generator=gen)
+  honests = [base + (0.5 + 0.05 * i) * torch.randn(d, device=DEV, generator=gen) for i in range(h)]
+  for g in honests:
+    g[::9] = g[::9].round()
+  traces = {}
+  for mode in ("auto", "generic"):
+    step = AggregationStep(n, f, f, gar="median", momentum=0.9, dampening=0.9, momentum_at="update", attack=attack,
+                           attack_factor=1.1, nb_past=0, attack_evals=10, attack_negative=negative, line_search=mode)
+    out = step.run([g.clone() for g in honests])
+    traces[mode] = (step.last_factor, list(step.last_search), out)
+  (fa, sa, oa), (fg, sg, og) = traces["auto"], traces["generic"]
+  assert fa == fg and sa == sg and len(sa) == 10 and max(y for _, y in sa) > 0
+  assert torch.equal(oa, og)
+  # a NaN in one honest row: the rule is NaN there whatever the candidate, both forms say so
+  honests[3][17] = math.nan
+  got = {}
+  for mode in ("auto", "generic"):
+    step = AggregationStep(n, f, f, gar="median", momentum_at="update", attack=attack, nb_past=0, attack_evals=3,
+                           attack_negative=negative, line_search=mode)
+    step.run([g.clone() for g in honests])
+    got[mode] = step.last_search
+  assert all(xa == xg and math.isnan(ya) and math.isnan(yg) for (xa, ya), (xg, yg) in zip(got["auto"], got["generic"]))
