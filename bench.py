@@ -640,7 +640,8 @@ def attack_search(bm, honests, n, f, d, evals=16, gar="krum"):
   factor=-16), wall-clock of the whole search in its two forms.  Against Multi-Krum (C3): scalar form (one distance
   pass over h+2 rows, then host only) and the reference's form (the rule on the vectors once per evaluation).
   Against the median (C2 shape): every candidate as the middle of (candidate, lo, hi), lo / hi being two order
-  statistics of the honest rows formed once per search (the key stays `scalar_form_ms`), and the reference's form."""
+  statistics of the honest rows formed once per search (the key stays `scalar_form_ms`), and the reference's form.
+  Against Bulyan (C4 shape): every candidate ranked on the host from one distance pass, pass 2 alone on the vectors."""
   from byzantinemomentum_amd.step import AggregationStep
   avg, _, direction = bm.stats.stack_stats_async(honests, scale=1.0, attack="empire", direction=True)
   res = {"config": f"empire against {gar}, n={n}, f={f}, d={d}, {evals} evaluations, one GPU"}
@@ -691,6 +692,10 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
         c4_sample = [g[:1 << 18].clone() for g in stacks[0]]
       if "BM_BENCH_CHILD" not in os.environ:  # (the PMC child keeps the per-launch traffic of the C2 column kernel clean)
         out["attack_search_c2_median"] = attack_search(bm, stacks[0][:n - f], n, f, d, gar="median")
+        try:  # (Bulyan: every candidate ranked on the host from ONE distance pass, only pass 2 on the vectors)
+          out["attack_search_c4_bulyan"] = attack_search(bm, stacks[0][:n - f], n, f, d, gar="bulyan")
+        except Exception as err:  # noqa: BLE001  (a side entry must not take the line down)
+          out["attack_search_c4_bulyan"] = {"error": repr(err)}
       # the other rules of aggregators/ on the C2 / C4 shape (n = 25, f = 5, d = 11.2 M)
       c = (n + 1) // 2
       ms_a = timed_loop(lambda i: bm.aksel(stacks[i & 1], f), 12, 3, timer, "aksel_c2")

@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported before the CDLL, see above)
 _PKG_DIR = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _PKG_DIR / "libbm_gar.so"
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 MAX_ROWS = 64
 EINVAL = -100000
 ENOCOMM, ECOMM = -100001, -100002
@@ -119,6 +119,8 @@ SIGNATURES = {
                                          ctypes.c_void_p]),
   "bm_attack_line_search": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+  "bm_attack_ranking": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                       ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),
 }
 
 class Search(ctypes.Structure):

@@ -133,12 +133,12 @@ struct AttackGeometry {
   }
 };
 
-// Multi-Krum ranking on the host with the semantics of krum_rank_kernel (pairwise.hip) / krum.py:44-62:
-// distances = sqrt, non-finite -> +inf; score = ascending fp64 sum of the n-f-1 smallest of the row;
-// stable order of the scores (ties to the lower index).
-void krum_order(const std::vector<double>& sq, int n, int f, std::vector<int>& order) {
+// Multi-Krum / Bulyan ranking on the host with the semantics of krum_rank_kernel (pairwise.hip) / krum.py:44-62,
+// bulyan.py:48-62: distances = sqrt, non-finite -> +inf; score = ascending fp64 sum of the `take` smallest of the
+// row; stable order of the scores (ties to the lower index).
+// `take`: distances summed per row — n-f-1 for Krum (krum.py:59-60), m for Bulyan (bulyan.py:56-62)
+void rank_order(const std::vector<double>& sq, int n, int take, std::vector<int>& order) {
   std::vector<double> score(n), row;
-  int take = n - f - 1;
   take = std::max(0, std::min(take, n - 1));
   for (int i = 0; i < n; ++i) {
     row.clear();
@@ -169,7 +169,7 @@ int select(const AttackGeometry& g, int f, int rule, int m, double t, std::vecto
   g.sqdist(t, sq);
   if (rule == BM_RULE_KRUM) {
     std::vector<int> order;
-    krum_order(sq, n, f, order);
+    rank_order(sq, n, n - f - 1, order);
     sel.assign(order.begin(), order.begin() + m);
     return 0;
   }
@@ -235,6 +235,26 @@ extern "C" int bm_attack_objective(const double* ext, int h, int k, int f, int r
   if (count_out != nullptr) *count_out = (int32_t)sel.size();
   std::sort(sel.begin(), sel.end());
   *y_out = g.objective(sel, t);
+  return 0;
+}
+
+// The ranking bm_krum_rank would give for honests + [avg + t*att] * k, from the scalars alone: what the factor search
+// needs of the distance pass when the rule's output is NOT a function of inner products (Bulyan: its second pass
+// runs on the vectors, bulyan.py:64-84, but the ranking that feeds it is).  Indices >= h are the Byzantine copies.
+extern "C" int bm_attack_ranking(const double* ext, int h, int k, int f, int mode, int m, double t,
+                                 int32_t* order_out) {
+  const int n = h + k;
+  if (ext == nullptr || order_out == nullptr || h < 1 || k < 0 || n > BM_MAX_ROWS || f < 0 ||
+      (mode != BM_RANK_KRUM && mode != BM_RANK_BULYAN))
+    return BM_EINVAL;
+  if (m <= 0) m = n - f - 2;
+  if (m < 1 || m > n) return BM_EINVAL;
+  const AttackGeometry g(ext, h, k);
+  std::vector<double> sq;
+  g.sqdist(t, sq);
+  std::vector<int> order;
+  rank_order(sq, n, mode == BM_RANK_KRUM ? n - f - 1 : m, order);
+  for (int i = 0; i < n; ++i) order_out[i] = order[i];
   return 0;
 }
 

@@ -4,8 +4,10 @@ Host logic of libbm_gar.so (csrc/linesearch.cpp), no device work here:
   line_maximize          the exploration routine around any Python callable, driven through the bm_search_* cursor;
   attack_objective       one evaluation of |GAR(honests + [avg + t*att]*k) - avg|^2 from scalars only,
   attack_line_search     the whole search from scalars only
-for the rules whose output is the mean of a selected subset (krum, brute, average).  The scalars are
-the (h+2) x (h+2) squared distances among the h honest rows, their average and average + att: ONE
+for the rules whose output is the mean of a selected subset (krum, brute, average), and
+  attack_ranking         the ranking of a candidate stack from scalars only (Bulyan ranks its candidates with it and
+                         runs only its second pass on the vectors).
+The scalars are the (h+2) x (h+2) squared distances among the h honest rows, their average and average + att: ONE
 distance pass instead of `evals` evaluations of the rule on d-sized vectors.
 """
 
@@ -56,6 +58,18 @@ def attack_objective(ext, h, k, f, rule, t, m=None):
                                      ctypes.cast(sel, ctypes.c_void_p),
                                      ctypes.cast(ctypes.pointer(count), ctypes.c_void_p)), "bm_attack_objective")
   return y.value, list(sel[:count.value])
+
+
+def attack_ranking(ext, h, k, f, mode, t, m=None):
+  """The ranking bm_krum_rank would give for honests + [avg + t*att] * k (mode "krum" / "bulyan"), from the scalars:
+  n indices, those >= h being Byzantine copies.  Bulyan's factor search ranks with it and runs only the second pass
+  of the rule on the vectors (step.py)."""
+  lib = _lib.load()
+  order = (ctypes.c_int32 * _lib.MAX_ROWS)()
+  mode_id = {"krum": _lib.RANK_KRUM, "bulyan": _lib.RANK_BULYAN}[mode]
+  _lib.check(lib.bm_attack_ranking(_ext_pointer(ext, h), h, k, f, mode_id, m or 0, float(t),
+                                   ctypes.cast(order, ctypes.c_void_p)), "bm_attack_ranking")
+  return list(order[:h + k])
 
 
 def attack_line_search(ext, h, k, f, rule, evals=16, negative=False, m=None):

@@ -138,7 +138,21 @@ class AggregationStep:
         m=self.gar_args.get("m"))
       return factor
 
-    rule = lambda cand: self._aggregate(list(honests) + [cand] * k)  # noqa: E731
+    rule = lambda cand, t: self._aggregate(list(honests) + [cand] * k)  # noqa: E731
+    n = h + k
+    if self.line_search == "auto" and self.gar == "bulyan" and k >= 1 and h + 2 <= 64 and hasattr(ops, "bulyan_pass2") \
+       and not (set(self.gar_args) - {"m"}):
+      # Bulyan's second pass needs the vectors, its ranking does not: the distances among honests + [avg + t*dir] * k
+      # are functions of the inner products of ONE distance pass over honests + [avg, avg + dir] (as for krum above),
+      # so every candidate is ranked on the host and costs pass 2 alone (m + 1 row passes instead of n + m + 1)
+      m = self.gar_args.get("m") or n - self.f_decl - 2
+      unit = torch.empty_like(h_avg)
+      ops.multi_fma3([unit], [h_avg], [direction], 1.0, 1.0)
+      ext = agg.global_sqdist(list(honests) + [h_avg, unit]).cpu().contiguous()
+
+      def rule(cand, t):  # noqa: F811
+        order = linesearch.attack_ranking(ext, h, k, self.f_decl, "bulyan", t, m)
+        return ops.bulyan_pass2(list(honests) + [cand] * k, ops.index_tensor(order + [0] * (64 - n), h_avg), self.f_decl, m)
     if self.line_search == "auto" and self.gar == "median" and k >= 1:
       # The lower median of the h honest values and k copies of ONE value b is monotone in b, equals b while b lies
       # between two order statistics of the honest values and stays at them outside: median(honests + [b] * k) =
@@ -148,13 +162,13 @@ class AggregationStep:
       # inputs, no arithmetic — hence the same objective, bit for bit, as evaluating the rule on the n rows.
       lo = agg.median(list(honests) + [torch.full_like(h_avg, -math.inf)] * k)
       hi = agg.median(list(honests) + [torch.full_like(h_avg, math.inf)] * k)
-      rule = lambda cand: agg.median([cand, lo, hi])  # noqa: E731
+      rule = lambda cand, t: agg.median([cand, lo, hi])  # noqa: E731
 
     def scape(x):
       t = -x if self.attack_negative else x
       cand = torch.empty_like(h_avg)
       ops.multi_fma3([cand], [h_avg], [direction], 1.0, t)
-      out = rule(cand)
+      out = rule(cand, t)
       sq = ops.pairwise_sqdist([out, h_avg])[0, 1].reshape(1)  # aggregated.sub_(grad_avg); dot with itself
       agg.all_reduce_sum(sq)
       return sq.item()

@@ -367,6 +367,11 @@ int bm_attack_objective(const double* ext, int h, int k, int f, int rule, int m,
                         int32_t* sel_out, int32_t* count_out);
 int bm_attack_line_search(const double* ext, int h, int k, int f, int rule, int m, int evals, int negative,
                           double* factor_out, double* trace_out);
+/* The ranking bm_krum_rank(mode, m) would give for honests + [avg + t*att] * k, from the same scalars (order_out: n
+ * int32, indices >= h being Byzantine copies): for the rules whose output needs the vectors but whose ranking does not
+ * — Bulyan (aggregators/bulyan.py:48-62 rank, :64-84 second pass): a candidate of the factor search then costs
+ * bm_bulyan_pass2 with this ranking instead of a distance pass over the n rows as well.  m <= 0: n - f - 2. */
+int bm_attack_ranking(const double* ext, int h, int k, int f, int mode, int m, double t, int32_t* order_out);
 
 #ifdef __cplusplus
 }

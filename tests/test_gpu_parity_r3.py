@@ -707,3 +707,29 @@ def test_median_factor_search_from_two_order_statistics_on_gpu(bm, n, f, d, atta
     step.run([g.clone() for g in honests])
     got[mode] = step.last_search
   assert all(xa == xg and math.isnan(ya) and math.isnan(yg) for (xa, ya), (xg, yg) in zip(got["auto"], got["generic"]))
+
+
+@pytest.mark.parametrize("n,f,d,attack,negative", [(25, 5, 1000003, "empire", False), (15, 3, 300000, "little", True)])
+def test_bulyan_factor_search_ranks_from_scalars_on_gpu(bm, n, f, d, attack, negative):
+  """attacks/identical.py:67-77 against Bulyan: `auto` ranks every candidate stack on the host from the inner products
+  of ONE distance pass over honests + [avg, avg + dir] (bm_attack_ranking) and runs bm_bulyan_pass2 alone on the
+  vectors; `generic` runs the distance pass, the rank kernel and pass 2 per evaluation.  Same candidates; the same
+  ranking gives the same vectors, so the objective values agree (to rounding at most if two scores nearly tie)."""
+  from byzantinemomentum_amd.step import AggregationStep
+  h = n - f
+  gen = torch.Generator(device=DEV).manual_seed(41)
+  base = 0.2 * torch.randn(d, device=DEV, generator=gen)
+  honests = [base + (0.5 + 0.05 * i) * torch.randn(d, device=DEV, generator=gen) for i in range(h)]
+  traces = {}
+  for mode in ("auto", "generic"):
+    step = AggregationStep(n, f, f, gar="bulyan", momentum=0.9, dampening=0.9, momentum_at="update", attack=attack,
+                           attack_factor=1.1, nb_past=0, attack_evals=10, attack_negative=negative, line_search=mode)
+    out = step.run([g.clone() for g in honests])
+    traces[mode] = (step.last_factor, list(step.last_search), out)
+  (fa, sa, oa), (fg, sg, og) = traces["auto"], traces["generic"]
+  assert len(sa) == len(sg) == 10 and max(y for _, y in sa) > 0
+  for (xa, ya), (xg, yg) in zip(sa, sg):
+    assert xa == xg and abs(ya - yg) <= 1e-5 * abs(yg) + 1e-12, (xa, ya, yg)
+  assert fa == fg
+  scale = float(torch.stack(honests).abs().max())
+  assert float((oa - og).abs().max()) <= 4e-6 * scale

@@ -3,6 +3,7 @@ the bm_search_* cursor against the restatement of tools.line_maximize, and the s
 (bm_attack_objective / bm_attack_line_search) against the search run the reference's way — the rule
 evaluated on the vectors once per candidate — on float64 distances."""
 
+import ctypes
 import math
 import random
 
@@ -142,3 +143,31 @@ def test_scalar_search_rejects_bad_arguments():
     h, k, f, rule, m = args
     rc = lib.bm_attack_objective(ext.data_ptr(), h, k, f, rule, m, 1.0, y.data_ptr(), None, None)
     assert rc == _lib.EINVAL, args
+
+
+@pytest.mark.parametrize("kind", ["empire", "little"])
+def test_ranking_from_scalars_equals_ranking_of_the_vectors(kind):
+  """bm_attack_ranking: the order bm_krum_rank gives for honests + [avg + t*att] * k, computed from the (h+2)^2 scalars —
+  against the oracle's Krum / Bulyan ranking (krum.py:41-62, bulyan.py:48-62) of the actual candidate stack in fp64."""
+  for seed in range(8):
+    n, f = ((11, 2), (15, 3), (25, 5), (9, 1))[seed % 4]
+    h = n - f
+    honests = honest_stack(seed, h)
+    ext = ext_matrix(honests, kind)
+    stck = torch.stack(honests)
+    avg = stck.mean(dim=0)
+    att = avg.neg() if kind == "empire" else stck.var(dim=0).sqrt_()
+    for t in (0.0, 0.3, 1.1, -2.0, 25.0):
+      grads = honests + [avg + t * att] * f
+      want_k, _ = O.krum_order(grads, f, "f64")
+      assert linesearch.attack_ranking(ext, h, f, f, "krum", t) == list(want_k)
+      for m in (None, 3):
+        want_b, _ = O.bulyan_order(grads, f, m, "f64")
+        assert linesearch.attack_ranking(ext, h, f, f, "bulyan", t, m) == list(want_b), (seed, t, m)
+  lib = _lib.load()
+  buf = (ctypes.c_int32 * 64)()
+  honests = honest_stack(0, 5)
+  ext = ext_matrix(honests, "empire")
+  for args in ((0, 1, 1, 0, 0), (5, -1, 1, 0, 0), (63, 2, 1, 0, 0), (5, 1, 1, 2, 0), (5, 1, 1, 1, 7)):
+    h, k, f, mode, m = args
+    assert lib.bm_attack_ranking(ext.data_ptr(), h, k, f, mode, m, 1.0, ctypes.cast(buf, ctypes.c_void_p)) == _lib.EINVAL

@@ -257,3 +257,30 @@ def test_median_factor_search_from_two_order_statistics(n, f, attack, negative):
     assert torch.equal(oa.nan_to_num(nan=7.0), og.nan_to_num(nan=7.0))
   first = [y for _, y in runs["auto"][0][1]]  # the first steps compare real objective values
   assert all(math.isfinite(y) and y >= 0 for y in first) and max(first) > 0
+
+
+@pytest.mark.parametrize("n,f,attack,negative,m", [(11, 2, "empire", False, None), (15, 3, "little", True, None),
+                                                   (25, 5, "little", False, None), (11, 2, "empire", False, 3)])
+def test_bulyan_factor_search_ranks_from_scalars(n, f, attack, negative, m):
+  """The factor search against Bulyan: `auto` ranks every candidate stack on the host from the inner products of ONE
+  distance pass (bm_attack_ranking) and runs only the rule's second pass on the vectors; `generic` runs the whole
+  rule per evaluation.  Equal rankings give the same vectors, hence the same candidates and objective values."""
+  from byzantinemomentum_amd.sharded import ShardedAggregator
+  from byzantinemomentum_amd.step import AggregationStep
+  from tests.sharded_backend import OracleBackend
+  h = n - f
+  runs = {}
+  for mode in ("auto", "generic"):
+    step = AggregationStep(n, f, f, gar="bulyan", gar_args={} if m is None else {"m": m}, momentum=0.9, dampening=0.9,
+                           momentum_at="server", attack=attack, attack_factor=1.1, nb_past=2,
+                           aggregator=ShardedAggregator(backend=OracleBackend()), attack_evals=10,
+                           attack_negative=negative, line_search=mode)
+    trace = []
+    for it in range(3):
+      out = step.run(sampled_for_step(it, h, d=801))
+      trace.append((step.last_factor, list(step.last_search), out.clone()))
+    runs[mode] = trace
+  for (fa, sa, oa), (fg, sg, og) in zip(runs["auto"], runs["generic"]):
+    assert fa == fg and sa == sg and len(sa) == 10
+    assert torch.equal(oa, og)
+  assert max(y for _, y in runs["auto"][0][1]) > 0
