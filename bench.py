@@ -24,8 +24,9 @@ unless --scaling weak).
 
 The JSON line also carries `roofline` (algorithmic bytes / HIP-event time of the dominant kernel vs
 8 TB/s; `traffic` = HBM bytes per launch from rocprofv3 FETCH_SIZE/WRITE_SIZE passes of this very
-command, collected live unless --no-traffic) and `cpu_baseline` (the oracle's reference-faithful
-PyTorch-CPU port on this box's host cores, rank 0, N = 1 only).
+command, collected live unless --no-traffic) and `cpu_baseline` (the reference's own
+aggregators — the staged checkout of scripts/stage_reference.sh — or, without one, the oracle's pinned f32 port, on this
+box's host cores, rank 0, N = 1 only; full-size stacks, nothing extrapolated).
 """
 
 import argparse
@@ -183,51 +184,97 @@ def _pick_threads(fn):
   return best
 
 
+def _cpu_reference():
+  """The reference's own registry (`aggregators.gars`) when a checkout is importable — /root/reference in the build
+  container, the staged oracle/_ref/reference (scripts/stage_reference.sh) on the GPU box — else None: the oracle's
+  f32 port, pinned bit-identical to it by tests/test_oracle_vs_reference.py, is timed instead (kind "port")."""
+  from oracle import reference_loader
+  if not reference_loader.available():
+    return None
+  try:
+    return reference_loader.load(with_native=False)[0].gars
+  except Exception as err:  # noqa: BLE001  (a baseline must not take the line down)
+    print(f"[bench] reference checkout present but not importable: {err!r}", file=sys.stderr)
+    return None
+
+
+def _host_copy(stack):
+  seen = {}
+  return [seen.setdefault(id(g), g.cpu()) for g in stack]
+
+
 def cpu_baseline_colwise(stack, f):
+  """median.py:31-39 + trmean.py:69-79 on the SAME full-size stack, on this box's host cores."""
   from oracle import gar_oracle as O
-  rows = [g.cpu() for g in stack]
+  gars = _cpu_reference()
+  rows = _host_copy(stack)
   d = rows[0].shape[0]
+  if gars is not None:
+    def pair(rs):
+      gars["median"].unchecked(gradients=rs, f=f)
+      gars["trmean"].unchecked(gradients=rs, f=f)
+    what = "the reference's aggregators/median.py + trmean.py (gar.unchecked)"
+  else:
+    def pair(rs):
+      O.median(rs)
+      O.trmean(rs, f)
+    what = "oracle f32 port (torch.stack+median, torch.stack+sort+mean: the reference's ops)"
   small = [r[:d // 16] for r in rows]
-  threads = _pick_threads(lambda: (O.median(small), O.trmean(small, f)))
+  threads = _pick_threads(lambda: pair(small))
   t0 = time.perf_counter()
   reps = 2
   for _ in range(reps):
-    O.median(rows)
-    O.trmean(rows, f)
+    pair(rows)
   dt = (time.perf_counter() - t0) / reps
-  return {"value": 2.0 / dt, "unit": "agg/s", "cores": threads, "kind": "port",
-          "sample": f"oracle f32 port (torch.stack+median, torch.stack+sort+mean: the reference's ops) on the same "
-                    f"n={len(rows)} x d={d} stack, {reps} passes of median+trmean, {dt:.3f} s per pass, "
-                    f"{threads} torch threads (fastest of 16/32/64/{(os.cpu_count() or 2) // 2}/{os.cpu_count()} "
-                    f"on a d/16 sample; host has {os.cpu_count()} hardware threads)"}
+  return {"value": 2.0 / dt, "unit": "agg/s", "cores": threads, "kind": "reference" if gars is not None else "port",
+          "sample": f"{what} on the same n={len(rows)} x d={d} stack (full size, nothing scaled), {reps} passes of "
+                    f"median+trmean, {dt:.3f} s per pass, {threads} torch threads (fastest of 16/32/64/"
+                    f"{(os.cpu_count() or 2) // 2}/{os.cpu_count()} on a d/16 sample; host has {os.cpu_count()} "
+                    f"hardware threads)"}
 
 
-def cpu_baseline_distance(stack, f, rule, d_sample, budget_s=10.0):
-  """The oracle's f32 port of a distance-based rule on the first coordinates of the same stack, scaled linearly to
-  the full length.  Bounded: a fixed thread count (the per-pair torch ops are small; searching the thread count
-  on them once picked a count that made the sample take minutes) and a sample length chosen from a short
-  calibration run so that the measurement stays within `budget_s` seconds."""
+def cpu_baseline_rule(rows, f, rule):
+  """krum.py:31-80 / bulyan.py:31-84 on the host copy `rows` of the SAME full-size stack: ONE aggregation, nothing
+  extrapolated.  A fixed thread count: the per-pair torch ops (`sub().norm().item()`) do not scale past it, and
+  searching the count on them once picked one that made the run take minutes."""
   from oracle import gar_oracle as O
-  n = len(stack)
+  gars = _cpu_reference()
   threads = min(32, os.cpu_count() or 1)
   torch.set_num_threads(threads)
-  fn = O.krum if rule == "krum" else O.bulyan
-  probe = 1 << 12
-  tiny = [g[:probe].cpu() for g in stack]
-  fn(tiny, f)
+  n, d = len(rows), rows[0].shape[0]
+  if gars is not None:
+    fn = lambda rs: gars[rule].unchecked(gradients=rs, f=f)  # noqa: E731
+    what = f"the reference's aggregators/{rule}.py (gar.unchecked)"
+  else:
+    fn = lambda rs: (O.krum if rule == "krum" else O.bulyan)(rs, f)  # noqa: E731
+    what = f"oracle f32 port of {rule}"
+  fn([r[:4096] for r in rows])  # (first-use costs of the torch ops and of the thread pool stay out of the timing)
   t0 = time.perf_counter()
-  fn(tiny, f)
-  per_probe = time.perf_counter() - t0
-  while d_sample > probe and per_probe * (d_sample / probe) > budget_s:  # (sub-linear in practice: call overheads dominate the probe)
-    d_sample //= 2
-  rows = [g[:d_sample].cpu() for g in stack]
-  t0 = time.perf_counter()
-  fn(rows, f)
+  fn(rows)
   dt = time.perf_counter() - t0
-  scale = stack[0].shape[0] / d_sample
-  return {"value": 1.0 / (dt * scale), "unit": "agg/s", "cores": threads, "kind": "port",
-          "sample": f"oracle f32 port of {rule} on n={n} x d={d_sample} (first coordinates of the same stack), one "
-                    f"pass {dt:.2f} s on {threads} torch threads, scaled linearly to d={stack[0].shape[0]}"}
+  return {"value": 1.0 / dt, "unit": "agg/s", "cores": threads, "kind": "reference" if gars is not None else "port",
+          "sample": f"{what} on the same n={n}, f={f}, d={d} stack (full size, nothing scaled), one aggregation "
+                    f"{dt:.2f} s on {threads} torch threads"}
+
+
+def cpu_baseline_step(sampled, n, f, gar):
+  """ONE step of the loop body attack.py:786-868 at full size on the host: oracle/step_oracle.ReferenceLoop in its
+  f32 form (the reference's own fp32 torch-CPU operations in the reference's order; pinned bit-faithful against the
+  loop body driven with the reference's own functions by tests/test_step_reference_vs_reference.py)."""
+  from oracle.step_oracle import ReferenceLoop
+  threads = min(32, os.cpu_count() or 1)
+  torch.set_num_threads(threads)
+  rows = [g.cpu() for g in sampled]
+  d = rows[0].shape[0]
+  loop = ReferenceLoop(n, f, f, gar, "worker", 0.99, 0.99, "empire", 1.1, None, 25, precision="f32")
+  params, origin = torch.zeros(d), torch.zeros(d)
+  t0 = time.perf_counter()
+  loop.step(rows, params, origin)
+  dt = time.perf_counter() - t0
+  return {"value": 1.0 / dt, "unit": "steps/s", "cores": threads, "kind": "port",
+          "sample": f"one full-size step (n={n}, f={f}, d={d}, worker momentum 0.99, empire 1.1, rule {gar}, study "
+                    f"block; the first step of a run: no past gradient in the deque yet) of the f32 loop-body "
+                    f"restatement, {dt:.2f} s on {threads} torch threads"}
 
 
 # ---------------------------------------------------------------------------- #
@@ -541,7 +588,7 @@ def main():
   # (also one rank under torchrun with --sharded-extras or --workload bulyan|krum: the same code path, testable on one GPU)
   cpu_sample = None
   if world == 1 and rank == 0 and not args.no_cpu_baseline and workload in ("bulyan", "krum"):
-    cpu_sample = [g[:min(d, 1 << 20)].clone() for g in stacks[0]]  # (the stacks go before the extras run)
+    cpu_sample = _host_copy(stacks[0])  # (the device stacks go before the extras run)
   if distributed and workload in ("bulyan", "krum"):
     del stacks
     torch.cuda.empty_cache()
@@ -564,10 +611,7 @@ def main():
     if workload == "colwise" and stacks is not None:
       extra["cpu_baseline"] = cpu_baseline_colwise(stacks[0], f)
     elif cpu_sample is not None:
-      base = cpu_baseline_distance(cpu_sample, f, workload, len(cpu_sample[0]))  # bounded sample, scaled to d
-      base["value"] *= len(cpu_sample[0]) / d
-      base["sample"] += f" (then to d={d})"
-      extra["cpu_baseline"] = base
+      extra["cpu_baseline"] = cpu_baseline_rule(cpu_sample, f, workload)
 
   if rank == 0:
     dominant = max(algo_bytes, key=lambda k: per_gar[k]["avg_ms"])
@@ -680,7 +724,7 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
       if "BM_BENCH_CHILD" not in os.environ:
         out["attack_search_c3_krum"] = attack_search(bm, stacks[0][:n - f], n, f, d)
       if cpu_baseline:
-        c3_sample = [g[:1 << 18].clone() for g in stacks[0]]  # kept for the CPU baseline at the very end
+        c3_sample = _host_copy(stacks[0])  # the full-size host copy, for the CPU baseline at the very end
       # Brute at the same shape: C(51, 12) = 1.6e11 subsets, which the reference's loop (brute.py:47-68) cannot enumerate;
       # bm_brute_select answers from the threshold graphs of the distances
       ms_b = timed_loop(lambda i: bm.brute(stacks[i & 1], f), 6, 2, timer, "brute_c3")
@@ -689,7 +733,7 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
                                      f"smallest diameter from the device's distances on the host, one synchronisation), d={d}")
     else:
       if cpu_baseline:
-        c4_sample = [g[:1 << 18].clone() for g in stacks[0]]
+        c4_sample = _host_copy(stacks[0])
       if "BM_BENCH_CHILD" not in os.environ:  # (the PMC child keeps the per-launch traffic of the C2 column kernel clean)
         out["attack_search_c2_median"] = attack_search(bm, stacks[0][:n - f], n, f, d, gar="median")
         try:  # (Bulyan: every candidate ranked on the host from ONE distance pass, only pass 2 on the vectors)
@@ -744,16 +788,15 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
       out[f"step_c5_update_{gar}"] = entry(ms, 4 * d * units,
                                            config=f"full step mirror, momentum at the update, rule {gar}, n={n}, f={f}, d={d}, one GPU")
       del runner
-  if cpu_baseline and c3_sample is not None:  # last: host threads busy with it must not sit next to a GPU measurement
-    base = cpu_baseline_distance(c3_sample, 12, "krum", 1 << 18)
-    base["value"] *= (1 << 18) / D_RESNET18  # the sample IS 2^18 coordinates long: scale to the C3 length
-    base["sample"] += f" (C3: n=51, f=12, d={D_RESNET18})"
-    out["krum_c3"]["cpu_baseline"] = base
+  # last: host threads busy with a baseline must not sit next to a GPU measurement.  Full size, the same stacks.
+  if cpu_baseline and c3_sample is not None:
+    out["krum_c3"]["cpu_baseline"] = cpu_baseline_rule(c3_sample, 12, "krum")
   if cpu_baseline and c4_sample is not None:
-    base = cpu_baseline_distance(c4_sample, 5, "bulyan", 1 << 18)
-    base["value"] *= (1 << 18) / D_RESNET18
-    base["sample"] += f" (C4: n=25, f=5, d={D_RESNET18})"
-    out["bulyan_c4_1gpu"]["cpu_baseline"] = base
+    out["bulyan_c4_1gpu"]["cpu_baseline"] = cpu_baseline_rule(c4_sample, 5, "bulyan")
+  del c3_sample, c4_sample
+  if cpu_baseline:
+    base = cpu_baseline_step(sets[0], n, f, "krum")
+    out["step_c5_krum"]["cpu_baseline"] = base
   return out
 
 

@@ -1,0 +1,109 @@
+"""The UNMODIFIED reference driver (`attack.py`) executing `--gar native-*` on the MI355X, next to the same
+run with the reference's own rule: the 24 columns of the `study` file (`attack.py:564-571,870-878`) must agree.
+
+This is the drop-in claim of BASELINE.json's north_star ("drops into the reference's attack.py loop
+unchanged") exercised end to end: `attack.py:821-822` -> `aggregators/krum.py:159-166` (the `native` hook) ->
+`native.krum.aggregate` -> libbm_gar.so.  The reference is the staged copy `scripts/stage_reference.sh`
+puts under the git-ignored oracle/_ref/ (it rides the gpurun snapshot); `torchvision`, absent from the image,
+is the seeded synthetic stand-in of tests/stubs/.  The `native` rules have no CPU fallback and an unknown
+rule name is fatal in `attack.py:470-472`, so a finished `native-*` run IS a run through the HIP library.
+"""
+
+import math
+import os
+import subprocess
+import sys
+
+import pytest
+
+from oracle import reference_loader
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STUBS = os.path.join(ROOT, "tests", "stubs")
+STEPS = 5
+
+HEADER_COLUMNS = 24
+ACCEPT = HEADER_COLUMNS - 1  # "Attack acceptation ratio", printed with str()
+
+
+def _run_attack(outdir, gar, device, n, f, attack, attack_args, momentum_at, model="simples-full", dataset="mnist",
+                extra=()):
+  env = dict(os.environ)
+  env["PYTHONPATH"] = os.pathsep.join([ROOT, STUBS] + ([env["PYTHONPATH"]] if env.get("PYTHONPATH") else []))
+  cmd = [sys.executable, "-OO", os.path.join(reference_loader.REFERENCE_DIR, "attack.py"),
+         "--seed", "1", "--device", device, "--nb-steps", str(STEPS), "--nb-workers", str(n),
+         "--nb-decl-byz", str(f), "--nb-real-byz", str(f), "--gar", gar, "--attack", attack,
+         "--attack-args", *attack_args, "--model", model, "--dataset", dataset, "--momentum-at", momentum_at,
+         "--momentum", "0.9", "--evaluation-delta", "0", "--nb-for-study", "1", "--nb-for-study-past", "3",
+         "--result-directory", str(outdir), *extra]
+  proc = subprocess.run(cmd, env=env, cwd=str(outdir.parent), capture_output=True, text=True, timeout=600)
+  assert proc.returncode == 0, f"{' '.join(cmd)}\n{proc.stdout[-3000:]}\n{proc.stderr[-3000:]}"
+  study = (outdir / "study").read_text().splitlines()
+  assert study[0].startswith("# Step number") and len(study[0].split("\t")) == HEADER_COLUMNS
+  rows = [line.split("\t") for line in study[1:] if line.strip()]
+  assert len(rows) == STEPS and all(len(r) == HEADER_COLUMNS for r in rows), proc.stdout[-2000:]
+  return study[0].lstrip("# ").split("\t"), rows
+
+
+def _compare(names, want, got, rtol, accept_exact):
+  """Column by column: NaN where the reference prints NaN, else |a-b| <= rtol * max(|b|, 1e-3 * row scale)."""
+  worst = (0.0, None)
+  for step, (rw, rg) in enumerate(zip(want, got)):
+    assert rw[:2] == rg[:2]  # step number, training point count
+    scale = max(abs(float(x)) for x in rw[2:ACCEPT] if math.isfinite(float(x)))
+    for col in range(2, HEADER_COLUMNS):
+      a, b = float(rg[col]), float(rw[col])
+      if col == ACCEPT and not accept_exact:
+        continue
+      if math.isnan(b):
+        assert math.isnan(a), f"step {step} {names[col]!r}: reference prints nan, native run {a}"
+        continue
+      assert math.isfinite(a), f"step {step} {names[col]!r}: native run prints {a}, reference {b}"
+      if col == ACCEPT:
+        assert a == b, f"step {step} accepted ratio {a} != {b}"
+        continue
+      err = abs(a - b) / max(abs(b), 1e-3 * scale)
+      if err > worst[0]:
+        worst = (err, f"step {step} {names[col]!r}: {a!r} vs {b!r}")
+      assert err <= rtol, f"step {step} {names[col]!r}: {a!r} vs reference {b!r} (rel {err:.2e})"
+  return worst
+
+
+# (rule, n, f, attack, attack-args, momentum placement, is the accepted ratio comparable)
+CASES = [
+  ("krum", 11, 2, "empire", ["factor:1.1"], "worker", True),
+  ("median", 11, 2, "empire", ["factor:1.1"], "worker", True),
+  ("bulyan", 11, 2, "little", ["factor:1.5", "negative:True"], "worker", True),
+  ("brute", 11, 2, "empire", ["factor:1.1"], "update", True),
+  ("trmean", 11, 2, "empire", ["factor:1.1"], "server", True),
+  ("krum", 25, 5, "empire", ["factor:-16"], "worker", True),  # the attacks' default: line search through the rule
+  ("bulyan", 25, 5, "empire", ["factor:1.1"], "worker", True),
+  ("aksel", 25, 5, "little", ["factor:1.5"], "update", True),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("rule,n,f,attack,attack_args,momentum_at,accept_exact", CASES,
+                         ids=[f"{c[0]}-n{c[1]}f{c[2]}-{c[3]}-{c[5]}" for c in CASES])
+def test_unmodified_attack_py_with_native_rules(tmp_path, rule, n, f, attack, attack_args, momentum_at, accept_exact):
+  if not reference_loader.available():
+    pytest.fail("no staged reference: run scripts/stage_reference.sh (build() does) before gpurun")
+  names, want = _run_attack(tmp_path / "reference", rule, "cuda:0", n, f, attack, attack_args, momentum_at)
+  _, got = _run_attack(tmp_path / "native", f"native-{rule}", "cuda:0", n, f, attack, attack_args, momentum_at)
+  worst = _compare(names, want, got, 1e-5, accept_exact)
+  print(f"native-{rule} n={n} f={f} {attack}: worst relative difference over {STEPS} steps x 21 floats = "
+        f"{worst[0]:.2e} ({worst[1]})")
+
+
+@pytest.mark.reference
+def test_stub_and_staging_run_the_reference_driver_on_cpu(tmp_path):
+  """The plumbing of the GPU test, here: the staged/real checkout + the torchvision stand-in run the unmodified
+  driver with the reference's OWN rule on CPU and produce the 24-column study file."""
+  global STEPS
+  saved, STEPS = STEPS, 2
+  try:
+    names, rows = _run_attack(tmp_path / "cpu", "krum", "cpu", 11, 2, "empire", ["factor:1.1"], "worker")
+  finally:
+    STEPS = saved
+  assert names[3] == "l2 from origin" and names[ACCEPT] == "Attack acceptation ratio"
+  assert float(rows[0][3]) == 0.0 and math.isnan(float(rows[0][21])) and math.isfinite(float(rows[1][21]))
