@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported before the CDLL, see above)
 _PKG_DIR = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _PKG_DIR / "libbm_gar.so"
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 MAX_ROWS = 64
 EINVAL = -100000
 ENOCOMM, ECOMM = -100001, -100002
@@ -102,15 +102,15 @@ SIGNATURES = {
   "bm_allgather_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                       ctypes.c_void_p]),
   "bm_sharded_workspace_bytes": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int64]),
-  "bm_sharded_krum": (ctypes.c_int, [ctypes.c_void_p, _c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
-                                     ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
-  "bm_sharded_bulyan": (ctypes.c_int, [ctypes.c_void_p, _c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
-                                       ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+  "bm_sharded_krum": (ctypes.c_int, [ctypes.c_void_p, _c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                     ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+  "bm_sharded_bulyan": (ctypes.c_int, [ctypes.c_void_p, _c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
+                                       ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                        ctypes.c_void_p]),
   "bm_step_stats_count": (ctypes.c_int, []),
   "bm_step_workspace_bytes": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int64]),
-  "bm_step_worker": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_float_pp, _c_float_pp, ctypes.c_int64]
-                     + [ctypes.c_void_p] * 13),
+  "bm_step_worker": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, _c_float_pp, _c_float_pp, ctypes.c_int64,
+                                    ctypes.c_int64] + [ctypes.c_void_p] * 13),
   "bm_search_begin": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_double]),
   "bm_search_propose": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
   "bm_search_report": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_double]),

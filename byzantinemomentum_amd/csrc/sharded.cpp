@@ -124,17 +124,16 @@ namespace {
 constexpr int64_t kShardHeader = BM_MAX_ROWS * BM_MAX_ROWS * 8 + BM_MAX_ROWS * 4 + 256;
 
 // have_sq: the squared distances of the local shard are already at the head of ws (bm_momentum_stats_sqdist wrote them)
-int sharded_rank(bm_comm* comm, const float* const* rows, int n, int64_t d_local, int f, int m, int mode, void* ws,
-                 void* stream, double** sq_out, int32_t** order_out, bool have_sq = false) {
+int sharded_rank(bm_comm* comm, const float* const* rows, int n, int64_t d_local, int64_t d_total, int f, int m, int mode,
+                 void* ws, void* stream, double** sq_out, int32_t** order_out, bool have_sq = false) {
   char* base = static_cast<char*>(ws);
   double* sq = reinterpret_cast<double*>(base);
   int32_t* order = reinterpret_cast<int32_t*>(base + BM_MAX_ROWS * BM_MAX_ROWS * 8);
   void* pair_ws = base + kShardHeader;
   int rc = 0;
   if (!have_sq) {
-    // the precision plan of the distance pass follows the length of the WHOLE vector (all shards): shards are equal
-    // up to the 64-coordinate rounding of shard_bounds, d_local * ranks is the total to within that
-    const int64_t d_total = d_local * (int64_t)bm_comm_size(comm);
+    // the precision plan of the distance pass follows the length of the WHOLE vector (all shards), which the caller
+    // states: a short or empty trailing shard must plan exactly like its peers
     rc = bm_pairwise_sqdist_shard(rows, n, d_local, d_total, sq, pair_ws, stream);
     if (rc != 0) return rc;
   }
@@ -152,15 +151,15 @@ extern "C" int64_t bm_sharded_workspace_bytes(int n, int64_t d_local) {
   return kShardHeader + bm::pairwise_workspace_bytes(n, d_local);
 }
 
-extern "C" int bm_sharded_krum(bm_comm* comm, const float* const* rows, int n, int64_t d_local, int f, int m,
+extern "C" int bm_sharded_krum(bm_comm* comm, const float* const* rows, int n, int64_t d_local, int64_t d_total, int f, int m,
                                float* out_local, int32_t* order_out, void* ws, void* stream) {
   // an empty shard (d_local == 0) has no output buffer: torch.empty(0).data_ptr() is NULL
   if (rows == nullptr || (out_local == nullptr && d_local > 0) || ws == nullptr || n < 1 || n > BM_MAX_ROWS ||
-      d_local < 0 || f < 0 || m < 1 || m > n)
+      d_local < 0 || d_total < d_local || f < 0 || m < 1 || m > n)
     return BM_EINVAL;
   double* sq;
   int32_t* order;
-  int rc = sharded_rank(comm, rows, n, d_local, f, m, BM_RANK_KRUM, ws, stream, &sq, &order);
+  int rc = sharded_rank(comm, rows, n, d_local, d_total, f, m, BM_RANK_KRUM, ws, stream, &sq, &order);
   if (rc != 0) return rc;
   if (order_out != nullptr) {
     rc = bm::hip_code(hipMemcpyAsync(order_out, order, BM_MAX_ROWS * sizeof(int32_t), hipMemcpyDeviceToDevice,
@@ -170,15 +169,15 @@ extern "C" int bm_sharded_krum(bm_comm* comm, const float* const* rows, int n, i
   return bm_selected_mean(rows, n, order, m, d_local, out_local, stream);
 }
 
-extern "C" int bm_sharded_bulyan(bm_comm* comm, const float* const* rows, int n, int64_t d_local, int f, int m,
+extern "C" int bm_sharded_bulyan(bm_comm* comm, const float* const* rows, int n, int64_t d_local, int64_t d_total, int f, int m,
                                  float* out_local, int32_t* order_out, void* ws, void* stream) {
   // an empty shard (d_local == 0) has no output buffer: torch.empty(0).data_ptr() is NULL
   if (rows == nullptr || (out_local == nullptr && d_local > 0) || ws == nullptr || n < 1 || n > BM_MAX_ROWS ||
-      d_local < 0 || f < 0 || m < 1 || m > n)
+      d_local < 0 || d_total < d_local || f < 0 || m < 1 || m > n)
     return BM_EINVAL;
   double* sq;
   int32_t* order;
-  int rc = sharded_rank(comm, rows, n, d_local, f, m, BM_RANK_BULYAN, ws, stream, &sq, &order);
+  int rc = sharded_rank(comm, rows, n, d_local, d_total, f, m, BM_RANK_BULYAN, ws, stream, &sq, &order);
   if (rc != 0) return rc;
   if (order_out != nullptr) {
     rc = bm::hip_code(hipMemcpyAsync(order_out, order, BM_MAX_ROWS * sizeof(int32_t), hipMemcpyDeviceToDevice,
@@ -201,7 +200,7 @@ extern "C" int bm_sharded_rule_from_sq(bm_comm* comm, int rule, const float* con
     return BM_EINVAL;
   double* sq;
   int32_t* order;
-  int rc = sharded_rank(comm, rows, n, d_local, f, m, rule == BM_RULE_KRUM ? BM_RANK_KRUM : BM_RANK_BULYAN, ws, stream,
+  int rc = sharded_rank(comm, rows, n, d_local, d_local, f, m, rule == BM_RULE_KRUM ? BM_RANK_KRUM : BM_RANK_BULYAN, ws, stream,
                         &sq, &order, true);
   if (rc != 0) return rc;
   if (order_out != nullptr) {

@@ -110,12 +110,14 @@ extern "C" int64_t bm_step_workspace_bytes(int n, int64_t d_local) {
 }
 
 extern "C" int bm_step_worker(bm_comm* comm, const bm_step_params* p, const float* const* sampled,
-                              float* const* buffers, int64_t d, float* defense_out, float* sampled_avg_out,
+                              float* const* buffers, int64_t d, int64_t d_total, float* defense_out,
+                              float* sampled_avg_out,
                               float* honest_avg_out, float* byz_out, float* attack_avg_out,
                               const float* past_newest, float* curv, const float* past_oldest, const float* params,
                               const float* origin, double* stats_out, void* ws, void* stream) {
   using namespace bm;
-  if (p == nullptr || sampled == nullptr || buffers == nullptr || stats_out == nullptr || ws == nullptr || d < 0)
+  if (p == nullptr || sampled == nullptr || buffers == nullptr || stats_out == nullptr || ws == nullptr || d < 0 ||
+      d_total < d)
     return BM_EINVAL;
   const int n = p->n, h = p->n - p->f_real, ks = p->ks, fr = p->f_real;
   if (n < 1 || n > BM_MAX_ROWS || h < 1 || ks < h || ks > BM_MAX_ROWS || fr < 0 ||
@@ -161,9 +163,9 @@ extern "C" int bm_step_worker(bm_comm* comm, const bm_step_params* p, const floa
     if (rc != 0) return rc;
   } else if (rides_along) {
     // Krum / Bulyan: the squared distances of this shard come out of the first pass (the plan of the distance pass
-    // follows the length of the whole vector, d_local x ranks, as in bm_sharded_krum); then all-reduce -> rank -> rule
+    // follows the length of the whole vector, d_total, as in bm_sharded_krum); then all-reduce -> rank -> rule
     char* rule_ws = base + lay.ws_rule;
-    rc = bm_momentum_stats_sqdist(sampled, ks, buffers, h, d, d * (int64_t)bm_comm_size(comm), p->mu, p->one_minus_damp,
+    rc = bm_momentum_stats_sqdist(sampled, ks, buffers, h, d, d_total, p->mu, p->one_minus_damp,
                                   clipf, sampled_avg_out, honest_avg_out, byz_out, p->attack_scale, p->attack_kind, fr,
                                   bm_sharded_sq_slot(rule_ws), sc->out6, base + lay.ws_step,
                                   bm_sharded_pair_workspace(rule_ws), stream);
@@ -177,10 +179,10 @@ extern "C" int bm_step_worker(bm_comm* comm, const bm_step_params* p, const floa
     // ---- the rule over the honest rows alone (no attack) ----
     switch (p->rule) {
       case BM_RULE_KRUM:
-        rc = bm_sharded_krum(comm, rows, n, d, p->f_decl, m, defense_out, nullptr, base + lay.ws_rule, stream);
+        rc = bm_sharded_krum(comm, rows, n, d, d_total, p->f_decl, m, defense_out, nullptr, base + lay.ws_rule, stream);
         break;
       case BM_RULE_BULYAN:
-        rc = bm_sharded_bulyan(comm, rows, n, d, p->f_decl, m, defense_out, nullptr, base + lay.ws_rule, stream);
+        rc = bm_sharded_bulyan(comm, rows, n, d, d_total, p->f_decl, m, defense_out, nullptr, base + lay.ws_rule, stream);
         break;
       case BM_RULE_MEDIAN: rc = bm_colwise(BM_OP_MEDIAN, rows, n, d, 0, defense_out, stream); break;
       case BM_RULE_TRMEAN: rc = bm_colwise(BM_OP_TRMEAN, rows, n, d, p->f_decl, defense_out, stream); break;

@@ -116,9 +116,9 @@ class HipBackend:
   def brute_select(self, dist_host, n, f):
     return self.gars.brute_select_host(dist_host, n, f)
 
-  def sharded_rule(self, name, comm, gradients, f, m):
+  def sharded_rule(self, name, comm, gradients, f, m, d_total=None):
     """Multi-Krum / Bulyan of the local slice in one C call (bm_sharded_krum / bm_sharded_bulyan);
-    comm: NativeComm or None (one rank)."""
+    comm: NativeComm or None (one rank); d_total: length of the whole vectors (default: this shard's)."""
     gars = self.gars
     n, d, device = gars._validate(gradients)
     lib = _lib.load()
@@ -127,12 +127,17 @@ class HipBackend:
     ws = gars._Scratch.get(device, "ws_sharded", nbytes=int(nbytes))
     fn = lib.bm_sharded_krum if name == "krum" else lib.bm_sharded_bulyan
     with torch.cuda.device(device):
-      _lib.check(fn(comm.handle if comm is not None else None, _lib.pointer_table(gradients), n, d, f, m,
-                    gars._ptr(out), None, gars._ptr(ws), gars._stream(device)), "bm_sharded_" + name)
+      _lib.check(fn(comm.handle if comm is not None else None, _lib.pointer_table(gradients), n, d,
+                    int(d_total) if d_total is not None else d, f, m, gars._ptr(out), None, gars._ptr(ws), gars._stream(device)), "bm_sharded_" + name)
     return out
 
   def index_tensor(self, indices, like):
     return torch.tensor(indices, dtype=torch.int32, device=like.device)
+
+  def sum_over_ranks(self, agg, value):
+    """A host integer summed over the ranks (shard lengths: once per shape, not per call)."""
+    t = torch.tensor([float(value)], dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+    return int(agg.all_reduce_sum(t).item())
 
   # -- step statistics and momentum -------------------------------------------- #
 
@@ -201,6 +206,22 @@ class ShardedAggregator:
           raise RuntimeError(f"libbm_gar RCCL communicator unavailable on at least one rank ({failure})")
         warnings.warn(f"libbm_gar RCCL communicator unavailable ({failure}); using torch.distributed collectives")
         self.single_call = False
+    self._totals = {}
+
+  def total_length(self, d_local, d_total=None):
+    """Length of the WHOLE vectors (all shards), the number every rank must hand to the distance pass so that a
+    short or empty trailing shard plans it exactly like its peers (bm_gar.h, bm_sharded_krum).  Stated by the caller
+    (`d_total`) or, once per local length, summed over the ranks (one tiny all-reduce; every rank must then make its
+    first call with a new shard length at the same point, which a dim-sharded job does by construction)."""
+    if d_total is not None:
+      return int(d_total)
+    if not self.collective:
+      return int(d_local)
+    total = self._totals.get(d_local)
+    if total is None:
+      total = int(self.backend.sum_over_ranks(self, int(d_local)))
+      self._totals[d_local] = total
+    return total
 
   def _create_native(self, group):
     """The library's own communicator, on EVERY rank or on none: a rank that fell back alone would issue
@@ -314,30 +335,30 @@ class ShardedAggregator:
   def meamed(self, local, f):
     return self.backend.colwise("meamed", local, f)
 
-  def global_sqdist(self, local):
+  def global_sqdist(self, local, d_total=None):
     """All-reduced n x n squared-distance matrix (every rank gets the same bits: the sum runs over
     the same P partial matrices in the collective's fixed order)."""
-    # the precision plan follows the length of the whole vectors (as bm_sharded_* does: d_local x ranks)
-    sq = self.backend.pairwise_sqdist(local, d_total=local[0].numel() * self.world_size)  # fresh, reduced in place
+    # the precision plan follows the length of the whole vectors, the same number on every rank (total_length)
+    sq = self.backend.pairwise_sqdist(local, d_total=self.total_length(local[0].numel(), d_total))  # fresh, reduced in place
     self._all_reduce(sq)
     return sq
 
-  def krum(self, local, f, m=None):
+  def krum(self, local, f, m=None, d_total=None):
     n = len(local)
     if m is None:
       m = n - f - 2
     if self.single_call:
-      return self.backend.sharded_rule("krum", self.native, local, f, m)
-    order = self.backend.rank(self.global_sqdist(local), n, f, m, _lib.RANK_KRUM)
+      return self.backend.sharded_rule("krum", self.native, local, f, m, self.total_length(local[0].numel(), d_total))
+    order = self.backend.rank(self.global_sqdist(local, d_total), n, f, m, _lib.RANK_KRUM)
     return self.backend.selected_mean(local, order, m)
 
-  def bulyan(self, local, f, m=None):
+  def bulyan(self, local, f, m=None, d_total=None):
     n = len(local)
     if m is None:
       m = n - f - 2
     if self.single_call:
-      return self.backend.sharded_rule("bulyan", self.native, local, f, m)
-    order = self.backend.rank(self.global_sqdist(local), n, f, m, _lib.RANK_BULYAN)
+      return self.backend.sharded_rule("bulyan", self.native, local, f, m, self.total_length(local[0].numel(), d_total))
+    order = self.backend.rank(self.global_sqdist(local, d_total), n, f, m, _lib.RANK_BULYAN)
     return self.backend.bulyan_pass2(local, order, f, m)
 
   def rule_from_sq(self, name, local, local_sq, f, m=None):
@@ -359,10 +380,10 @@ class ShardedAggregator:
     self._all_reduce(sq)
     return self.backend.selected_mean(local, self.backend.argsort(sq, n), count)
 
-  def brute(self, local, f):
+  def brute(self, local, f, d_total=None):
     """Brute rule: all-reduced distances, the (deterministic) subset search on every rank's host."""
     n = len(local)
-    dist_host = self.global_sqdist(local).sqrt().cpu().contiguous()
+    dist_host = self.global_sqdist(local, d_total).sqrt().cpu().contiguous()
     sel = self.backend.brute_select(dist_host, n, f)
     return self.backend.selected_mean(local, self.backend.index_tensor(sel, local[0]), n - f)
 

@@ -325,10 +325,11 @@ def l2_distance(a, b):
 
 
 def step_worker(comm, sampled, buffers, n, f_decl, f_real, rule, m, mu, one_minus_damp, clip, attack, attack_scale,
-                nb_past, past_count, past_newest, curv, past_oldest, params=None, origin=None):
+                nb_past, past_count, past_newest, curv, past_oldest, params=None, origin=None, d_total=None):
   """One simulation step with worker-side momentum as ONE C call (bm_step_worker, include/bm_gar.h).
 
-  comm: sharded.NativeComm or None.  Returns (defense, sampled_avg, honest_avg, byz, stats) with `stats` the
+  comm: sharded.NativeComm or None; d_total: length of the whole vectors over all shards (default: this shard's).
+  Returns (defense, sampled_avg, honest_avg, byz, stats) with `stats` the
   device fp64 vector documented in the header (already reduced over the ranks). No sync."""
   ks, d, device = gars._validate(list(sampled))
   lib = _lib.load()
@@ -346,7 +347,8 @@ def step_worker(comm, sampled, buffers, n, f_decl, f_real, rule, m, mu, one_minu
   gars.invalidate_rank_cache()
   with torch.cuda.device(device):
     _lib.check(lib.bm_step_worker(comm.handle if comm is not None else None, ctypes.byref(par),
-                                  _lib.pointer_table(sampled), _lib.pointer_table(buffers), d, _ptr(defense),
+                                  _lib.pointer_table(sampled), _lib.pointer_table(buffers), d,
+                                  int(d_total) if d_total is not None else d, _ptr(defense),
                                   _ptr(s_avg), _ptr(h_avg), opt(byz), None, opt(past_newest), opt(curv),
                                   opt(past_oldest), opt(params), opt(origin), _ptr(stats), _ptr(ws),
                                   gars._stream(device)), "bm_step_worker")

@@ -218,7 +218,7 @@ class AggregationStep:
         # first pass + the distance pass of the rule in one call (one kernel at h = 20 for long gradients)
         s_avg, h_avg, byz, fused_sq, out6 = ops.momentum_stats_sqdist(
           sampled, self.buffers, self.mu, omd, factors, self.factor, self.attack, self.f_real,
-          d_total=sampled[0].shape[0] * agg.world_size)
+          d_total=agg.total_length(sampled[0].shape[0]))
       elif self.attack_evals is None:
         s_avg, h_avg, byz, out6 = ops.momentum_stats(sampled, self.buffers, self.mu, omd, factors, self.factor, self.attack)
       else:  # the attack direction alone; the Byzantine vector follows the factor search
@@ -250,7 +250,7 @@ class AggregationStep:
       elif plain_update and self.gar in ("krum", "bulyan") and not (set(self.gar_args) - {"m"}) \
           and hasattr(ops, "stack_stats_sqdist"):
         h_avg, byz, fused_sq, o6 = ops.stack_stats_sqdist(honests, self.factor, self.attack, self.f_real,
-                                                          d_total=sampled[0].shape[0] * agg.world_size)
+                                                          d_total=agg.total_length(sampled[0].shape[0]))
         h_out3 = o6[3:]
       elif self.attack_evals is None:
         h_avg, h_out3, byz = ops.stack_stats(honests, scale=self.factor, attack=self.attack)
@@ -319,7 +319,8 @@ class AggregationStep:
     defense, s_avg, h_avg, byz, stats = self.ops.step_worker(
       self.agg.native, sampled, self.buffers, self.n, self.f_decl, self.f_real, self.gar, self.gar_args.get("m"),
       self.mu, omd, self.clip, self.attack, self.factor, self.nb_past, count,
-      self.pasts[0] if count > 0 else None, self._curv, self.pasts[-1] if full else None, params, origin)
+      self.pasts[0] if count > 0 else None, self._curv, self.pasts[-1] if full else None, params, origin,
+      d_total=self.agg.total_length(sampled[0].shape[0]))
     self._update = defense
     self._pending = dict(packed=stats, prev=self._prev_stats if count > 0 else None, npast=2 if count > 0 else 0,
                          has_attack=self.f_real > 0, has_l2=params is not None and origin is not None, ks=ks,

@@ -277,11 +277,13 @@ int bm_allgather_f32(bm_comm* comm, const float* mine, float* all, int64_t count
 /* Multi-Krum / Bulyan of the local slice in ONE call: partial squared distances -> all-reduce ->
  * score + stable rank (identical on every rank) -> selected mean / Bulyan pass 2 of the slice
  * (aggregators/krum.py:31-80, bulyan.py:31-84).  order_out (DEVICE, BM_MAX_ROWS int32, may be NULL)
- * receives the ranking.  ws: bm_sharded_workspace_bytes(n, d_local). */
+ * receives the ranking.  ws: bm_sharded_workspace_bytes(n, d_local).  d_total >= d_local is the length of the
+ * WHOLE vectors (all shards): the plan of the distance pass follows it, and every rank must state the same number
+ * (a short or empty trailing shard then plans exactly like its peers, whatever the world size). */
 int64_t bm_sharded_workspace_bytes(int n, int64_t d_local);
-int bm_sharded_krum(bm_comm* comm, const float* const* rows, int n, int64_t d_local, int f, int m,
+int bm_sharded_krum(bm_comm* comm, const float* const* rows, int n, int64_t d_local, int64_t d_total, int f, int m,
                     float* out_local, int32_t* order_out, void* ws, void* stream);
-int bm_sharded_bulyan(bm_comm* comm, const float* const* rows, int n, int64_t d_local, int f, int m,
+int bm_sharded_bulyan(bm_comm* comm, const float* const* rows, int n, int64_t d_local, int64_t d_total, int f, int m,
                       float* out_local, int32_t* order_out, void* ws, void* stream);
 
 /* The tail of bm_sharded_krum / bm_sharded_bulyan (all-reduce -> rank -> selected mean / pass 2) when the squared
@@ -328,7 +330,8 @@ typedef struct bm_step_params {
 int bm_step_stats_count(void);
 int64_t bm_step_workspace_bytes(int n, int64_t d_local);
 int bm_step_worker(bm_comm* comm, const bm_step_params* p, const float* const* sampled, float* const* buffers,
-                   int64_t d, float* defense_out, float* sampled_avg_out, float* honest_avg_out, float* byz_out,
+                   int64_t d, int64_t d_total /* >= d: all shards, as bm_sharded_krum */, float* defense_out,
+                   float* sampled_avg_out, float* honest_avg_out, float* byz_out,
                    float* attack_avg_out, const float* past_newest, float* curv, const float* past_oldest,
                    const float* params, const float* origin, double* stats_out, void* ws, void* stream);
 

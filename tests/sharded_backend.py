@@ -10,7 +10,15 @@ from oracle import gar_oracle as O
 
 
 class OracleBackend:
+  def __init__(self):
+    self.totals_seen = []  # the d_total every distance pass was handed (the tests check it is the true total)
+
+  def sum_over_ranks(self, agg, value):
+    t = torch.tensor([float(value)], dtype=torch.float64)
+    return int(agg.all_reduce_sum(t).item())
+
   def pairwise_sqdist(self, gradients, d_total=None):
+    self.totals_seen.append(d_total)
     n = len(gradients)
     sq = torch.zeros(n, n, dtype=torch.float64)
     g64 = [g.double() for g in gradients]

@@ -68,7 +68,12 @@ def test_new_entry_points_validate_arguments_without_gpu(lib):
   assert lib.bm_step_workspace_bytes(25, 1000) > lib.bm_sharded_workspace_bytes(25, 1000)
   assert lib.bm_step_stats_count() == 32
   par = _lib.StepParams(n=25, f_decl=5, f_real=5, ks=10, rule=0)  # ks < honest count
-  assert lib.bm_step_worker(None, ctypes.byref(par), rows, rows, 10, *([None] * 13)) == _lib.EINVAL
+  assert lib.bm_step_worker(None, ctypes.byref(par), rows, rows, 10, 10, *([None] * 13)) == _lib.EINVAL
+  ok = _lib.StepParams(n=25, f_decl=5, f_real=5, ks=20, rule=0)
+  assert lib.bm_step_worker(None, ctypes.byref(ok), rows, rows, 10, 9, *([None] * 13)) == _lib.EINVAL  # d_total < d
+  # round 4: the sharded rules take the length of the whole vectors (every rank states the same number)
+  assert lib.bm_sharded_krum(None, rows, 4, 10, 9, 1, 1, rows, None, rows, None) == _lib.EINVAL      # d_total < d_local
+  assert lib.bm_sharded_bulyan(None, rows, 7, 10, 9, 1, 4, rows, None, rows, None) == _lib.EINVAL
   assert lib.bm_comm_size(None) == 1
   assert lib.bm_allreduce_sum_f64(None, None, 4, None) == _lib.EINVAL
   assert lib.bm_comm_init(None, 1, 0, None) == _lib.EINVAL

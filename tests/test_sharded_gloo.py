@@ -47,6 +47,8 @@ def _worker(rank, world, port, queue):
     res["avg"] = agg.all_gather_output(avg, D)
     res["stats"] = (norm, dev, mx)
     res["sq"] = agg.global_sqdist(local)
+    # every distance pass of every rank was handed the TRUE total length (not d_local x ranks: the last shard is short)
+    res["totals_ok"] = bool(agg.backend.totals_seen) and all(t == D for t in agg.backend.totals_seen)
     # numpy arrays are pickled by value; torch tensors would be shared through file descriptors of
     # this process, which may already have exited when the parent rebuilds them
     queue.put((rank, {k: (v.detach().numpy().copy() if torch.is_tensor(v) else v) for k, v in res.items()}))
@@ -88,6 +90,7 @@ def test_two_rank_sharded_aggregation_matches_single_process():
     d64 = torch.from_numpy(O.pairwise_distances(rows, "f64")) ** 2
     assert torch.allclose(got["sq"], d64, rtol=1e-12)
   assert torch.equal(results[0]["sq"], results[1]["sq"])   # every rank ranks the same bits
+  assert results[0]["totals_ok"] and results[1]["totals_ok"]
 
 
 def _a2a_worker(rank, world, port, n, d, queue):
