@@ -298,6 +298,45 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
 
   // ---- main loop: loads of the next chunk(s) stay in flight under the MFMAs of this one ----
   int64_t c = gw;
+  if constexpr (ALIGNED) {
+    // Steady state, free of conditions.  The compiler places `s_waitcnt vmcnt(N)` from what it can PROVE is in flight:
+    // with the refill behind `if (nxt < nchunks)` (the generic loop below) it has to assume the path that issued
+    // nothing, so the first use of set b waited for everything issued after it as well — the refill of the other set
+    // had one `multiply` (24 MFMAs at K = 7) to arrive instead of a whole iteration, and the two register sets bought
+    // nothing (round 3: K = 7 at 0.73 of the HBM peak, K = 13 with ONE set at 0.84).  Here every chunk index is a full
+    // chunk by the loop bound, every issue is unconditional, and the counts come out exact: set b is consumed with
+    // the NSETS - 1 younger sets still in flight.  Same chunks, same order per wave as the generic loop: same bits.
+    const int64_t full = d / kB3Chunk;  // chunks that lie entirely inside the row
+    auto issue_fast = [&](int64_t cc, f32x4 (&v)[K]) {
+      const int64_t coord = cc * kB3Chunk + 4 * x;
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        int r = 4 * k + rho;
+        if (k == K - 1) r = r < n ? r : n - 1;
+        v[k] = __builtin_nontemporal_load(reinterpret_cast<const GlobalF4*>((GlobalF)row_ptr[r] + coord));
+      }
+    };
+    if (c + (2 * NSETS - 1) * nw < full) {
+#pragma unroll
+      for (int b = 0; b < NSETS; ++b) issue_fast(c + b * nw, xs[b]);
+      do {
+#pragma unroll
+        for (int b = 0; b < NSETS; ++b) {
+          contract(xs[b], c + b * nw);
+          issue_fast(c + (NSETS + b) * nw, xs[b]);
+          multiply(c + b * nw);
+        }
+        c += NSETS * nw;
+      } while (c + (2 * NSETS - 1) * nw < full);
+      // drain: the chunks c + b nw were loaded by the last iteration; what is left after them is the generic loop's
+#pragma unroll
+      for (int b = 0; b < NSETS; ++b) {
+        contract(xs[b], c + b * nw);
+        multiply(c + b * nw);
+      }
+      c += NSETS * nw;
+    }
+  }
 #pragma unroll
   for (int b = 0; b < NSETS; ++b)
     if (c + b * nw < nchunks) issue(c + b * nw, xs[b]);

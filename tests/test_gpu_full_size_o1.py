@@ -33,7 +33,7 @@ def bm():
 
 @pytest.fixture(scope="module")
 def ref():
-  torch.set_num_threads(os.cpu_count() or 1)
+  torch.set_num_threads(min(32, os.cpu_count() or 1))  # the per-pair torch ops do not scale past it (256 threads: 174 s at C3, 32: 16 s)
   if reference_loader.available():
     return reference_loader.load(with_native=False)[0]
   return None
