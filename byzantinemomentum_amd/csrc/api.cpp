@@ -19,7 +19,8 @@ static double env_double(const char* name, double dflt) {
 const Tuning& tuning() {
   static const Tuning t = {env_int("BM_COL_BURST", 8),  env_int("BM_MEAN_BURST", 8),
                            env_int("BM_STEP_BURST", 8), env_int("BM_STEP_STREAM", 0), env_int("BM_PAIR_MODE", 0),
-                           env_int("BM_PAIR_PLANES", 0), env_int("BM_PAIR_DITHER", 0), env_double("BM_PAIR_TAU", 2e-3)};
+                           env_int("BM_PAIR_PLANES", 0), env_int("BM_PAIR_DITHER", 0), env_double("BM_PAIR_TAU", 2e-3),
+                           env_int("BM_STUDY_BURST", 8)};
   return t;
 }
 }  // namespace bm

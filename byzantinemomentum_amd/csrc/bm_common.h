@@ -278,6 +278,7 @@ struct Tuning {
   int pair_planes;     // BM_PAIR_PLANES (mode 0): 0 (default) by length, 2 or 3 forced
   int pair_dither;     // BM_PAIR_DITHER (mode 0, two planes): seed of the coordinate dither (default 0); -1 = round to nearest (A/B)
   double pair_tau;     // BM_PAIR_TAU: accuracy gate of mode 0 (see gram_to_sqdist_kernel); <= 0 disables
+  int study_burst;     // BM_STUDY_BURST: iterations per CU from which bm_study_stats takes its burst form (default 8; 0 = never, 1 = always: tests)
 };
 const Tuning& tuning();
 }  // namespace bm

@@ -16,7 +16,8 @@
 // sequential mean a = (byz + ... + byz) / f and its deviations are rebuilt per element from byz with exactly the
 // operations of tools/pytorch.py:105-125 (stack_stats_kernel on f aliased rows).
 //
-// Reductions: per-lane fp32 partials over a few dozen columns, fp64 per workgroup, finished in a fixed order by a
+// Reductions: per-lane fp32 partials (the plain form: over the lane's columns of the whole grid-stride loop, d / 2^21
+// elements; the burst form below: 32 elements, then fp64), fp64 per workgroup, finished in a fixed order by a
 // one-workgroup kernel: deterministic, no atomics, no host synchronisation.
 #include "bm_common.h"
 
@@ -157,6 +158,168 @@ __global__ __launch_bounds__(kStudyBlock) void study_stats_kernel(StudyArgs a, i
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Burst form (CM >= 1, 16-byte columns, long vectors, no attack-average output): the same loads and the same
+// arithmetic per element, but the ONE written stream — the curvature combination C — leaves the CU in bursts
+// that coincide across the chip, like the results of colwise_burst_kernel (colwise_kernels.h): a write stream that
+// trickles out between the reads of 256 CUs costs about twice its bytes on this HBM system, and here it is one
+// stream in eight.  One workgroup of 1024 lanes per CU walks the column groups interleaved with the other CUs,
+// two groups per lane and iteration (14 loads of 16 bytes in flight per lane instead of 7), stages kStudySlots
+// iterations of C in LDS, meets at a barrier and writes them back to back.
+// The per-lane fp32 partial sums are folded into fp64 at every burst (32 elements per sum), so the length of an fp32
+// chain no longer grows with d (the plain form: one chain per lane over the whole grid-stride loop).
+// ---------------------------------------------------------------------------------------------------
+constexpr int kStudyBurstThreads = 1024;
+constexpr int kStudySlots = 8;  // iterations staged per burst: 8 x 1024 lanes x 16 B = 128 KB of LDS
+
+template <bool ATT, int CM, bool L2>
+__global__ __launch_bounds__(kStudyBurstThreads) void study_stats_burst_kernel(StudyArgs a, int f_real, float mu,
+                                                                               float w_oldest, uint32_t nvec,
+                                                                               double* __restrict__ partial) {
+  static_assert(CM >= 1, "without a written stream there is nothing to burst");
+  constexpr int VEC = 4;
+  constexpr int U = (L2 && CM >= 2) ? 1 : 2;  // column groups per lane and iteration (with params / origin two do not fit 128 VGPRs)
+  using V = typename VecLoad<VEC>::T;
+  __shared__ V stage[kStudySlots * kStudyBurstThreads];
+  __shared__ double red[kStudyBurstThreads / 64];
+  __shared__ float mred[kStudyBurstThreads / 64];
+  float acc[kStudySums];
+  double acc64[kStudySums];
+#pragma unroll
+  for (int i = 0; i < kStudySums; ++i) {
+    acc[i] = 0.0f;
+    acc64[i] = 0.0;
+  }
+  float amax = 0.0f, dmax = 0.0f;
+  bool a_nan = false, d_nan = false;
+  const float ff = (float)f_real;
+  const uint32_t tid = threadIdx.x;
+  const uint32_t span = gridDim.x * kStudyBurstThreads;  // column groups per iteration of the whole grid
+  const uint32_t iters = (nvec + span - 1) / span;
+  const uint32_t first = blockIdx.x * kStudyBurstThreads + tid;
+  for (uint32_t p0 = 0; p0 < iters; p0 += kStudySlots) {
+    const uint32_t p1 = (p0 + kStudySlots < iters) ? p0 + kStudySlots : iters;
+    for (uint32_t it = p0; it < p1; it += U) {
+      float s[U][VEC], h[U][VEC], df[U][VEC], bz[U][VEC], pa[U][VEC], cv[U][VEC], ol[U][VEC], pp[U][VEC], oo[U][VEC];
+      bool live[U];
+      // every load of the iteration is issued before the first use
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t v = (it + u) * span + first;
+        live[u] = (it + u) < p1 && v < nvec;
+        if (live[u]) {
+          const int64_t j = (int64_t)v * VEC;
+          load_stream<VEC>(a.s + j, s[u]);
+          load_stream<VEC>(a.h + j, h[u]);
+          load_stream<VEC>(a.def + j, df[u]);
+          if constexpr (ATT) load_stream<VEC>(a.byz + j, bz[u]);
+          if constexpr (CM >= 2) {
+            load_stream<VEC>(a.past + j, pa[u]);
+            load_stream<VEC>(a.curv + j, cv[u]);
+          }
+          if constexpr (CM == 3) load_stream<VEC>(a.oldest + j, ol[u]);
+          if constexpr (L2) {
+            load_stream<VEC>(a.params + j, pp[u]);
+            load_stream<VEC>(a.origin + j, oo[u]);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (!live[u]) continue;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) {
+          float av = 0.0f;
+          if constexpr (ATT) {
+            // grad_avg = samples[0].clone(); add_(...) f - 1 times; div_(f)   (tools/pytorch.py:108-111)
+            float t = bz[u][c];
+            for (int i = 1; i < f_real; ++i) t += bz[u][c];
+            t = t / ff;
+            av = t;
+            amax = fmaxf(amax, __builtin_fabsf(t));
+            a_nan |= (t != t);
+            const float dd = bz[u][c] - t;
+            float q = 0.0f;
+            for (int i = 0; i < f_real; ++i) q = __builtin_fmaf(dd, dd, q);
+            acc[12] += q;
+          }
+          dmax = fmaxf(dmax, __builtin_fabsf(df[u][c]));
+          d_nan |= (df[u][c] != df[u][c]);
+          acc[0] = __builtin_fmaf(s[u][c], s[u][c], acc[0]);
+          acc[1] = __builtin_fmaf(s[u][c], h[u][c], acc[1]);
+          acc[2] = __builtin_fmaf(s[u][c], df[u][c], acc[2]);
+          acc[4] = __builtin_fmaf(h[u][c], h[u][c], acc[4]);
+          acc[5] = __builtin_fmaf(h[u][c], df[u][c], acc[5]);
+          acc[7] = __builtin_fmaf(df[u][c], df[u][c], acc[7]);
+          if constexpr (ATT) {
+            acc[3] = __builtin_fmaf(s[u][c], av, acc[3]);
+            acc[6] = __builtin_fmaf(h[u][c], av, acc[6]);
+            acc[8] = __builtin_fmaf(df[u][c], av, acc[8]);
+            acc[9] = __builtin_fmaf(av, av, acc[9]);
+          }
+          if constexpr (CM >= 2) {
+            acc[10] = __builtin_fmaf(s[u][c], pa[u][c], acc[10]);
+            acc[11] = __builtin_fmaf(s[u][c], cv[u][c], acc[11]);
+          }
+          if constexpr (L2) {
+            const float e = pp[u][c] - oo[u][c];
+            acc[13] = __builtin_fmaf(e, e, acc[13]);
+          }
+          // curvature combination for the NEXT step: the arithmetic of study_stats_kernel, same bits per element
+          if constexpr (CM == 1) cv[u][c] = s[u][c];
+          if constexpr (CM == 3) cv[u][c] = __builtin_fmaf(w_oldest, ol[u][c], 1.0f * cv[u][c]);
+          if constexpr (CM >= 2) cv[u][c] = __builtin_fmaf(1.0f, s[u][c], mu * cv[u][c]);
+        }
+        V packed;
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) packed[c] = cv[u][c];
+        stage[(it + u - p0) * kStudyBurstThreads + tid] = packed;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < kStudySums; ++i) {  // fp32 chains end here: 32 elements each
+      acc64[i] += (double)acc[i];
+      acc[i] = 0.0f;
+    }
+    __syncthreads();  // not for the data (a lane reads back its own slots): it is what makes the stores a burst
+    for (uint32_t it = p0; it < p1; ++it) {
+      const uint32_t v = it * span + first;
+      if (v < nvec)
+        __builtin_nontemporal_store(stage[(it - p0) * kStudyBurstThreads + tid], reinterpret_cast<V*>(a.curv + (int64_t)v * VEC));
+    }
+  }
+  if (a_nan) amax = __builtin_nanf("");
+  if (d_nan) dmax = __builtin_nanf("");
+  constexpr int64_t kSlotStride = kStudyMaxBlocks + 1;
+  double* p = partial + blockIdx.x;
+#pragma unroll
+  for (int i = 0; i < kStudySums; ++i) {
+    const double r = block_reduce_sum<kStudyBurstThreads>(acc64[i], red);
+    if (threadIdx.x == 0) p[i * kSlotStride] = r;
+  }
+  float m2[2] = {amax, dmax};
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    float m = m2[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float o = __shfl_down(m, off, 64);
+      m = (m != m || o != o) ? __builtin_nanf("") : fmaxf(m, o);
+    }
+    if ((threadIdx.x & 63) == 0) mred[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      float mm = mred[0];
+      for (int wv = 1; wv < kStudyBurstThreads / 64; ++wv) {
+        const float o = mred[wv];
+        mm = (mm != mm || o != o) ? __builtin_nanf("") : fmaxf(mm, o);
+      }
+      p[(kStudySums + k) * kSlotStride] = (double)mm;
+    }
+    __syncthreads();
+  }
+}
+
 // out (BM_STUDY_SLOTS doubles, layout in include/bm_gar.h) from the per-workgroup partials, fixed order:
 // one wave per slot, lane l adds the partials of workgroups l, l + 64, ..., then a fixed shuffle tree.
 __global__ __launch_bounds__(64) void study_finish_kernel(const double* __restrict__ partial, int nparts,
@@ -235,6 +398,27 @@ static int launch_study_cm(const StudyArgs& a, int cm, int vec, int f_real, floa
   }
 }
 
+template <bool ATT, bool L2>
+static int launch_study_burst(const StudyArgs& a, int cm, int f_real, float mu, float w, int64_t n, int grid,
+                              double* partial, hipStream_t s) {
+  const uint32_t nv = (uint32_t)n;
+  if (cm == 1)
+    hipLaunchKernelGGL((study_stats_burst_kernel<ATT, 1, L2>), dim3(grid), dim3(kStudyBurstThreads), 0, s, a, f_real, mu, w, nv, partial);
+  else if (cm == 2)
+    hipLaunchKernelGGL((study_stats_burst_kernel<ATT, 2, L2>), dim3(grid), dim3(kStudyBurstThreads), 0, s, a, f_real, mu, w, nv, partial);
+  else
+    hipLaunchKernelGGL((study_stats_burst_kernel<ATT, 3, L2>), dim3(grid), dim3(kStudyBurstThreads), 0, s, a, f_real, mu, w, nv, partial);
+  BM_LAUNCH_CHECK();
+  return 0;
+}
+
+// The burst form pays from a few iterations per CU on (BM_STUDY_BURST, default 8; 0 = never, 1 = always: tests).
+static bool study_burst_eligible(const StudyArgs& a, int cm, int vec, int64_t nvec) {
+  const int threshold = tuning().study_burst;
+  if (threshold <= 0 || cm < 1 || vec != 4 || a.a_out != nullptr || nvec >= ((int64_t)1 << 30)) return false;
+  return nvec >= (int64_t)threshold * compute_units() * kStudyBurstThreads;
+}
+
 static int launch_study(const StudyArgs& a, bool att, bool l2, int cm, int vec, int f_real, float mu, float w, int64_t n,
                         int grid, double* partial, hipStream_t s) {
   if (att) return l2 ? launch_study_cm<true, true>(a, cm, vec, f_real, mu, w, n, grid, partial, s)
@@ -272,8 +456,20 @@ extern "C" int bm_study_stats(const float* sampled_avg, const float* honest_avg,
   int rc = 0;
   if (vec >= 2 && d / vec > 0) {
     const int64_t nvec = d / vec;
-    const int grid = stream_grid(nvec, kStudyBlock, kStudyMaxBlocks);
-    rc = launch_study(a, att, l2, curv_mode, vec, f_real, mu, oldest_weight, nvec, grid, partial, s);
+    int grid;
+    if (study_burst_eligible(a, curv_mode, vec, nvec)) {
+      grid = compute_units();  // one workgroup of 1024 lanes per CU (<= kStudyMaxBlocks partial sets)
+      if (grid > kStudyMaxBlocks) grid = kStudyMaxBlocks;
+      if (att)
+        rc = l2 ? launch_study_burst<true, true>(a, curv_mode, f_real, mu, oldest_weight, nvec, grid, partial, s)
+                : launch_study_burst<true, false>(a, curv_mode, f_real, mu, oldest_weight, nvec, grid, partial, s);
+      else
+        rc = l2 ? launch_study_burst<false, true>(a, curv_mode, f_real, mu, oldest_weight, nvec, grid, partial, s)
+                : launch_study_burst<false, false>(a, curv_mode, f_real, mu, oldest_weight, nvec, grid, partial, s);
+    } else {
+      grid = stream_grid(nvec, kStudyBlock, kStudyMaxBlocks);
+      rc = launch_study(a, att, l2, curv_mode, vec, f_real, mu, oldest_weight, nvec, grid, partial, s);
+    }
     if (rc != 0) return rc;
     nparts = grid;
     body = nvec * vec;

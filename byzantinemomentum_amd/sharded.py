@@ -251,11 +251,19 @@ class ShardedAggregator:
     return comm, None
 
   # -- collectives (never called when world_size == 1) ----------------------- #
+  # Every exchange of this class goes through the three primitives below (a subclass may route them elsewhere:
+  # tests/test_gpu_multirank.py stages them through host tensors to run several ranks on ONE GPU over gloo).
 
   def _all_reduce(self, tensor, op=None):
     if self.collective:
       dist.all_reduce(tensor, op=(op or dist.ReduceOp.SUM), group=self.group)
     return tensor
+
+  def _all_gather_into(self, everyone, mine):
+    dist.all_gather_into_tensor(everyone, mine, group=self.group)
+
+  def _all_to_all(self, recv, send):
+    dist.all_to_all_single(recv, send, group=self.group)
 
   def all_reduce_sum(self, tensor):
     """In-place sum over the ranks of a small device tensor (no-op with one rank)."""
@@ -270,7 +278,7 @@ class ShardedAggregator:
     ns = sums.shape[0]
     mine = torch.cat([sums, maxes]).contiguous()
     everyone = torch.empty(self.world_size * mine.shape[0], dtype=mine.dtype, device=mine.device)
-    dist.all_gather_into_tensor(everyone, mine, group=self.group)
+    self._all_gather_into(everyone, mine)
     everyone = everyone.view(self.world_size, -1)
     total = everyone[0, :ns].clone()
     for r in range(1, self.world_size):
@@ -286,7 +294,7 @@ class ShardedAggregator:
     padded = torch.zeros(per, dtype=local_out.dtype, device=local_out.device)
     padded[:local_out.shape[0]] = local_out
     full = torch.empty(per * self.world_size, dtype=local_out.dtype, device=local_out.device)
-    dist.all_gather_into_tensor(full, padded, group=self.group)
+    self._all_gather_into(full, padded)
     return full[:d]
 
   def to_dim_sharded(self, my_gradients, n, d, dtype=torch.float32, device=None):
@@ -317,7 +325,7 @@ class ShardedAggregator:
       if full < world and g.shape[0] > full * per:
         send[full, j, :g.shape[0] - full * per] = g[full * per:]
     recv = torch.empty_like(send)
-    dist.all_to_all_single(recv.view(-1), send.view(-1), group=self.group)
+    self._all_to_all(recv.view(-1), send.view(-1))
     lo, hi = shard_bounds(d, world, rank)
     return [recv[i % world, i // world, :hi - lo] for i in range(n)]
 

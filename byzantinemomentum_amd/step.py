@@ -180,7 +180,8 @@ class AggregationStep:
     """params <- params - mu*lr*momentum in place (attack.py:760-767): the parameter shift before
     the gradients of a Nesterov step are computed.  worker: index of the worker momentum buffer
     (worker placement), else the server momentum."""
-    mom = self.buffers[worker] if worker is not None else self.server_momentum
+    # (before the first step every momentum is zero, attack.py:676-678: the shift is then the identity)
+    mom = (self.buffers[worker] if self.buffers is not None else None) if worker is not None else self.server_momentum
     if mom is not None:
       self.ops.multi_fma3([params], [params], [mom], 1.0, -(self.mu * lr))
     return params

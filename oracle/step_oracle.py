@@ -74,6 +74,7 @@ class ReferenceLoop:
       attacks, self.last_factor, self.last_search = O.identical_attack(
         honests, self.f_real, self.f_decl, rule, self.attack, -self.evals, self.negative, self.precision)
     grads = list(honests) + attacks
+    self.last_gradients = grads  # what the rule saw (tests look at single columns of it: exact-tie identification)
     defense = rule(grads, self.f_decl)
     if params is None:
       l2 = math.nan

@@ -1,0 +1,193 @@
+"""Several ranks of the dim-sharded path with the HIP kernels underneath — on ONE MI355X.
+
+`gpurun` hands out one GPU, so no RCCL job of more than one rank can run there; the gloo tests cover the
+partitioning logic with an oracle backend on CPU.  What neither covers is the REAL kernels on ragged and empty
+shards inside a multi-rank job.  Here 2-4 processes share `cuda:0`, each holds its coordinate slice as GPU tensors
+and runs `ShardedAggregator(native_comm=False)` with the product's HipBackend; only the transport of the (tiny)
+exchanges is replaced: the three collective primitives of the class are staged through host tensors over gloo.
+Every rank compares its slice with the UNSHARDED HIP call on the full vectors (which it can make itself: the
+GPU is shared), so the kernels are checked against themselves across world sizes and, through the other GPU
+tests, against the oracle.  SURVEY.md §8e; BASELINE.json configs[3], configs[4].
+"""
+
+import math
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import gar_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+N, F = 25, 5
+
+
+def _free_port():
+  with socket.socket() as s:
+    s.bind(("127.0.0.1", 0))
+    return s.getsockname()[1]
+
+
+def _staged_aggregator():
+  from byzantinemomentum_amd.sharded import ShardedAggregator
+
+  class HostStaged(ShardedAggregator):
+    """The product's sharded rules; the bytes of each exchange travel through host memory (gloo)."""
+
+    def _all_reduce(self, tensor, op=None):
+      if self.collective:
+        host = tensor.cpu()
+        dist.all_reduce(host, op=(op or dist.ReduceOp.SUM), group=self.group)
+        tensor.copy_(host)
+      return tensor
+
+    def _all_gather_into(self, everyone, mine):
+      parts = [torch.empty(mine.shape, dtype=mine.dtype) for _ in range(self.world_size)]
+      dist.all_gather(parts, mine.cpu(), group=self.group)
+      everyone.copy_(torch.cat([p.reshape(-1) for p in parts]).to(everyone.device))
+
+    def _all_to_all(self, recv, send):
+      world = self.world_size
+      src = list(send.cpu().chunk(world))
+      dst = [torch.empty_like(s) for s in src]
+      # gloo has no all_to_all: P broadcasts of what each rank sends, every receiver keeps its own part
+      for r in range(world):
+        box = [s.clone() for s in src] if r == self.rank else [torch.empty_like(s) for s in src]
+        for part in box:
+          dist.broadcast(part, src=r, group=self.group)
+        dst[r] = box[self.rank]
+      recv.copy_(torch.cat(dst).to(recv.device))
+
+  return HostStaged(native_comm=False)
+
+
+def _shard(rows, lo, hi):
+  seen = {}
+  return [seen.setdefault(id(g), g[lo:hi].to(DEV)) for g in rows]
+
+
+def _close(a, b, tol, what):
+  scale = max(float(b.abs().max()) if b.numel() else 0.0, 1e-30)
+  err = float((a - b).abs().max()) if b.numel() else 0.0
+  assert err <= tol * scale, (what, err, scale)
+
+
+def _worker(rank, world, port, d, queue):
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+  dist.init_process_group("gloo", rank=rank, world_size=world)
+  try:
+    torch.cuda.set_device(0)
+    import byzantinemomentum_amd as bm
+    from byzantinemomentum_amd.sharded import HipBackend, owned_workers, shard_bounds
+    from byzantinemomentum_amd.step import AggregationStep
+    agg = _staged_aggregator()
+    assert isinstance(agg.backend, HipBackend) and agg.world_size == world and agg.collective and agg.native is None
+    lo, hi = shard_bounds(d, world, rank)
+    report = {"shard": (lo, hi)}
+    for kind in ("hetero", "little"):
+      rows, h = O.make_stack(kind, N, F, d, seed=1234)
+      local = _shard(rows, lo, hi)
+      full = _shard(rows, 0, d)
+      assert agg.total_length(hi - lo) == d
+      # the all-reduced squared distances against the single-GPU pass on the whole vectors
+      sq = agg.global_sqdist(local)
+      want_sq = bm.gars.pairwise_sqdist(full)
+      off = ~torch.eye(N, dtype=torch.bool, device=DEV) & (want_sq > 0)
+      assert float(((sq - want_sq).abs()[off] / want_sq[off]).max()) <= 1e-6, kind
+      assert float(sq[h, h + 1]) == 0.0  # aliased Byzantine rows: exactly zero on every shard, hence in the sum
+      # selections: identical to the unsharded call (the decisive gaps of these stacks are far above the 1e-6 above)
+      for name, sharded, single in (("krum", lambda: agg.krum(local, F), lambda: bm.krum(full, F)),
+                                    ("krum m=1", lambda: agg.krum(local, F, 1), lambda: bm.krum(full, F, 1)),
+                                    ("bulyan", lambda: agg.bulyan(local, F), lambda: bm.bulyan(full, F)),
+                                    ("aksel", lambda: agg.aksel(local, F), lambda: bm.aksel(full, F)),
+                                    ("cge", lambda: agg.cge(local, F), lambda: bm.cge(full, F)),
+                                    ("brute", lambda: agg.brute(local, F), lambda: bm.brute(full, F))):
+        got, want = sharded(), single()
+        assert got.shape[0] == hi - lo
+        if name == "bulyan":  # pass 2 may keep either of two exactly tied deviations: allow isolated columns only if tied
+          bad = (got - want[lo:hi]).abs() > 2e-6 * float(want.abs().max())
+          assert int(bad.sum()) <= max(1, (hi - lo) // 10000), (kind, name, int(bad.sum()))
+        else:
+          assert torch.equal(got, want[lo:hi]), (kind, name)
+        whole = agg.all_gather_output(got, d)
+        assert whole.shape[0] == d and torch.equal(whole[lo:hi], got)
+      # the coordinate-wise rules need no exchange: bit-identical slices
+      assert torch.equal(agg.median(local), bm.median(full)[lo:hi])
+      assert torch.equal(agg.trmean(local, F), bm.trmean(full, F)[lo:hi])
+      assert torch.equal(agg.phocas(local, F), bm.phocas(full, F)[lo:hi])
+      # statistics through the packed exchange
+      avg, norm, dev, mx = agg.compute_avg_dev_max(local[:h])
+      wavg, wnorm, wdev, wmx = bm.compute_avg_dev_max(full[:h])
+      assert torch.equal(avg, wavg[lo:hi])
+      assert abs(norm - wnorm) <= 1e-9 * wnorm and abs(dev - wdev) <= 1e-9 * wdev and mx == wmx
+      report[kind] = (norm, dev, mx)
+    # worker-parallel production -> dimension-major, GPU tensors through the (staged) all-to-all
+    rows, _ = O.make_stack("iid", N, 0, d, seed=77)
+    mine = [rows[i].to(DEV) for i in owned_workers(N, world, rank)]
+    got = agg.to_dim_sharded(mine, N, d, device=torch.device(DEV))
+    assert len(got) == N
+    for i in range(N):
+      assert got[i].device.type == "cuda" and torch.equal(got[i].cpu(), rows[i][lo:hi]), i
+    if hi > lo:
+      assert torch.equal(agg.median(got), bm.median(_shard(rows, 0, d))[lo:hi])  # views of the receive buffer feed the kernels
+    # the full step (worker momentum, empire, study block) on the slice against the single-rank step on the whole vectors
+    for gar in ("krum", "bulyan", "median"):
+      sharded = AggregationStep(N, F, F, gar=gar, momentum=0.9, dampening=0.9, attack_factor=1.1, nb_past=2, aggregator=agg)
+      single = AggregationStep(N, F, F, gar=gar, momentum=0.9, dampening=0.9, attack_factor=1.1, nb_past=2)
+      gen = torch.Generator().manual_seed(5)
+      origin = torch.randn(d, generator=gen)
+      params = origin + 0.01
+      for it in range(4):
+        base = 0.2 * torch.randn(d, generator=gen)
+        sampled = [base + (0.5 + 0.05 * i) * torch.randn(d, generator=gen) for i in range(N - F)]
+        got_def = sharded.run([g[lo:hi].to(DEV) for g in sampled], params[lo:hi].to(DEV), origin[lo:hi].to(DEV))
+        got = sharded.floats()
+        want_def = single.run([g.to(DEV) for g in sampled], params.to(DEV), origin.to(DEV))
+        want = single.floats()
+        if gar == "median":
+          assert torch.equal(got_def, want_def[lo:hi]), (gar, it)
+        else:
+          _close(got_def, want_def[lo:hi], 2e-6, (gar, it))
+        for key, val in want.items():
+          g = got[key]
+          assert (math.isnan(g) and math.isnan(val)) or abs(g - val) <= 1e-6 * max(abs(val), 1e-6), (gar, it, key, g, val)
+        report[(gar, it)] = tuple(sorted((k, v) for k, v in got.items() if not math.isnan(v)))
+    torch.cuda.synchronize()
+    queue.put((rank, report))
+    dist.barrier()
+  finally:
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,d", [(2, 200003), (3, 130), (4, 300), (4, 1 << 20)])
+def test_multi_rank_sharded_path_on_the_hip_kernels(world, d):
+  """world 2, d = 200 003: two long ragged shards (the second one is not a multiple of 4 coordinates long: the
+  kernels' tail paths); world 3, d = 130: shards of 64, 64 and 2 coordinates; world 4, d = 300: 128, 128, 44 and an
+  EMPTY one; world 4, d = 2^20: the length at which the distance pass changes its split plan — every rank must plan
+  from the total, not from its 262 144 coordinates."""
+  ctx = mp.get_context("spawn")
+  queue = ctx.Queue()
+  port = _free_port()
+  procs = [ctx.Process(target=_worker, args=(r, world, port, d, queue)) for r in range(world)]
+  for p in procs:
+    p.start()
+  results = {}
+  try:
+    for _ in range(world):
+      rank, rep = queue.get(timeout=800)
+      results[rank] = rep
+  finally:
+    for p in procs:
+      p.join(timeout=120)
+  assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+  # every rank decoded the same floats from the same packed exchange
+  keys = [k for k in results[0] if k != "shard"]
+  for r in range(1, world):
+    for k in keys:
+      assert results[r][k] == results[0][k], (r, k)

