@@ -101,6 +101,8 @@ SIGNATURES = {
   "bm_allreduce_sum_f64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]),
   "bm_allgather_f32": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                       ctypes.c_void_p]),
+  "bm_brute_select_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p]),
   "bm_sharded_workspace_bytes": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int64]),
   "bm_sharded_krum": (ctypes.c_int, [ctypes.c_void_p, _c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                      ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),

@@ -400,9 +400,11 @@ __device__ __forceinline__ void gram_to_sqdist(const double* __restrict__ gram, 
     const int i = e / n_full, j = e - i * n_full;
     const int ci = i < n ? i : n - 1, cj = j < n ? j : n - 1;
     if (ci == cj) {
-      // the diagonal (a row with a non-finite coordinate is at non-finite distance of everything, itself
-      // included in the reference, x - x = nan; keep 0, it is never read) and pairs of aliased copies
-      sq[e] = 0.0;
+      // the diagonal (never read: 0) and pairs of aliased copies: exactly 0 when the row is finite; a row with a
+      // non-finite coordinate is at non-finite distance of everything, its own copies included (x - x = nan in
+      // krum.py:44-47, which the rules turn into +inf; bm_pairwise_sqdist on the expanded stack says NaN too)
+      const double gdd = gram[b3_tri_index(ci, ci, n)];
+      sq[e] = (i != j && !(fabs(gdd) < __builtin_inf())) ? __builtin_nan("") : 0.0;
       continue;
     }
     const int lo = ci < cj ? ci : cj, hi = ci < cj ? cj : ci;

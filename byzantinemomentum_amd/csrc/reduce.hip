@@ -335,8 +335,10 @@ __global__ __launch_bounds__(kRedBlock) void row_sqnorms_kernel(RowTable rows, i
   __shared__ double red[kRedBlock / 64];
   const float* row = rows.p[blockIdx.y];
   float acc[2] = {0.0f, 0.0f};
+  double wide = 0.0;  // the fp32 chains are folded into fp64 every 16 iterations: their length does not grow with d
   const int64_t stride = (int64_t)gridDim.x * kRedBlock;
   int64_t v = (int64_t)blockIdx.x * kRedBlock + threadIdx.x;
+  int since = 0;
   for (; v + stride < nvec; v += 2 * stride) {  // two loads in flight per lane
     float a[VEC], b[VEC];
     load_stream<VEC>(row + v * VEC, a);
@@ -346,6 +348,11 @@ __global__ __launch_bounds__(kRedBlock) void row_sqnorms_kernel(RowTable rows, i
       acc[0] = __builtin_fmaf(a[e], a[e], acc[0]);
       acc[1] = __builtin_fmaf(b[e], b[e], acc[1]);
     }
+    if (++since == 16) {
+      wide += (double)acc[0] + (double)acc[1];
+      acc[0] = acc[1] = 0.0f;
+      since = 0;
+    }
   }
   if (v < nvec) {
     float a[VEC];
@@ -353,7 +360,7 @@ __global__ __launch_bounds__(kRedBlock) void row_sqnorms_kernel(RowTable rows, i
 #pragma unroll
     for (int e = 0; e < VEC; ++e) acc[0] = __builtin_fmaf(a[e], a[e], acc[0]);
   }
-  const double r = block_reduce_sum<kRedBlock>((double)acc[0] + (double)acc[1], red);
+  const double r = block_reduce_sum<kRedBlock>(wide + ((double)acc[0] + (double)acc[1]), red);
   if (threadIdx.x == 0) partial[(int64_t)blockIdx.y * gridDim.x + blockIdx.x] = r;
 }
 

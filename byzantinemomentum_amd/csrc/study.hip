@@ -16,8 +16,8 @@
 // sequential mean a = (byz + ... + byz) / f and its deviations are rebuilt per element from byz with exactly the
 // operations of tools/pytorch.py:105-125 (stack_stats_kernel on f aliased rows).
 //
-// Reductions: per-lane fp32 partials (the plain form: over the lane's columns of the whole grid-stride loop, d / 2^21
-// elements; the burst form below: 32 elements, then fp64), fp64 per workgroup, finished in a fixed order by a
+// Reductions: per-lane fp32 partials over at most 64 elements (the plain form folds them into fp64 every 16
+// iterations, the burst form at every burst), fp64 per lane, workgroup and grid, finished in a fixed order by a
 // one-workgroup kernel: deterministic, no atomics, no host synchronisation.
 #include "bm_common.h"
 
@@ -50,8 +50,13 @@ __global__ __launch_bounds__(kStudyBlock) void study_stats_kernel(StudyArgs a, i
   __shared__ double red[kStudyBlock / 64];
   __shared__ float mred[kStudyBlock / 64];
   float acc[kStudySums];
+  double acc64[kStudySums];  // the fp32 chains are folded into fp64 every 16 iterations (<= 64 elements each)
 #pragma unroll
-  for (int i = 0; i < kStudySums; ++i) acc[i] = 0.0f;
+  for (int i = 0; i < kStudySums; ++i) {
+    acc[i] = 0.0f;
+    acc64[i] = 0.0;
+  }
+  int since = 0;
   float amax = 0.0f, dmax = 0.0f;
   bool a_nan = false, d_nan = false;
   const float ff = (float)f_real;
@@ -123,6 +128,14 @@ __global__ __launch_bounds__(kStudyBlock) void study_stats_kernel(StudyArgs a, i
     if constexpr (ATT) {
       if (a.a_out != nullptr) store_stream<VEC>(a.a_out + j, av);
     }
+    if (++since == 16) {
+#pragma unroll
+      for (int i = 0; i < kStudySums; ++i) {
+        acc64[i] += (double)acc[i];
+        acc[i] = 0.0f;
+      }
+      since = 0;
+    }
   }
   if (a_nan) amax = __builtin_nanf("");  // torch's abs().max() propagates NaN; fmaxf does not
   if (d_nan) dmax = __builtin_nanf("");
@@ -131,7 +144,7 @@ __global__ __launch_bounds__(kStudyBlock) void study_stats_kernel(StudyArgs a, i
   double* p = partial + blockIdx.x;
 #pragma unroll
   for (int i = 0; i < kStudySums; ++i) {
-    const double r = block_reduce_sum<kStudyBlock>((double)acc[i], red);
+    const double r = block_reduce_sum<kStudyBlock>(acc64[i] + (double)acc[i], red);
     if (threadIdx.x == 0) p[i * kSlotStride] = r;
   }
   // NaN-propagating maxima

@@ -257,20 +257,51 @@ def brute_select_host(dist_host, n, f):
   return list(sel)
 
 
+def brute_select_device(sq, n, f):
+  """Subset search of the Brute rule on a DEVICE fp64 n x n matrix of SQUARED distances (bm_brute_select_device: one
+  wave, no host round trip).  Returns (sel int32[MAX_ROWS]: the n - f rows ascending, status int32[1]: 0, or -1 when
+  every subset touches a non-finite distance), both on the device."""
+  lib = _lib.load()
+  device = sq.device
+  sel = torch.empty(_lib.MAX_ROWS, dtype=torch.int32, device=device)
+  status = torch.empty(1, dtype=torch.int32, device=device)
+  with torch.cuda.device(device):
+    _lib.check(lib.bm_brute_select_device(_ptr(sq), n, f, _ptr(sel), _ptr(status), _stream(device)),
+               "bm_brute_select_device")
+  return sel, status
+
+
+def _brute_sel(gradients, f):
+  """(sel, status) of the stack, from the cache when `influence` follows `aggregate` on the same tensors
+  (attack.py:821-822): the distance pass is then not repeated."""
+  hit = _rank_cache_get("brute", gradients, (f,))
+  if hit is None:
+    n, d, device = _validate(gradients)
+    # brute keeps non-finite distances as they are and skips the subsets that contain one (brute.py:45,56-57)
+    hit = brute_select_device(pairwise_sqdist(gradients), n, f)
+    _rank_cache_put("brute", gradients, (f,), hit)
+  return hit
+
+
 def brute_selection(gradients, f, **kwargs):
-  """Index set (ascending) of the n-f rows of smallest diameter (aggregators/brute.py:32-68)."""
-  n, d, device = _validate(gradients)
-  # brute keeps non-finite distances as they are and skips the subsets that contain one
-  dist = pairwise_sqdist(gradients).sqrt().cpu().contiguous()  # the subset search is host work
-  return brute_select_host(dist, n, f)
+  """Index set (ascending) of the n-f rows of smallest diameter (aggregators/brute.py:32-68) — host list,
+  synchronises; raises when no subset of n-f rows has a finite diameter (the reference then has no selection)."""
+  n = len(gradients)
+  sel, status = _brute_sel(gradients, f)
+  if int(status.item()) != 0:
+    raise RuntimeError("brute: too many non-finite gradients, no subset of n-f rows has a finite diameter")
+  return sel[:n - f].tolist()
 
 
 def brute(gradients, f, **kwargs):
-  """Brute rule (aggregators/brute.py:70-80): mean of the minimum-diameter subset, index order."""
+  """Brute rule (aggregators/brute.py:70-80): mean of the minimum-diameter subset, index order.  Distances, subset
+  search and average all run on the device, on the caller's stream: no host synchronisation (graph-capturable).  When
+  no subset of n-f rows has a finite diameter — more than f gradients with non-finite coordinates, where the reference
+  has no selection at all (brute.py:56-57,68) — the result is the average of n-f copies of one such gradient, i.e.
+  non-finite where it is; `brute_selection` raises in that case."""
   n, d, device = _validate(gradients)
-  sel = brute_selection(gradients, f)
-  idx = torch.tensor(sel, dtype=torch.int32, device=device)
-  return selected_mean(gradients, idx, n - f)
+  sel, _ = _brute_sel(gradients, f)
+  return selected_mean(gradients, sel, n - f)
 
 
 def aksel_sqdist(gradients):

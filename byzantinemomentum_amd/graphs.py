@@ -15,13 +15,22 @@ bm_gar.h) frozen at the recorded addresses.
 
 What a replay does NOT do is run the Python of the call again: the shapes, the rule's arguments and the addresses
 are those of the recording.  Contents may change freely; a stack at other addresses needs its own GraphedCall.
+
+`fn` must not synchronise with the host while it is recorded.  Calls that do, and therefore cannot be graphed: the
+factor search of the attacks (`AggregationStep(attack_evals=...)`: `.item()` per evaluation), `floats()`, sharded
+rules over torch.distributed collectives that stage through the host, `ShardedAggregator.brute` (host search of the
+all-reduced matrix).  A failed recording raises GraphCaptureError and leaves nothing behind.
 """
 
 import torch
 
 from . import gars
 
-__all__ = ["GraphedCall"]
+__all__ = ["GraphedCall", "GraphCaptureError"]
+
+
+class GraphCaptureError(RuntimeError):
+  """`fn` could not be recorded into a HIP graph (it synchronised with the host, or a launch failed under capture)."""
 
 
 class GraphedCall:
@@ -44,8 +53,21 @@ class GraphedCall:
     torch.cuda.synchronize()
     gars.invalidate_rank_cache()
     # thread_local: RCCL's helper threads may call the runtime while this thread records
-    with torch.cuda.graph(self._graph, stream=side, capture_error_mode="thread_local"):
-      self.output = fn()
+    try:
+      with torch.cuda.graph(self._graph, stream=side, capture_error_mode="thread_local"):
+        self.output = fn()
+    except Exception as err:  # noqa: BLE001
+      # nothing of the failed recording may survive: the scratch entries the warm-up created for the side stream (a
+      # later stream that maps to the same handle would find them), the ranking cache, the half-built graph
+      for key in [k for k in gars._Scratch._cache if k[1] == side.cuda_stream]:
+        del gars._Scratch._cache[key]
+      gars.invalidate_rank_cache()
+      self._graph = None
+      torch.cuda.synchronize()
+      raise GraphCaptureError(
+        "the call could not be recorded into a HIP graph: it must not synchronise with the host while recording "
+        "(the attacks' factor search, floats(), host-staged collectives and the sharded brute rule do; see the module "
+        f"docstring) — {type(err).__name__}: {err}") from err
     gars.invalidate_rank_cache()  # (the entry the recording left points into the graph's private pool)
     # the scratch buffers the recorded kernels use belong to gars._Scratch, keyed by (device, stream): a later call on
     # a stream that maps to the same handle with another size would replace — and free — them under the graph

@@ -53,16 +53,30 @@ class NativeComm:
   per aggregation with the all-reduce issued from C on the caller's stream.  Bootstrapped through the
   existing torch.distributed group (rank 0's unique id is broadcast as a Python object)."""
 
-  def __init__(self, group=None):
+  def __init__(self, group=None, vote=None):
+    """vote(ok) -> bool: "did this step succeed on EVERY rank?" (a collective of the torch group).  With it, no rank
+    can be left alone in a collective: the unique id is only broadcast once every rank knows rank 0 made one, and a
+    failure of bm_comm_init on one rank is learnt by all (the caller's last vote).  Without it (vote=None) a failure
+    simply raises on the rank it happens on."""
     lib = _lib.load()
     if not lib.bm_comm_available():
       raise RuntimeError("RCCL could not be bound by libbm_gar.so")
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    ident = [None]
+    ident, failure = [None], None
     if rank == 0:
-      buf = ctypes.create_string_buffer(128)
-      _lib.check(lib.bm_comm_unique_id(buf), "bm_comm_unique_id")
-      ident[0] = buf.raw
+      try:
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(lib.bm_comm_unique_id(buf), "bm_comm_unique_id")
+        ident[0] = buf.raw
+      except Exception as err:  # noqa: BLE001
+        failure = err
+    # rank 0 must not skip the broadcast its peers are about to enter: first everyone learns whether there is an id
+    if vote is not None:
+      if not vote(failure is None):
+        raise RuntimeError(f"bm_comm_unique_id failed on rank 0: {failure}" if failure is not None else
+                           "bm_comm_unique_id failed on rank 0")
+    elif failure is not None:
+      raise failure
     dist.broadcast_object_list(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     handle = ctypes.c_void_p()
     _lib.check(lib.bm_comm_init(ctypes.byref(handle), world, rank, ctypes.c_char_p(ident[0])), "bm_comm_init")
@@ -115,6 +129,9 @@ class HipBackend:
 
   def brute_select(self, dist_host, n, f):
     return self.gars.brute_select_host(dist_host, n, f)
+
+  def brute_select_device(self, sq, n, f):
+    return self.gars.brute_select_device(sq, n, f)[0]
 
   def sharded_rule(self, name, comm, gradients, f, m, d_total=None):
     """Multi-Krum / Bulyan of the local slice in one C call (bm_sharded_krum / bm_sharded_bulyan);
@@ -241,7 +258,7 @@ class ShardedAggregator:
       return None, "RCCL could not be bound by libbm_gar.so"
     comm, failure = None, None
     try:
-      comm = NativeComm(group)
+      comm = NativeComm(group, vote=everyone)  # (votes once inside: "rank 0 has an id", before the id is broadcast)
     except Exception as err:  # noqa: BLE001
       failure = err
     if not everyone(comm is not None):
@@ -389,10 +406,13 @@ class ShardedAggregator:
     return self.backend.selected_mean(local, self.backend.argsort(sq, n), count)
 
   def brute(self, local, f, d_total=None):
-    """Brute rule: all-reduced distances, the (deterministic) subset search on every rank's host."""
+    """Brute rule: all-reduced distances, then the (deterministic) subset search on every rank — on the device with
+    the HIP backend (same bits in, same selection out on every rank, no host round trip)."""
     n = len(local)
-    dist_host = self.global_sqdist(local, d_total).sqrt().cpu().contiguous()
-    sel = self.backend.brute_select(dist_host, n, f)
+    sq = self.global_sqdist(local, d_total)
+    if hasattr(self.backend, "brute_select_device"):
+      return self.backend.selected_mean(local, self.backend.brute_select_device(sq, n, f), n - f)
+    sel = self.backend.brute_select(sq.sqrt().cpu().contiguous(), n, f)
     return self.backend.selected_mean(local, self.backend.index_tensor(sel, local[0]), n - f)
 
   def average(self, local):

@@ -253,6 +253,14 @@ int bm_multi_scale(float* const* y, int k, int64_t d, const float* factors, void
  * The subsets are not enumerated (bisection over the distances, a search tree of
  * depth <= f per probe): n = 51, f = 12 — 1.6e11 subsets — takes 0.1 ms. */
 int bm_brute_select(const double* dist_nxn, int n, int f, int32_t* sel_out);
+/* The same search by one wave ON THE DEVICE, from the SQUARED distances where bm_pairwise_sqdist left them: no copy
+ * out, no host search, no copy in — distances -> search -> bm_selected_mean are three launches on one stream, and a
+ * HIP graph can record them.  sel_out (DEVICE, BM_MAX_ROWS int32): the n-f rows ascending, then zeros — the index
+ * table bm_selected_mean reads.  status (DEVICE, one int32): 0, or -1 when every subset touches a non-finite distance
+ * (brute.py:56-57: the reference then selects nothing); sel_out then holds n-f copies of the first row all of whose
+ * distances are non-finite, so that the average that follows is non-finite where that row is.  Same selections as
+ * bm_brute_select (tests/test_gpu_parity_r4.py). */
+int bm_brute_select_device(const double* sq_nxn, int n, int f, int32_t* sel_out, int32_t* status, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Dim-sharded aggregation: one process per GPU, every rank holds all n rows

@@ -150,3 +150,72 @@ def test_nesterov_sequence_against_the_reference_order_of_operations(bm, momentu
   want = p.sub(step.buffers[1] if momentum_at == "worker" else step.server_momentum, alpha=mu * lr)
   got = step.nesterov_lookahead(p.clone(), lr, worker=1 if momentum_at == "worker" else None)
   assert float((got - want).abs().max()) <= 1e-6 * float(want.abs().max())
+
+
+# ---------------------------------------------------------------------------- #
+# The Brute subset search on the device (brute.py:47-68)
+
+def test_brute_search_on_the_device_equals_the_host_search(bm):
+  """bm_brute_select_device (one wave, squared distances where the distance pass left them) against bm_brute_select
+  (host; pinned on exhaustive enumeration by tests/test_host_logic.py): random matrices of many shapes, matrices of
+  FEW distinct values (ties everywhere: the lexicographically first subset must come out), zero distances (aliased
+  rows), rows at non-finite distance of everything, and the case where no subset has a finite diameter."""
+  gars = bm.gars
+  gen = torch.Generator().manual_seed(7)
+  cases = 0
+  for n, f in ((4, 1), (7, 2), (11, 2), (11, 4), (25, 5), (25, 11), (33, 8), (51, 12), (64, 20), (64, 1), (9, 0)):
+    for variant in range(8):
+      if variant % 4 == 0:
+        pts = torch.randn(n, 6, generator=gen, dtype=torch.float64)
+      elif variant % 4 == 1:  # few distinct distances
+        pts = torch.randint(0, 3, (n, 4), generator=gen).double()
+      elif variant % 4 == 2:  # a tight cluster of n - f rows plus outliers, then aliased rows
+        pts = torch.randn(n, 5, generator=gen, dtype=torch.float64)
+        pts[: n - f] *= 0.01
+        pts[-1] = pts[-2]
+      else:
+        pts = torch.rand(n, 3, generator=gen, dtype=torch.float64).round(decimals=1)
+      sq = (pts[:, None, :] - pts[None, :, :]).pow(2).sum(dim=2)
+      bad_rows = 0
+      if variant >= 4 and f >= 1:  # rows with a non-finite coordinate: at most f of them, then f + 1
+        bad_rows = min(f, 2) if variant < 6 else f + 1
+        for r in range(bad_rows):
+          row = (3 * r + 1) % n
+          sq[row, :] = math.nan if r % 2 == 0 else math.inf
+          sq[:, row] = sq[row, :]
+      sq_dev = sq.to(DEV).contiguous()
+      sel, status = gars.brute_select_device(sq_dev, n, f)
+      try:
+        want = gars.brute_select_host(sq.sqrt().contiguous(), n, f)
+      except RuntimeError:
+        want = None
+      if want is None:
+        assert int(status.item()) == -1, (n, f, variant)
+        picked = sel[: n - f].tolist()
+        assert len(set(picked)) == 1 and not math.isfinite(float(sq[picked[0], (picked[0] + 1) % n])), (n, f, variant)
+      else:
+        assert int(status.item()) == 0 and sel[: n - f].tolist() == want, (n, f, variant, sel[: n - f].tolist(), want)
+        assert sel[n - f:].abs().sum().item() == 0
+      cases += 1
+  assert cases == 88
+
+
+def test_brute_rule_runs_without_the_host_and_can_be_graphed(bm):
+  """gars.brute: distances -> device search -> selected mean on one stream, the oracle's selection; recorded into a
+  HIP graph (impossible with a host search in the middle) the replay gives the same bits, also after the contents
+  of the rows changed."""
+  from byzantinemomentum_amd.graphs import GraphedCall
+  n, f, d = 25, 5, 300007
+  rows, h = O.make_stack("hetero", n, f, d, seed=11)
+  seen = {}
+  dev = [seen.setdefault(id(g), g.to(DEV)) for g in rows]
+  want_sel = O.brute_selection(rows, f)
+  assert bm.gars.brute_selection(dev, f) == want_sel
+  eager = bm.brute(dev, f)
+  assert torch.equal(eager.cpu(), O.brute(rows, f))
+  graphed = GraphedCall(lambda: bm.brute(dev, f))
+  assert torch.equal(graphed(), eager)
+  for g in dev[:h]:
+    g.mul_(-0.5)
+  bm.gars.invalidate_rank_cache()
+  assert torch.equal(graphed(), bm.brute(dev, f))
