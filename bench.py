@@ -685,7 +685,9 @@ def attack_search(bm, honests, n, f, d, evals=16, gar="krum"):
   pass over h+2 rows, then host only) and the reference's form (the rule on the vectors once per evaluation).
   Against the median (C2 shape): every candidate as the middle of (candidate, lo, hi), lo / hi being two order
   statistics of the honest rows formed once per search (the key stays `scalar_form_ms`), and the reference's form.
-  Against Bulyan (C4 shape): every candidate ranked on the host from one distance pass, pass 2 alone on the vectors."""
+  Against Bulyan (C4 shape): every candidate ranked on the host from one distance pass, pass 2 alone on the vectors.
+  Against the trimmed mean (C2 shape; phocas and meamed alike): every candidate in one pass over the honest rows that
+  writes nothing (bm_colwise_eval; the key stays `scalar_form_ms`)."""
   from byzantinemomentum_amd.step import AggregationStep
   avg, _, direction = bm.stats.stack_stats_async(honests, scale=1.0, attack="empire", direction=True)
   res = {"config": f"empire against {gar}, n={n}, f={f}, d={d}, {evals} evaluations, one GPU"}
@@ -736,6 +738,9 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
         c4_sample = _host_copy(stacks[0])
       if "BM_BENCH_CHILD" not in os.environ:  # (the PMC child keeps the per-launch traffic of the C2 column kernel clean)
         out["attack_search_c2_median"] = attack_search(bm, stacks[0][:n - f], n, f, d, gar="median")
+        # (trimmed mean: every candidate in ONE pass that writes nothing — candidate, rule and objective in registers,
+        #  bm_colwise_eval — against candidate vector + rule + objective per evaluation)
+        out["attack_search_c2_trmean"] = attack_search(bm, stacks[0][:n - f], n, f, d, gar="trmean")
         try:  # (Bulyan: every candidate ranked on the host from ONE distance pass, only pass 2 on the vectors)
           out["attack_search_c4_bulyan"] = attack_search(bm, stacks[0][:n - f], n, f, d, gar="bulyan")
         except Exception as err:  # noqa: BLE001  (a side entry must not take the line down)

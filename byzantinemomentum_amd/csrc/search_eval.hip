@@ -1,0 +1,160 @@
+// search_eval.hip — ONE candidate of the attacks' factor search against a coordinate-wise rule, evaluate only.
+//
+// attacks/identical.py:67-77 maximises, over the factor t,
+//     eval(t) = | GAR(honests + [avg + t * dir] * k) - avg |^2          (identical.py:73-76)
+// with tools.line_maximize (tools/misc.py:468-514): by default 16 evaluations per step, each one a full aggregation.
+// Krum, Brute, the average, the median and Bulyan have cheaper forms of the whole search (linesearch.cpp, step.py);
+// the trimmed mean, phocas and meamed do not — their output is not a function of inner products or of two order
+// statistics — and cost, per candidate, the candidate vector (2 rows read, 1 written), the rule (h + 1 rows read, the
+// k aliased copies from cache, 1 written) and the objective (2 rows read): h + 5 rows read, 2 written, three launches.
+//
+// Here the candidate exists in registers only: a lane reads its columns of the h honest rows, of avg and of dir,
+// forms avg + t * dir with the arithmetic of bm_multi_fma3 (fma(t, dir, 1 * avg): the same bits as the vector the
+// generic form writes), runs the rule's own device code (column_rule, colwise_kernels.h) on the h + k values, and
+// accumulates (rule - avg)^2 — h + 2 rows read, NOTHING written, one launch.  The value of the rule at every column is
+// the one bm_colwise gives on the materialised stack, so the objective agrees with the generic form to the rounding
+// of its sum (fp32 over <= 64 elements per lane, fp64 beyond; the generic form takes it from the distance kernel).
+//
+// Instances: n = h + k in {11, 25, 51} (the worker counts of reproduce.py:122-209, reproduce-appendix.py:109), any
+// split into honest rows and copies; other shapes take the generic form (bm_colwise_eval_supported says which).
+#include "colwise_kernels.h"
+
+namespace bm {
+
+constexpr int kEvalMaxBlocks = 4096;
+
+template <int N, int OP, int VEC>
+__global__ __launch_bounds__(kColBlock) void colwise_eval_kernel(RowTable rows, int h, const float* __restrict__ avg,
+                                                                 const float* __restrict__ dir, float t, int64_t nvec,
+                                                                 int f, float inv_keep, double* __restrict__ partial) {
+  constexpr bool kNeedsLds = (OP == BM_OP_PHOCAS || OP == BM_OP_MEAMED);
+  __shared__ float scratch[kNeedsLds ? N * kColBlock : 1];
+  __shared__ double red[kColBlock / 64];
+  float* lds = scratch + (kNeedsLds ? threadIdx.x : 0);
+  float acc = 0.0f;
+  double wide = 0.0;
+  int since = 0;
+  const int64_t stride = (int64_t)gridDim.x * kColBlock;
+  for (int64_t v = (int64_t)blockIdx.x * kColBlock + threadIdx.x; v < nvec; v += stride) {
+    const int64_t j = v * VEC;
+    float x[VEC][N];
+    float a[VEC], dr[VEC];
+    load_stream<VEC>(avg + j, a);
+    load_stream<VEC>(dir + j, dr);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      if (i < h) {  // wave-uniform
+        float tmp[VEC];
+        load_stream<VEC>(rows.p[i] + j, tmp);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) x[c][i] = tmp[c];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      const float cand = __builtin_fmaf(t, dr[c], 1.0f * a[c]);  // bm_multi_fma3(out, avg, dir, 1, t): same bits
+#pragma unroll
+      for (int i = 0; i < N; ++i)
+        if (i >= h) x[c][i] = cand;
+      const float r = column_rule<N, OP>(x[c], f, inv_keep, lds);
+      const float df = r - a[c];  // aggregated.sub_(grad_avg) (identical.py:75)
+      acc = __builtin_fmaf(df, df, acc);
+    }
+    if (++since == 16) {
+      wide += (double)acc;
+      acc = 0.0f;
+      since = 0;
+    }
+  }
+  const double r = block_reduce_sum<kColBlock>(wide + (double)acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// out[0] = sum of the partials in index order (one wave: lane l adds l, l + 64, ..., then a fixed shuffle tree)
+__global__ __launch_bounds__(64) void eval_finish_kernel(const double* __restrict__ partial, int nparts,
+                                                         double* __restrict__ out) {
+  double tot = 0.0;
+  for (int b = threadIdx.x; b < nparts; b += 64) tot += partial[b];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) tot += __shfl_down(tot, off, 64);
+  if (threadIdx.x == 0) out[0] = tot;
+}
+
+template <int N, int OP>
+static int launch_eval(const float* const* rows, int h, int64_t d, int f, const float* avg, const float* dir, float t,
+                       double* out, double* partial, hipStream_t s) {
+  constexpr int kMaxVec = (N <= 28) ? 4 : 2;
+  const int keep = (OP == BM_OP_TRMEAN) ? (N - 2 * f) : (N - f);
+  const float inv_keep = 1.0f / (float)(keep > 0 ? keep : 1);
+  RowTable tab{};
+  for (int i = 0; i < h; ++i) tab.p[i] = rows[i];
+  const void* more[2] = {avg, dir};
+  int vec = common_vec_width(reinterpret_cast<const void* const*>(rows), h, nullptr);
+  const int vec2 = common_vec_width(more, 2, nullptr);
+  if (vec2 < vec) vec = vec2;
+  if (vec > kMaxVec) vec = kMaxVec;
+  int nparts = 0;
+  int64_t body = 0;
+  if (vec >= 2 && d / vec > 0) {
+    const int64_t nvec = d / vec;
+    const int grid = stream_grid(nvec, kColBlock, kEvalMaxBlocks);
+    if (vec == 4)
+      hipLaunchKernelGGL((colwise_eval_kernel<N, OP, (kMaxVec >= 4 ? 4 : 2)>), dim3(grid), dim3(kColBlock), 0, s, tab, h,
+                         avg, dir, t, nvec, f, inv_keep, partial);
+    else
+      hipLaunchKernelGGL((colwise_eval_kernel<N, OP, 2>), dim3(grid), dim3(kColBlock), 0, s, tab, h, avg, dir, t, nvec,
+                         f, inv_keep, partial);
+    BM_LAUNCH_CHECK();
+    nparts = grid;
+    body = nvec * vec;
+  }
+  if (body < d) {
+    RowTable tail{};
+    for (int i = 0; i < h; ++i) tail.p[i] = rows[i] + body;
+    const int64_t rest = d - body;
+    const int grid = (body == 0) ? stream_grid(rest, kColBlock, kEvalMaxBlocks) : 1;
+    hipLaunchKernelGGL((colwise_eval_kernel<N, OP, 1>), dim3(grid), dim3(kColBlock), 0, s, tail, h, avg + body, dir + body,
+                       t, rest, f, inv_keep, partial + nparts);
+    BM_LAUNCH_CHECK();
+    nparts += grid;
+  }
+  // d == 0: no partial, the finish kernel writes zero (every rank of a sharded job reaches its all-reduce)
+  hipLaunchKernelGGL(eval_finish_kernel, dim3(1), dim3(64), 0, s, partial, nparts, out);
+  BM_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int N>
+static int launch_eval_op(int op, const float* const* rows, int h, int64_t d, int f, const float* avg, const float* dir,
+                          float t, double* out, double* partial, hipStream_t s) {
+  switch (op) {
+    case BM_OP_TRMEAN: return launch_eval<N, BM_OP_TRMEAN>(rows, h, d, f, avg, dir, t, out, partial, s);
+    case BM_OP_PHOCAS: return launch_eval<N, BM_OP_PHOCAS>(rows, h, d, f, avg, dir, t, out, partial, s);
+    case BM_OP_MEAMED: return launch_eval<N, BM_OP_MEAMED>(rows, h, d, f, avg, dir, t, out, partial, s);
+    default: return BM_EINVAL;
+  }
+}
+
+}  // namespace bm
+
+extern "C" int bm_colwise_eval_supported(int op, int n) {
+  return (op == BM_OP_TRMEAN || op == BM_OP_PHOCAS || op == BM_OP_MEAMED) && (n == 11 || n == 25 || n == 51) ? 1 : 0;
+}
+
+extern "C" int64_t bm_colwise_eval_workspace_bytes(void) { return (int64_t)(2 * bm::kEvalMaxBlocks) * (int64_t)sizeof(double); }
+
+extern "C" int bm_colwise_eval(int op, const float* const* honests, int h, int copies, int64_t d, int f,
+                               const float* avg, const float* dir, float t, double* out, void* ws, void* stream) {
+  using namespace bm;
+  const int n = h + copies;
+  if (honests == nullptr || out == nullptr || ws == nullptr || h < 1 || copies < 1 || n > BM_MAX_ROWS || d < 0 || f < 0 ||
+      n < 2 * f + 1 || (d > 0 && (avg == nullptr || dir == nullptr)) || !bm_colwise_eval_supported(op, n))
+    return BM_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  double* partial = static_cast<double*>(ws);
+  switch (n) {
+    case 11: return launch_eval_op<11>(op, honests, h, d, f, avg, dir, t, out, partial, s);
+    case 25: return launch_eval_op<25>(op, honests, h, d, f, avg, dir, t, out, partial, s);
+    default: return launch_eval_op<51>(op, honests, h, d, f, avg, dir, t, out, partial, s);
+  }
+}

@@ -191,6 +191,12 @@ class HipBackend:
   def study_stats(self, *args, **kwargs):
     return self.stats.study_stats(*args, **kwargs)
 
+  def colwise_eval_supported(self, rule, n):
+    return self.stats.colwise_eval_supported(rule, n)
+
+  def colwise_eval(self, *args, **kwargs):
+    return self.stats.colwise_eval(*args, **kwargs)
+
   def study_dots(self, core, extra):
     return self.stats.study_dots(core, extra)
 

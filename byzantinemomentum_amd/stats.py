@@ -87,6 +87,30 @@ def study_dots(core, extra=()):
   return out[:nc * nc].view(nc, nc), out[nc * nc:]
 
 
+_EVAL_OPS = {"trmean": _lib.OP_TRMEAN, "phocas": _lib.OP_PHOCAS, "meamed": _lib.OP_MEAMED}
+
+
+def colwise_eval_supported(rule, n):
+  """Does the evaluate-only form of the factor search exist for this rule and worker count (bm_colwise_eval)?"""
+  return rule in _EVAL_OPS and bool(_lib.load().bm_colwise_eval_supported(_EVAL_OPS[rule], n))
+
+
+def colwise_eval(rule, honests, copies, f, h_avg, direction, t):
+  """| RULE(honests + [h_avg + t * direction] * copies) - h_avg |^2 as a device fp64[1] tensor, the candidate and the
+  rule's output formed in registers only (bm_colwise_eval): one candidate of attacks/identical.py:67-77. No sync."""
+  honests = list(honests)
+  h, d, device = gars._validate(honests)
+  gars._validate([h_avg, direction] + honests[:1])
+  lib = _lib.load()
+  out = torch.empty(1, dtype=torch.float64, device=device)
+  ws = gars._Scratch.get(device, "ws_eval", nbytes=int(lib.bm_colwise_eval_workspace_bytes()))
+  with torch.cuda.device(device):
+    _lib.check(lib.bm_colwise_eval(_EVAL_OPS[rule], _lib.pointer_table(honests), h, copies, d, f, _ptr(h_avg),
+                                   _ptr(direction), float(t), _ptr(out), _ptr(ws), gars._stream(device)),
+               "bm_colwise_eval")
+  return out
+
+
 def study_stats(s_avg, h_avg, defense, byz, f_real, past_newest=None, curv=None, past_oldest=None, curv_mode=0, mu=0.0,
                 oldest_weight=0.0, params=None, origin=None, attack_avg_out=None):
   """The study block of a step in ONE pass (bm_study_stats, include/bm_gar.h): statistics of the attack stack

@@ -164,8 +164,17 @@ class AggregationStep:
       hi = agg.median(list(honests) + [torch.full_like(h_avg, math.inf)] * k)
       rule = lambda cand, t: agg.median([cand, lo, hi])  # noqa: E731
 
+    fused_eval = (self.line_search == "auto" and k >= 1 and not self.gar_args and hasattr(ops, "colwise_eval")
+                  and ops.colwise_eval_supported(self.gar, n))
+
     def scape(x):
       t = -x if self.attack_negative else x
+      if fused_eval:
+        # trmean / phocas / meamed: candidate, rule and objective in ONE pass over the honest rows, nothing written
+        # (bm_colwise_eval: h + 2 row passes instead of h + 5 read and 2 written); the same value at every column
+        sq = ops.colwise_eval(self.gar, honests, k, self.f_decl, h_avg, direction, t)
+        agg.all_reduce_sum(sq)
+        return sq.item()
       cand = torch.empty_like(h_avg)
       ops.multi_fma3([cand], [h_avg], [direction], 1.0, t)
       out = rule(cand, t)

@@ -343,6 +343,18 @@ int bm_step_worker(bm_comm* comm, const bm_step_params* p, const float* const* s
                    float* attack_avg_out, const float* past_newest, float* curv, const float* past_oldest,
                    const float* params, const float* origin, double* stats_out, void* ws, void* stream);
 
+/* ONE candidate of the attacks' factor search against the trimmed mean, phocas or meamed, evaluate only
+ * (attacks/identical.py:73-76 with aggregators/trmean.py:69-109 as the defense):
+ *     out[0] = sum_j ( RULE(honests + [avg + t * dir] * copies)_j - avg_j )^2        (DEVICE, one double)
+ * The candidate vector is never written (it is fma(t, dir, avg) in registers, the bits bm_multi_fma3 would store),
+ * nor the rule's output: h + 2 rows read, nothing written, against h + 5 read and 2 written by candidate vector +
+ * bm_colwise + objective.  Instances exist for n = h + copies in {11, 25, 51} (bm_colwise_eval_supported);
+ * ws: bm_colwise_eval_workspace_bytes().  d == 0 is legal (an empty shard: out[0] = 0). */
+int bm_colwise_eval_supported(int op, int n);
+int64_t bm_colwise_eval_workspace_bytes(void);
+int bm_colwise_eval(int op, const float* const* honests, int h, int copies, int64_t d, int f, const float* avg,
+                    const float* dir, float t, double* out, void* ws, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * The factor search of the "identical" attacks (attacks/identical.py:67-77, the reference's default
  * factor=-16) — HOST functions, no stream.

@@ -219,3 +219,56 @@ def test_brute_rule_runs_without_the_host_and_can_be_graphed(bm):
     g.mul_(-0.5)
   bm.gars.invalidate_rank_cache()
   assert torch.equal(graphed(), bm.brute(dev, f))
+
+
+# ---------------------------------------------------------------------------- #
+# The evaluate-only form of the factor search (bm_colwise_eval) against the per-evaluation form
+
+@pytest.mark.parametrize("gar,n,f,d,attack,negative", [
+  ("trmean", 25, 5, 1000003, "empire", False), ("phocas", 25, 5, 300001, "little", True),
+  ("meamed", 25, 11, 262144, "empire", False), ("trmean", 11, 2, 65537, "little", False),
+  ("meamed", 11, 4, 4099, "empire", True), ("trmean", 51, 12, 200002, "empire", False),
+  ("phocas", 51, 24, 100001, "little", False)])
+def test_evaluate_only_search_form_against_the_per_evaluation_form(bm, gar, n, f, d, attack, negative):
+  """attacks/identical.py:67-77 against trmean / phocas / meamed: `auto` evaluates every candidate with ONE pass
+  that writes nothing (candidate, rule and objective in registers, bm_colwise_eval), `generic` writes the candidate
+  vector, runs the rule on the n rows and takes the objective from the distance kernel, like the reference does.
+  Same candidates in the same order, objectives within 1e-6 (the two sums round differently), the same factor and
+  the same aggregated gradient (the final aggregation is the rule itself in both) — unaligned lengths, a one-,
+  two- and three-column tail, n = 11 / 25 / 51, and a column with a NaN."""
+  from byzantinemomentum_amd.step import AggregationStep
+  h = n - f
+  gen = torch.Generator(device=DEV).manual_seed(61)
+  base = 0.2 * torch.randn(d, device=DEV, generator=gen)
+  honests = [base + (0.5 + 0.05 * i) * torch.randn(d, device=DEV, generator=gen) for i in range(h)]
+  assert bm.stats.colwise_eval_supported(gar, n) and not bm.stats.colwise_eval_supported(gar, n + 1)
+  traces = {}
+  for mode in ("auto", "generic"):
+    step = AggregationStep(n, f, f, gar=gar, momentum=0.9, dampening=0.9, momentum_at="update", attack=attack,
+                           attack_factor=1.1, nb_past=0, attack_evals=12, attack_negative=negative, line_search=mode)
+    out = step.run([g.clone() for g in honests])
+    traces[mode] = (step.last_factor, list(step.last_search), out)
+  (fa, sa, oa), (fg, sg, og) = traces["auto"], traces["generic"]
+  assert len(sa) == len(sg) == 12 and max(y for _, y in sa) > 0
+  for (xa, ya), (xg, yg) in zip(sa, sg):
+    assert xa == xg and abs(ya - yg) <= 1e-6 * abs(yg) + 1e-30, (gar, xa, ya, yg)
+  assert fa == fg and torch.equal(oa, og)
+  # the entry point alone, on views that are only 4-byte aligned (the scalar form of the kernel), against the rule
+  off = [torch.cat([torch.zeros(1, device=DEV), g])[1:] for g in honests]
+  avg = torch.stack(honests).mean(dim=0)
+  direction = -avg if attack == "empire" else torch.stack(honests).var(dim=0).sqrt_()
+  cand = avg + 0.75 * direction
+  want = (getattr(bm, gar)(honests + [torch.addcmul(avg, direction, torch.tensor(0.75, device=DEV))] * f, f).double()
+          - avg.double()).pow(2).sum().item()
+  got = bm.stats.colwise_eval(gar, off, f, f, avg, direction, 0.75).item()
+  assert abs(got - want) <= 1e-5 * want, (got, want, float((cand - avg).norm()))
+  # a NaN in one honest row: trmean tolerates up to f of them per column, meamed / phocas follow their centre
+  honests[2][5] = math.nan
+  got = {}
+  for mode in ("auto", "generic"):
+    step = AggregationStep(n, f, f, gar=gar, momentum_at="update", attack=attack, nb_past=0, attack_evals=3,
+                           attack_negative=negative, line_search=mode)
+    step.run([g.clone() for g in honests])
+    got[mode] = step.last_search
+  for (xa, ya), (xg, yg) in zip(got["auto"], got["generic"]):
+    assert xa == xg and ((math.isnan(ya) and math.isnan(yg)) or abs(ya - yg) <= 1e-6 * abs(yg)), (gar, ya, yg)
