@@ -208,13 +208,15 @@ class HipBackend:
 class ShardedAggregator:
   """Aggregation rules over gradients whose coordinates are sharded across the ranks of `group`."""
 
-  def __init__(self, backend=None, group=None, force_collectives=False, native_comm="auto"):
+  def __init__(self, backend=None, group=None, force_collectives=False, native_comm="auto", local_only=False):
     """native_comm: "auto" (default) gives the HIP backend its own RCCL communicator when there is
     more than one rank, so that Multi-Krum / Bulyan are single C calls; False keeps every collective
-    in torch.distributed; True insists (raises if RCCL cannot be bound)."""
+    in torch.distributed; True insists (raises if RCCL cannot be bound).
+    local_only: a single-rank aggregator whatever the state of torch.distributed (the whole vectors are here:
+    no collective is ever issued) — e.g. the unsharded reference computation inside a multi-rank job."""
     self.backend = backend if backend is not None else HipBackend()
     self.group = group
-    initialised = dist.is_available() and dist.is_initialized()
+    initialised = dist.is_available() and dist.is_initialized() and not local_only
     self.world_size = dist.get_world_size(group) if initialised else 1
     self.rank = dist.get_rank(group) if initialised else 0
     # force_collectives: issue the all-reduce / all-gather calls even with one rank (used to

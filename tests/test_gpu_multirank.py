@@ -78,12 +78,14 @@ def _close(a, b, tol, what):
 
 
 def _worker(rank, world, port, d, queue):
+  import datetime
   os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-  dist.init_process_group("gloo", rank=rank, world_size=world)
+  # (a short timeout: a rank that fails an assertion leaves its peers in a collective; they must not wait for long)
+  dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
   try:
     torch.cuda.set_device(0)
     import byzantinemomentum_amd as bm
-    from byzantinemomentum_amd.sharded import HipBackend, owned_workers, shard_bounds
+    from byzantinemomentum_amd.sharded import HipBackend, ShardedAggregator, owned_workers, shard_bounds
     from byzantinemomentum_amd.step import AggregationStep
     agg = _staged_aggregator()
     assert isinstance(agg.backend, HipBackend) and agg.world_size == world and agg.collective and agg.native is None
@@ -138,7 +140,8 @@ def _worker(rank, world, port, d, queue):
     # the full step (worker momentum, empire, study block) on the slice against the single-rank step on the whole vectors
     for gar in ("krum", "bulyan", "median"):
       sharded = AggregationStep(N, F, F, gar=gar, momentum=0.9, dampening=0.9, attack_factor=1.1, nb_past=2, aggregator=agg)
-      single = AggregationStep(N, F, F, gar=gar, momentum=0.9, dampening=0.9, attack_factor=1.1, nb_past=2)
+      single = AggregationStep(N, F, F, gar=gar, momentum=0.9, dampening=0.9, attack_factor=1.1, nb_past=2,
+                               aggregator=ShardedAggregator(local_only=True))  # (the default one would span the job)
       gen = torch.Generator().manual_seed(5)
       origin = torch.randn(d, generator=gen)
       params = origin + 0.01
@@ -177,15 +180,25 @@ def test_multi_rank_sharded_path_on_the_hip_kernels(world, d):
   procs = [ctx.Process(target=_worker, args=(r, world, port, d, queue)) for r in range(world)]
   for p in procs:
     p.start()
+  import queue as queue_mod
+  import time
   results = {}
+  deadline = time.time() + 800
   try:
-    for _ in range(world):
-      rank, rep = queue.get(timeout=800)
-      results[rank] = rep
+    while len(results) < world and time.time() < deadline:
+      try:
+        rank, rep = queue.get(timeout=5)
+        results[rank] = rep
+      except queue_mod.Empty:
+        if any(p.exitcode not in (None, 0) for p in procs):
+          break  # a rank failed: its peers sit in a collective, do not wait for them
   finally:
     for p in procs:
-      p.join(timeout=120)
-  assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+      p.join(timeout=30 if len(results) == world else 1)
+      if p.is_alive():
+        p.terminate()
+        p.join(timeout=10)
+  assert len(results) == world and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
   # every rank decoded the same floats from the same packed exchange
   keys = [k for k in results[0] if k != "shard"]
   for r in range(1, world):
