@@ -279,6 +279,8 @@ struct Tuning {
   int pair_dither;     // BM_PAIR_DITHER (mode 0, two planes): seed of the coordinate dither (default 0); -1 = round to nearest (A/B)
   double pair_tau;     // BM_PAIR_TAU: accuracy gate of mode 0 (see gram_to_sqdist_kernel); <= 0 disables
   int study_burst;     // BM_STUDY_BURST: iterations per CU from which bm_study_stats takes its burst form (default 8; 0 = never, 1 = always: tests)
+  int step_stagger_us; // BM_STEP_STAGGER_US: start every other workgroup of an XCD this many microseconds late in the fused first pass of a Krum / Bulyan step (0 = off)
+  int gram_steady;     // BM_GRAM_STEADY: 1 (default) = the condition-free steady-state loop of the Gram kernel, 0 = the generic loop only (A/B)
 };
 const Tuning& tuning();
 }  // namespace bm

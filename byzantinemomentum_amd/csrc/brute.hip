@@ -12,8 +12,8 @@
 //     they all go, or it goes), depth <= f, as an explicit stack of 64-bit row sets;
 //   * the smallest t among {0} and the finite distances for which G(t) holds such a set: the host bisects over the
 //     SORTED distances; a wave has no cheap sort of up to 2 016 doubles, so it bisects quickselect-fashion — the
-//     pivot is the candidate in the middle of the still-open ones in row-major enumeration order — which visits
-//     O(log) pivots on any input that is not built against it and stops at the same t (G only grows with t);
+//     pivot is the middle open candidate of the middle row that still has one — which visits O(log) pivots on any
+//     input that is not built against it and stops at the same t (G only grows with t);
 //   * the lexicographically first such set in G(t*): position by position, the smallest row that still extends.
 // Lane i owns row i: its adjacency set, its count of non-neighbours in `cand`; the row sets themselves are wave-uniform.
 #include "bm_common.h"
@@ -22,10 +22,15 @@ namespace bm {
 
 namespace {
 
-__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
-  const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, 64);
-  const uint32_t hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, 64);
+// lane `src` (wave-uniform) of a 64-bit per-lane value, through v_readlane (no LDS crossbar, no latency chain)
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int src) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, src);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), src);
   return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, int src) {
+  return __longlong_as_double((long long)readlane64((uint64_t)__double_as_longlong(v), src));
 }
 
 __device__ __forceinline__ int wave_max_i32(int v) {
@@ -34,12 +39,6 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     const int o = __shfl_xor(v, off, 64);
     v = o > v ? o : v;
   }
-  return v;
-}
-
-__device__ __forceinline__ int wave_sum_i32(int v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
 
@@ -61,28 +60,45 @@ struct BruteWave {
   }
 
   // are there `need` mutually adjacent rows among `cand`?  (wave-uniform arguments and result)
-  __device__ bool has_clique(uint64_t cand0, int need) {
+  // Everything that steers the search is wave-uniform and lives on the scalar unit: the row sets, the stack pointer,
+  // the worst row (six ballots over the bits of the per-lane counts, ties to the lowest lane: the host loop keeps the
+  // first maximum), its adjacency row (v_readlane).  The alternative tried first stays in registers; only the one
+  // tried second goes through the LDS stack.
+  __device__ bool has_clique(uint64_t cand, int need) {
     int top = 0;
-    stack[top++] = cand0;
-    while (top > 0) {
-      const uint64_t cand = stack[--top];
+    bool have = true;
+    for (;;) {
+      if (!have) {
+        if (top == 0) return false;
+        cand = stack[--top];
+      }
+      have = false;
       const int count = __builtin_popcountll(cand);
       if (count < need) continue;
       if (need <= 1) return true;
       const uint64_t me = (uint64_t)1 << lane;
-      const int missing = (cand & me) ? __builtin_popcountll(cand & ~adj & ~me) : -1;
-      // the row with the most non-neighbours, the lowest index among equals (the host loop keeps the first maximum)
-      const int key = wave_max_i32(missing > 0 ? missing * 64 + (63 - lane) : -1);
-      if (key < 0) return true;  // no non-adjacent pair left: `cand` itself, count >= need rows
+      const int missing = (cand & me) ? __builtin_popcountll(cand & ~adj & ~me) : 0;
+      uint64_t active = __builtin_amdgcn_ballot_w64(missing > 0);
+      if (active == 0) return true;  // no non-adjacent pair left: `cand` itself, count >= need rows
       const int budget = count - need;
       if (budget == 0) continue;
-      const int worst = 63 - (key & 63), worst_missing = key >> 6;
+#pragma unroll
+      for (int b = 5; b >= 0; --b) {
+        const uint64_t with_bit = __builtin_amdgcn_ballot_w64(((missing >> b) & 1) != 0) & active;
+        active = with_bit != 0 ? with_bit : active;
+      }
+      const int worst = __builtin_ctzll(active);
+      const int worst_missing = __builtin_amdgcn_readlane(missing, worst);
       const uint64_t bit = (uint64_t)1 << worst;
-      const uint64_t adj_worst = shfl64(adj, worst);
-      stack[top++] = cand & ~bit;                                                 // it goes (tried second)
-      if (worst_missing <= budget) stack[top++] = cand & (adj_worst | bit);       // it stays, they go (tried first)
+      const uint64_t goes = cand & ~bit;
+      if (worst_missing <= budget) {
+        stack[top++] = goes;                               // it goes (tried second)
+        cand = cand & (readlane64(adj, worst) | bit);      // it stays, they go (tried first)
+      } else {
+        cand = goes;
+      }
+      have = true;
     }
-    return false;
   }
 };
 
@@ -146,23 +162,19 @@ __global__ __launch_bounds__(64) void brute_select_kernel(const double* __restri
   } else {
     lo = 0.0;
     for (;;) {
-      // the open candidates, counted per row; the pivot is the one in the middle of their row-major enumeration
+      // the open candidates, counted per row; the pivot: the middle one of the middle row that has any (ballots and
+      // v_readlane only: no cross-lane scan)
       int mine = 0;
       if (lane < n)
         for (int j = lane + 1; j < n; ++j) mine += in_range(dist[lane * n + j], lo, hi) ? 1 : 0;
-      const int total = wave_sum_i32(mine);
-      if (total == 0) break;  // nothing between lo and hi: hi is the smallest diameter
-      int before = mine;      // inclusive prefix sum over the lanes
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(before, off, 64);
-        if (lane >= off) before += o;
-      }
-      const int target = total / 2;  // 0-based position in the enumeration
-      const bool owner = (before - mine) <= target && target < before;
+      const uint64_t holders = __builtin_amdgcn_ballot_w64(mine > 0);
+      if (holders == 0) break;  // nothing between lo and hi: hi is the smallest diameter
+      const int my_rank = __builtin_popcountll(holders & (((uint64_t)1 << lane) - 1));
+      const uint64_t owner_mask = __builtin_amdgcn_ballot_w64(mine > 0 && my_rank == __builtin_popcountll(holders) / 2);
+      const int src = __builtin_ctzll(owner_mask);
       double pivot = 0.0;
-      if (owner) {
-        int skip = target - (before - mine);
+      if (lane == src) {
+        int skip = mine / 2;
         for (int j = lane + 1; j < n; ++j) {
           const double v = dist[lane * n + j];
           if (in_range(v, lo, hi)) {
@@ -174,11 +186,7 @@ __global__ __launch_bounds__(64) void brute_select_kernel(const double* __restri
           }
         }
       }
-      const uint64_t mask = __ballot(owner);
-      const int src = __builtin_ctzll(mask);
-      const uint32_t plo = (uint32_t)__shfl((int)(uint32_t)__double_as_longlong(pivot), src, 64);
-      const uint32_t phi = (uint32_t)__shfl((int)(uint32_t)((uint64_t)__double_as_longlong(pivot) >> 32), src, 64);
-      pivot = __longlong_as_double((long long)(((uint64_t)phi << 32) | plo));
+      pivot = readlane_f64(pivot, src);
       w.build(pivot);
       if (w.has_clique(everyone, k))
         hi = pivot;
@@ -195,7 +203,7 @@ __global__ __launch_bounds__(64) void brute_select_kernel(const double* __restri
     const uint64_t bit = (uint64_t)1 << c;
     if ((cand & bit) == 0) continue;
     const uint64_t above = c == 63 ? 0 : ~(((uint64_t)1 << (c + 1)) - 1);
-    const uint64_t next = cand & shfl64(w.adj, c) & above;
+    const uint64_t next = cand & readlane64(w.adj, c) & above;
     if (w.has_clique(next, k - chosen - 1)) {
       if (lane == chosen) mine_sel = c;
       ++chosen;

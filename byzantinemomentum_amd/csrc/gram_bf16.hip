@@ -81,7 +81,7 @@ struct B3Shape {
 template <int K, int NPL, bool ALIGNED>
 __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_partial_kernel(
     RowTable rows, int n, int64_t d, float inv_n, int centre, unsigned dither_seed, double* __restrict__ partial,
-    int* __restrict__ arrival) {
+    int* __restrict__ arrival, int steady) {
   using S = B3Shape<K, NPL>;
   constexpr int RB = S::RB, NP = S::NP, NSETS = S::NSETS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
         v[k] = __builtin_nontemporal_load(reinterpret_cast<const GlobalF4*>((GlobalF)row_ptr[r] + coord));
       }
     };
-    if (c + (2 * NSETS - 1) * nw < full) {
+    if (steady != 0 && c + (2 * NSETS - 1) * nw < full) {  // (steady == 0: BM_GRAM_STEADY=0, the A/B against the generic loop)
 #pragma unroll
       for (int b = 0; b < NSETS; ++b) issue_fast(c + b * nw, xs[b]);
       do {
@@ -491,7 +491,7 @@ static int launch_gram3_planes(const RowTable& tab, int n, int64_t d, bool align
     if (e != hipSuccess) return hip_code(e);
   }
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * kB3Waves), S::kLds, s, tab, n, d, 1.0f / (float)n, centre,
-                     (unsigned)tuning().pair_dither, partial, arrival);
+                     (unsigned)tuning().pair_dither, partial, arrival, tuning().gram_steady);
   BM_LAUNCH_CHECK();
   return 0;
 }

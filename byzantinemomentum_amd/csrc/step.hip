@@ -253,7 +253,7 @@ template <int TT, bool CLIP, bool NOMOM = false>
 __global__ __launch_bounds__(kStepBurstBlock) void momentum_gram_kernel(
     StepTable tab, uint32_t nvec, float mu, float omd, const float* __restrict__ clipf, float* __restrict__ s_avg_out,
     float* __restrict__ h_avg_out, float* __restrict__ byz_out, float scale, int attack_kind, unsigned dither_seed,
-    double* __restrict__ partial, double* __restrict__ gram_partial, int* __restrict__ arrival) {
+    double* __restrict__ partial, double* __restrict__ gram_partial, int* __restrict__ arrival, int stagger_ticks) {
   using SG = SgShape<TT>;
   constexpr int T = TT, VEC = 4, BLOCK = kStepBurstBlock;
   constexpr int kSgPlaneBytes = SG::kPlaneBytes, kSgWaveBytes = SG::kWaveBytes, kSgN = SG::N, RB = SG::RB, NP = SG::NP;
@@ -265,6 +265,14 @@ __global__ __launch_bounds__(kStepBurstBlock) void momentum_gram_kernel(
   // zero this wave's planes once (the rows past the Byzantine one are never written again)
   for (int o = lane * 16; o < kSgWaveBytes; o += 64 * 16) *reinterpret_cast<f32x4*>(wbase + o) = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
   if (blockIdx.x == 0 && tid == 0 && arrival != nullptr) *arrival = 0;  // see gram_reduce_sqdist_kernel
+  // Stagger (BM_STEP_STAGGER_US, experiments): every workgroup walks load -> arithmetic -> barrier -> store in lockstep
+  // with the 255 others (one per CU, started together), so the HBM system idles while the chip computes.  Every
+  // other workgroup of an XCD (workgroup i runs on XCD i % 8) starts late by about half an iteration: one half of
+  // the chip then computes while the other half loads or stores.
+  if (stagger_ticks > 0 && ((blockIdx.x >> 3) & 1)) {
+    const uint64_t t0 = wall_clock64();  // 100 MHz
+    while ((uint64_t)wall_clock64() - t0 < (uint64_t)stagger_ticks) __builtin_amdgcn_s_sleep(16);
+  }
   const float fks = (float)T, fh = (float)T;
   float n2s = 0.0f, dvs = 0.0f, mxs = 0.0f, n2h = 0.0f, dvh = 0.0f, mxh = 0.0f;
   bool nan_s = false, nan_h = false;
@@ -1072,7 +1080,7 @@ extern "C" int bm_momentum_stats_sqdist(const float* const* sampled, int ks, flo
   const int nc = h + 1;  // rows of the compact Gram
   const int per_block = nc * (nc + 1) / 2;
   void (*kern)(StepTable, uint32_t, float, float, const float*, float*, float*, float*, float, int, unsigned, double*,
-               double*, int*);
+               double*, int*, int);
   int lds;
   if (h == 20) {
     kern = clip_factors != nullptr ? momentum_gram_kernel<20, true> : momentum_gram_kernel<20, false>;
@@ -1085,7 +1093,7 @@ extern "C" int bm_momentum_stats_sqdist(const float* const* sampled, int ks, flo
   if (e != hipSuccess) return hip_code(e);
   hipLaunchKernelGGL(kern, dim3(cus), dim3(kStepBurstBlock), lds, s, tab, (uint32_t)nvec, mu, one_minus_damp,
                      clip_factors, sampled_avg, honest_avg, byz_out, scale, attack_kind, (unsigned)tuning().pair_dither,
-                     partial, gram_partial, pairwise_arrival_counter(ws_pair));
+                     partial, gram_partial, pairwise_arrival_counter(ws_pair), tuning().step_stagger_us * 100);
   BM_LAUNCH_CHECK();
   int nparts = cus, blocks = cus;
   const int64_t body = nvec * 4;
@@ -1205,7 +1213,7 @@ extern "C" int bm_stack_stats_sqdist(const float* const* rows, int k, int64_t d,
   double* partial = static_cast<double*>(ws);
   double* gram_partial = pairwise_gram_area(ws_pair);
   void (*kern)(StepTable, uint32_t, float, float, const float*, float*, float*, float*, float, int, unsigned, double*,
-               double*, int*);
+               double*, int*, int);
   int lds;
   if (k == 20) {
     kern = momentum_gram_kernel<20, false, true>;
@@ -1218,7 +1226,7 @@ extern "C" int bm_stack_stats_sqdist(const float* const* rows, int k, int64_t d,
   if (e != hipSuccess) return hip_code(e);
   hipLaunchKernelGGL(kern, dim3(cus), dim3(kStepBurstBlock), lds, s, tab, (uint32_t)nvec, 0.0f, 1.0f, nullptr, nullptr,
                      avg_out, byz_out, scale, attack_kind, (unsigned)tuning().pair_dither, partial, gram_partial,
-                     pairwise_arrival_counter(ws_pair));
+                     pairwise_arrival_counter(ws_pair), tuning().step_stagger_us * 100);
   BM_LAUNCH_CHECK();
   hipLaunchKernelGGL(step_finish_kernel, dim3(1), dim3(kFinishThreads), 0, s, partial, cus, out6);
   BM_LAUNCH_CHECK();

@@ -87,6 +87,7 @@ class AggregationStep:
     self.line_search = line_search
     self.last_factor = attack_factor  # the factor of the last step (the searched one with attack_evals)
     self.last_search = None           # [(x, objective)] of the last search, in evaluation order
+    self.last_byzantine = None        # the Byzantine vector of the last step (aliased f_real times by the rule)
     self.buffers = None        # worker placement: one momentum buffer per honest worker (attack.py:676)
     self.server_momentum = None  # server / update placements: grad_momentum_server (attack.py:678)
     self.pasts = collections.deque(maxlen=max(nb_past, 1))  # past sampled averages, newest first (attack.py:868)
@@ -277,6 +278,7 @@ class AggregationStep:
       byz = torch.empty_like(h_avg)  # grad_att.mul_(factor); byz_grad = grad_avg.add_(grad_att)  (identical.py:82-84)
       ops.multi_fma3([byz], [h_avg], [direction], 1.0, self.last_factor)
     attacks = [byz] * self.f_real
+    self.last_byzantine = byz if self.f_real > 0 else None  # the Byzantine vector of this step (callers, tests)
     # 3. aggregation
     if fused_defense is not None:
       defense = fused_defense
@@ -332,6 +334,7 @@ class AggregationStep:
       self.pasts[0] if count > 0 else None, self._curv, self.pasts[-1] if full else None, params, origin,
       d_total=self.agg.total_length(sampled[0].shape[0]))
     self._update = defense
+    self.last_byzantine = byz
     self._pending = dict(packed=stats, prev=self._prev_stats if count > 0 else None, npast=2 if count > 0 else 0,
                          has_attack=self.f_real > 0, has_l2=params is not None and origin is not None, ks=ks,
                          floats=None)

@@ -533,26 +533,34 @@ def test_first_pass_with_the_distance_pass_riding_along(bm, d, h, nb):
     assert bm.gars.krum_selection(rows, 5) is not None
 
 
-def bulyan_edge_ties(rows, f, cols):
-  """For the columns `cols` of the CPU rows the reference's rule saw: is the beta-th smallest deviation from the median
-  of `selected` EQUAL to the (beta+1)-th (bulyan.py:79-82: `topk(..., sorted=False)` may then keep either row)?  The
-  reference's own fp32 arithmetic, column by column: sequential sums in rank order, true division, lower median."""
+def bulyan_columns(rows, order, f, cols):
+  """Pass 2 of Bulyan (bulyan.py:64-84) on the columns `cols` of `rows` in the reference's own fp32 arithmetic
+  (sequential sums in rank order, true division, lower median, mean of the beta closest).  Returns (value, tie):
+  tie = the beta-th smallest deviation from the median of `selected` EQUALS the (beta+1)-th, where
+  `topk(..., sorted=False)` may keep either row."""
   n = len(rows)
   m, theta = n - f - 2, n - 2 * f - 2
   beta = theta - 2 * f
-  order, _ = O.bulyan_order(rows, f)
   sub = [g[cols] for g in rows]
   sel = torch.stack([O._seq_sum_div([sub[r] for r in order[i:m]], m - i) for i in range(theta)])
-  dev = (sel - sel.median(dim=0).values).abs().sort(dim=0).values
-  return dev[beta - 1] == dev[beta]
+  centre = sel.median(dim=0).values
+  dev = (sel - centre).abs().sort(dim=0).values
+  return O._closest_like_reference(sel, beta, centre), dev[beta - 1] == dev[beta]
 
 
-def closest_edge_ties(rows, keep, cols, centre="median", f=None):
-  """The same question for meamed / phocas (trmean.py:35-50): the keep-th and (keep+1)-th smallest |g - centre| tie."""
-  x = torch.stack([g[cols] for g in rows])
-  c = x.median(dim=0).values if centre == "median" else O.trmean([g[cols] for g in rows], f)
+def closest_columns(rows, keep, cols, centre="median", f=None):
+  """The same for meamed / phocas (trmean.py:35-50): (value, tie) per column, tie = the keep-th and (keep+1)-th
+  smallest |g - centre| are equal."""
+  sub = [g[cols] for g in rows]
+  x = torch.stack(sub)
+  c = x.median(dim=0).values if centre == "median" else O.trmean(sub, f)
   dev = (x - c).abs().sort(dim=0).values
-  return dev[keep - 1] == dev[keep]
+  return O._closest_like_reference(x, keep, c), dev[keep - 1] == dev[keep]
+
+
+def explained(got, value, tie, scale, tol=4e-6):
+  """Every column: the kernel's result IS the reference rule's on the same inputs, or the column is an exact tie."""
+  return bool((((got - value).abs() <= tol * scale) | tie).all())
 
 
 @pytest.mark.parametrize("gar,f", [("krum", 5), ("bulyan", 5), ("median", 5), ("krum", 11), ("trmean", 11)])
@@ -589,7 +597,12 @@ def test_step_with_the_rule_fed_from_the_first_pass(bm, gar, f):
     # at the window edge, where the reference's topk keeps either value and this kernel the upper window (documented
     # deviation).  Every column out of tolerance must BE such a tie, in the reference's own arithmetic.
     if gar == "bulyan" and len(bad):
-      assert len(bad) <= 20 and bool(bulyan_edge_ties(ref.last_gradients, f, bad).all()), (gar, it, bad.tolist())
+      # the inputs of the two rules differ in their last bit (the Byzantine vector is formed by different sums), so a
+      # column at a NEAR tie can flip too: ask the question on the kernel's OWN inputs — the reference's arithmetic on the
+      # device's rows must give the kernel's value there, or the column is an exact tie of those rows
+      mine = [b[bad].cpu() for b in one.buffers] + [one.last_byzantine[bad].cpu()] * f
+      value, tie = bulyan_columns(mine, O.bulyan_order(ref.last_gradients, f)[0], f, torch.arange(len(bad)))
+      assert len(bad) <= 20 and explained(a[bad].cpu(), value, tie, scale), (gar, it, bad.tolist())
     else:
       assert len(bad) == 0, (gar, it, bad[:10].tolist())
     assert_floats_close(fa, want, tag=(gar, it), tol=1e-5)
@@ -621,7 +634,10 @@ def test_update_placement_with_the_rule_fed_from_the_statistics_pass(bm, gar, f)
     # carries a disagreement of step 0 into step 1, may only differ where the defense of this or an earlier step did).
     bad = ((got.cpu() - want_def).abs() > 4e-6 * scale).nonzero().flatten()
     if gar == "meamed" and len(bad):
-      assert len(bad) <= 50 and bool(closest_edge_ties(ref.last_gradients, n - f, bad).all()), (gar, it, bad.tolist())
+      # (on the kernel's OWN inputs: the Byzantine vector differs from the reference's in its last bit, a near tie flips)
+      mine = [g[bad].cpu() for g in dev] + [step.last_byzantine[bad].cpu()] * f
+      value, tie = closest_columns(mine, n - f, torch.arange(len(bad)))
+      assert len(bad) <= 50 and explained(got[bad].cpu(), value, tie, scale), (gar, it, bad.tolist())
     else:
       assert len(bad) == 0, (gar, it, bad[:10].tolist())
     excused = bad if it == 0 else torch.unique(torch.cat([excused, bad]))
