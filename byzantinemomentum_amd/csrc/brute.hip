@@ -9,7 +9,9 @@
 // Same algorithm, same answer as the host search (which the CPU tests pin on exhaustive enumeration):
 //   * G(t) = {pairs at finite distance <= t}; "n - f mutually adjacent rows among `cand`" is decided by the same
 //     search tree (take the row with the most non-neighbours, the lowest index among equals: either it stays and
-//     they all go, or it goes), depth <= f, as an explicit stack of 64-bit row sets;
+//     they all go, or it goes), depth <= f, as an explicit stack of 64-bit row sets, plus one reduction rule (rows
+//     with more non-neighbours than removals left go at once) — the truth of the question does not depend on how the
+//     tree is walked;
 //   * the smallest t among {0} and the finite distances for which G(t) holds such a set: the host bisects over the
 //     SORTED distances; a wave has no cheap sort of up to 2 016 doubles, so it bisects quickselect-fashion — the
 //     pivot is the middle open candidate of the middle row that still has one — which visits O(log) pivots on any
@@ -82,6 +84,15 @@ struct BruteWave {
       if (active == 0) return true;  // no non-adjacent pair left: `cand` itself, count >= need rows
       const int budget = count - need;
       if (budget == 0) continue;
+      // rows that cannot stay (keeping one would cost more removals than the budget allows) all go at once, without
+      // branching: the answer does not depend on the order in which the tree is explored, only its size does — on the
+      // stacks of SURVEY 8d this rule alone settles most probes (50 instead of 120 tree nodes at n = 25, f = 5)
+      const uint64_t forced = __builtin_amdgcn_ballot_w64(missing > budget);
+      if (forced != 0) {
+        cand &= ~forced;
+        have = true;
+        continue;
+      }
 #pragma unroll
       for (int b = 5; b >= 0; --b) {
         const uint64_t with_bit = __builtin_amdgcn_ballot_w64(((missing >> b) & 1) != 0) & active;
