@@ -370,6 +370,15 @@ def sharded_extras(bm, agg, dist, device, world, rank, timer, args, rule_name, d
                                          f"matrix inside ({'libbm_gar RCCL communicator' if agg.native is not None else 'torch.distributed'}), "
                                          f"{tag}; wall clock of {args.steps} calls between barriers", scaling="strong")
   result = rule(stacks[0], f)
+  # the exchange itself: the n x n fp64 matrix through the same collective the rule uses (latency-bound: 5 KB)
+  probe = torch.zeros((n, n), dtype=torch.float64, device=device)
+  if agg.native is not None:
+    lib = bm._lib.load()
+    reduce_once = lambda i: bm._lib.check(lib.bm_allreduce_sum_f64(  # noqa: E731
+      agg.native.handle, probe.data_ptr(), n * n, torch.cuda.current_stream().cuda_stream), "bm_allreduce_sum_f64")
+  else:
+    reduce_once = lambda i: agg.all_reduce_sum(probe)  # noqa: E731
+  us_ar = over_ranks(timed_loop(reduce_once, 50, 5, timer, "x_allreduce")) * 1e3
   ms3 = over_ranks(timed_loop(lambda i: agg.all_gather_output(result, d_total), 10, 2, timer, "x_allgather"))
   out["allgather_output"] = entry(ms3, 4 * d_total, gpus=world, config=f"all-gather of the output slices, {tag}")
   if args.graph_replay:
@@ -422,6 +431,18 @@ def sharded_extras(bm, agg, dist, device, world, rank, timer, args, rule_name, d
   if rank == 0:
     extra["single_gpu_same_workload"] = {"value": 1e3 / single, "unit": "agg/s", "ms": single,
                                          "note": f"the unsharded {rule_name} on rank 0 alone, same total d = {d_total}"}
+    # the path's one real exchange, at the top level of the line (a SCALE record then carries it, not only the
+    # embarrassingly parallel headline): BASELINE.json configs[3] for Bulyan — strong scaling of a fixed d
+    key = f"{rule_name}_{'c3' if rule_name == 'krum' else 'c4'}_sharded"
+    sharded_ms = out[key]["avg_ms"] if key in out else None
+    extra["exchange"] = {
+      "workload": f"{rule_name} n={n} f={f}, total d={d_total} dim-sharded over {world} ranks (strong scaling), one all-reduce "
+                  f"of the {n}x{n} fp64 squared-distance partials inside the call",
+      "ms": sharded_ms, "agg_per_s": None if sharded_ms is None else 1e3 / sharded_ms,
+      "allreduce_us": us_ar, "allreduce_bytes": 8 * n * n,
+      "allgather_output_ms": ms3, "layout_exchange_ms": ms_a2a,
+      "single_gpu_ms": single, "speedup_vs_1gpu": None if sharded_ms is None else single / sharded_ms,
+      "collectives": "libbm_gar's own RCCL communicator" if agg.native is not None else "torch.distributed (RCCL)"}
   return out
 
 

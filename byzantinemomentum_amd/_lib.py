@@ -108,6 +108,9 @@ SIGNATURES = {
   "bm_colwise_eval": (ctypes.c_int, [ctypes.c_int, _c_float_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p]),
+  "bm_pairwise_rank": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                      ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                      ctypes.c_void_p]),
   "bm_sharded_workspace_bytes": (ctypes.c_int64, [ctypes.c_int, ctypes.c_int64]),
   "bm_sharded_krum": (ctypes.c_int, [ctypes.c_void_p, _c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_int64,
                                      ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),

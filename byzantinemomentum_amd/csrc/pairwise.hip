@@ -32,6 +32,8 @@
 //   * per-workgroup partial sums go to a workspace as fp64 and are reduced in a fixed order by
 //     a second tiny kernel — deterministic, no float atomics.
 #include "bm_common.h"
+#include "rank_body.h"
+#include "gram_tail.h"
 
 namespace bm {
 
@@ -424,61 +426,16 @@ static int pair_grid_blocks(const PairGeom& g, int64_t d) {
 // fp64 — the same sequence of additions as the reference's `sum(sorted(...)[:take])`.
 // ---------------------------------------------------------------------------
 constexpr int kRankThreads = 1024;
-__device__ __forceinline__ double readlane_f64(double v, int lane) {
-  const unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
-  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)bits, lane);
-  const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), lane);
-  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
+// ranked: NULL, or a device flag that says "the Gram kernel's last workgroup has ranked this call already" (the fused
+// single-GPU path, gram_bf16.hip): the launch then has nothing to do.
 __global__ __launch_bounds__(kRankThreads) void krum_rank_kernel(const double* __restrict__ sq, int n,
                                                                  int f, int m, int mode,
                                                                  int32_t* __restrict__ order,
-                                                                 double* __restrict__ scores_out) {
-  __shared__ double srt[BM_MAX_ROWS][BM_MAX_ROWS + 1];  // srt[i][r] = r-th smallest distance of row i to the others
-  __shared__ double score[BM_MAX_ROWS];
-  const double kInf = __builtin_inf();
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  // One wave per row (n <= 64): lane j holds dist(i, j) = sqrt in fp64, non-finite -> +inf (krum.py:46-47); its rank
-  // among the row's other distances is counted against every lane's value broadcast from its register
-  // (v_readlane: no LDS traffic; round 2 read n^2 * n doubles from LDS here, 8 us of the 19 at n = 51).
-  for (int i = wave; i < n; i += kRankThreads / 64) {
-    const bool mine = lane < n && lane != i;
-    double v = kInf;
-    if (mine) {
-      v = sqrt(sq[i * n + lane]);
-      if (!(v == v) || v == kInf || v == -kInf) v = kInf;
-    }
-    int rank = 0;
-    for (int l = 0; l < n; ++l) {  // wave-uniform
-      const double o = readlane_f64(v, l);
-      rank += (l != i && (o < v || (o == v && l < lane))) ? 1 : 0;
-    }
-    if (mine) srt[i][rank] = v;
-  }
-  __syncthreads();
-  if (tid < n) {
-    // krum: n-f-1 smallest (krum.py:59-60); bulyan: m smallest (bulyan.py:58-61)
-    int take = (mode == BM_RANK_KRUM) ? (n - f - 1) : m;
-    if (take > n - 1) take = n - 1;
-    if (take < 0) take = 0;
-    double s = 0.0;
-#pragma unroll 8
-    for (int t = 0; t < take; ++t) s += srt[tid][t];  // additions stay in ascending order
-    score[tid] = s;
-    if (scores_out != nullptr) scores_out[tid] = s;
-  }
-  __syncthreads();
-  if (tid < n) {
-    // stable argsort: rank = #rows with a smaller score, ties to the lower index
-    const double si = score[tid];
-    int rank = 0;
-#pragma unroll 8
-    for (int j = 0; j < n; ++j) {
-      const double sj = score[j];
-      rank += (sj < si || (sj == si && j < tid)) ? 1 : 0;
-    }
-    order[rank] = tid;
-  }
+                                                                 double* __restrict__ scores_out,
+                                                                 const int* __restrict__ ranked) {
+  __shared__ double lds[kRankLdsBytes / sizeof(double)];
+  if (ranked != nullptr && *ranked != 0) return;
+  krum_rank_body(sq, n, f, m, mode, order, scores_out, lds);
 }
 
 }  // namespace bm
@@ -488,7 +445,8 @@ int gram_finish(const double* partial, int blocks, int n, int n_full, double* gr
                 hipStream_t s);
 int gram_arrival_slot();
 int gram3_partials(const float* const* rows, int n, int64_t d, int64_t d_total, double* partial, int* sub,
-                   int* blocks_out, hipStream_t s);
+                   int* blocks_out, hipStream_t s, const GramTail* fold);
+int gram_ranked_slot();
 int64_t gram3_partial_doubles(int n);
 
 // Workspace layout of bm_pairwise_sqdist: [row list of the gate: 512 B][Gram partials][Gram n(n+1)/2][direct partials]
@@ -539,6 +497,43 @@ static int pairwise_direct(const float* const* rows, int n, int64_t d, double* s
 }
 }  // namespace bm
 
+namespace bm {
+// The default distance pass (BM_PAIR_MODE 0) in TWO launches: the Gram kernel, whose last workgroups also sum the
+// partial matrices, form the squared distances and the accuracy gate's row list (and rank the rows when `rank` is
+// given and the list is empty), then the gated direct kernel, which returns at once unless rows were listed.
+// Round 3: Gram -> reduction + distances -> gated kernel (-> rank): the chain of small dependent launches that a
+// rank of an 8-GPU job spends a third of its time in.
+struct RankRequest {
+  int f, m, mode;
+  int32_t* order;
+  double* scores;
+};
+static int pairwise_gram_path(const float* const* rows, int n, int64_t d, int64_t d_total, double* sq_nxn, void* ws,
+                              const RankRequest* rank, hipStream_t s) {
+  int* flag = static_cast<int*>(ws);  // flag[0] = rows to recompute, flag[1..] = their indices; counters behind them
+  double* gram_partial = reinterpret_cast<double*>(static_cast<char*>(ws) + 512);
+  double* direct_partial = gram_partial + pair_gram_doubles(n);
+  const double tau = tuning().pair_tau;
+  GramTail tail{};
+  tail.gram = gram_partial + gram3_partial_doubles(n);
+  tail.sq = sq_nxn;
+  tail.tau = tau;
+  tail.n_full = n;
+  if (rank != nullptr) {
+    tail.rank = 1;
+    tail.rank_f = rank->f;
+    tail.rank_m = rank->m;
+    tail.rank_mode = rank->mode;
+    tail.order = rank->order;
+    tail.scores = rank->scores;
+  }
+  int blocks = 0;
+  int rc = gram3_partials(rows, n, d, d_total, gram_partial, flag, &blocks, s, &tail);
+  if (rc != 0 || tau <= 0.0) return rc;
+  return pairwise_direct(rows, n, d, sq_nxn, direct_partial, flag, s);
+}
+}  // namespace bm
+
 extern "C" int bm_pairwise_sqdist(const float* const* rows, int n, int64_t d, double* sq_nxn,
                                   void* ws, void* stream) {
   return bm_pairwise_sqdist_shard(rows, n, d, d, sq_nxn, ws, stream);
@@ -550,7 +545,6 @@ extern "C" int bm_pairwise_sqdist_shard(const float* const* rows, int n, int64_t
   if (rows == nullptr || sq_nxn == nullptr || ws == nullptr || n < 1 || n > BM_MAX_ROWS || d < 0 || d_total < d)
     return BM_EINVAL;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  int* flag = static_cast<int*>(ws);  // flag[0] = rows to recompute, flag[1..] = their indices
   double* gram_partial = reinterpret_cast<double*>(static_cast<char*>(ws) + 512);
   double* direct_partial = gram_partial + pair_gram_doubles(n);
   // BM_PAIR_MODE: 0 (default) centred Gram on the bf16 matrix cores, error-free split (gram_bf16.hip), ending with the
@@ -559,14 +553,7 @@ extern "C" int bm_pairwise_sqdist_shard(const float* const* rows, int n, int64_t
   //               1 direct differences on the VALU (this file) for every pair, no cancellation at all.
   const int mode = tuning().pair_mode;
   if (mode == 1) return pairwise_direct(rows, n, d, sq_nxn, direct_partial, nullptr, s);
-  const double tau = tuning().pair_tau;
-  int blocks = 0;
-  int rc = gram3_partials(rows, n, d, d_total, gram_partial, flag, &blocks, s);
-  if (rc != 0) return rc;
-  double* gram = gram_partial + gram3_partial_doubles(n);
-  rc = gram_finish(gram_partial, blocks, n, n, gram, sq_nxn, flag, tau, s);
-  if (rc != 0 || tau <= 0.0) return rc;
-  return pairwise_direct(rows, n, d, sq_nxn, direct_partial, flag, s);
+  return pairwise_gram_path(rows, n, d, d_total, sq_nxn, ws, nullptr, s);
 }
 
 namespace bm {
@@ -596,7 +583,29 @@ extern "C" int bm_krum_rank(const double* sq_nxn, int n, int f, int m, int mode,
       (mode != BM_RANK_KRUM && mode != BM_RANK_BULYAN))
     return BM_EINVAL;
   hipLaunchKernelGGL(krum_rank_kernel, dim3(1), dim3(kRankThreads), 0, static_cast<hipStream_t>(stream),
-                     sq_nxn, n, f, m, mode, order_out, scores_out);
+                     sq_nxn, n, f, m, mode, order_out, scores_out, static_cast<const int*>(nullptr));
+  BM_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int bm_pairwise_rank(const float* const* rows, int n, int64_t d, int64_t d_total, int f, int m, int mode,
+                                double* sq_nxn, int32_t* order_out, double* scores_out, void* ws, void* stream) {
+  using namespace bm;
+  if (rows == nullptr || sq_nxn == nullptr || order_out == nullptr || ws == nullptr || n < 1 || n > BM_MAX_ROWS ||
+      d < 0 || d_total < d || f < 0 || (mode != BM_RANK_KRUM && mode != BM_RANK_BULYAN))
+    return BM_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (tuning().pair_mode == 1) {
+    const int rc = bm_pairwise_sqdist_shard(rows, n, d, d_total, sq_nxn, ws, stream);
+    return rc != 0 ? rc : bm_krum_rank(sq_nxn, n, f, m, mode, order_out, scores_out, stream);
+  }
+  const RankRequest req{f, m, mode, order_out, scores_out};
+  const int rc = pairwise_gram_path(rows, n, d, d_total, sq_nxn, ws, &req, s);
+  if (rc != 0) return rc;
+  // the rows are ranked already unless the gate listed some (the direct kernel has then corrected their distances):
+  // this launch returns at once in the first case
+  hipLaunchKernelGGL(krum_rank_kernel, dim3(1), dim3(kRankThreads), 0, s, sq_nxn, n, f, m, mode, order_out, scores_out,
+                     static_cast<const int*>(static_cast<int*>(ws) + gram_ranked_slot()));
   BM_LAUNCH_CHECK();
   return 0;
 }

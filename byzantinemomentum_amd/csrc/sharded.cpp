@@ -131,6 +131,12 @@ int sharded_rank(bm_comm* comm, const float* const* rows, int n, int64_t d_local
   int32_t* order = reinterpret_cast<int32_t*>(base + BM_MAX_ROWS * BM_MAX_ROWS * 8);
   void* pair_ws = base + kShardHeader;
   int rc = 0;
+  if (!have_sq && comm == nullptr) {
+    // one rank: nothing to exchange — distances, gate and ranking in the distance pass's own launches
+    *sq_out = sq;
+    *order_out = order;
+    return bm_pairwise_rank(rows, n, d_local, d_total, f, m, mode, sq, order, nullptr, pair_ws, stream);
+  }
   if (!have_sq) {
     // the precision plan of the distance pass follows the length of the WHOLE vector (all shards), which the caller
     // states: a short or empty trailing shard must plan exactly like its peers

@@ -62,11 +62,14 @@ class _Scratch:
 
   @classmethod
   def get(cls, device, name, nbytes=None, shape=None, dtype=torch.uint8):
+    """Workspaces are ZEROED when they are created: the distance pass keeps the arrival counters of its in-kernel
+    reductions in the first 512 bytes of its workspace and expects them zero at first use (include/bm_gar.h,
+    bm_pairwise_sqdist); the kernels leave them zero afterwards."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream, name)
     buf = cls._cache.get(key)
     want = (nbytes,) if shape is None else tuple(shape)
     if buf is None or buf.dtype != dtype or tuple(buf.shape) != want:
-      buf = torch.empty(want, dtype=dtype, device=device)
+      buf = torch.zeros(want, dtype=dtype, device=device)
       cls._cache[key] = buf
     return buf
 
@@ -147,9 +150,18 @@ def rank_from_sqdist(sq, n, f, m, mode):
 
 
 def _rank(gradients, f, m, mode):
-  """Distances -> scores -> stable order, all on the device. Returns (order int32[n], scores f64[n])."""
+  """Distances -> scores -> stable order, all on the device, in the distance pass's own launches (bm_pairwise_rank:
+  its last workgroups rank the rows).  Returns (order int32[MAX_ROWS], scores f64[MAX_ROWS])."""
   n, d, device = _validate(gradients)
-  return rank_from_sqdist(pairwise_sqdist(gradients), n, f, m, mode)
+  lib = _lib.load()
+  sq = torch.empty((n, n), dtype=torch.float64, device=device)
+  order = torch.empty(_lib.MAX_ROWS, dtype=torch.int32, device=device)
+  scores = torch.empty(_lib.MAX_ROWS, dtype=torch.float64, device=device)
+  ws = _workspace(device, _lib.WS_PAIRWISE, n, d, "ws_pair")
+  with torch.cuda.device(device):
+    _lib.check(lib.bm_pairwise_rank(_lib.pointer_table(gradients), n, d, d, f, m, mode, _ptr(sq), _ptr(order),
+                                    _ptr(scores), _ptr(ws), _stream(device)), "bm_pairwise_rank")
+  return order, scores
 
 
 def selected_mean(gradients, idx, m):
