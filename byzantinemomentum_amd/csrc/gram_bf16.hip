@@ -44,8 +44,6 @@
 //   * fp32 chains cover 32 coordinates, per-wave fp32 sums ~100 chunks, everything wider is fp64
 //     (workgroup, grid, GPUs) in a fixed order: deterministic, no atomics.
 #include "gram_split.h"
-#include "rank_body.h"
-#include "gram_tail.h"
 
 namespace bm {
 
@@ -77,79 +75,13 @@ struct B3Shape {
   static constexpr bool PIPE = !(NPL == 3 && K >= 15);
   static constexpr int kPtrBytes = BM_MAX_ROWS * 8;
   static constexpr int kRedBytes = kB3Waves * 256 * 8;
-  static constexpr int kWork = kB3Waves * WS > kRedBytes ? kB3Waves * WS : kRedBytes;
-  // (the last workgroup of a folded launch ranks the rows in the same region: rank_body.h)
-  static constexpr int kLds = kPtrBytes + (kWork > kRankLdsBytes ? kWork : kRankLdsBytes);
+  static constexpr int kLds = kPtrBytes + (kB3Waves * WS > kRedBytes ? kB3Waves * WS : kRedBytes);
 };
-
-// The tail of the distance pass inside the Gram kernel (single launch instead of Gram + reduction): where the partial
-// Gram matrices of the workgroups are summed, in which order, and what the last workgroup does with the result.
-//   level 1: groups of kTailGroup consecutive workgroups; the LAST of a group to arrive adds the group's partials in
-//            workgroup order -> gpart[group];
-//   level 2: the LAST group to finish adds the group sums in group order -> gram, forms the squared distances and the
-//            accuracy gate's row list (gram_to_sqdist), and — when asked to and the list is empty — ranks the rows.
-// Every entry is summed in a fixed order whatever the arrival order: deterministic.  The counters (ints of the
-// 512-byte row-list area) must be zero when the launch starts; whoever arrives last sets them back to zero, so a
-// workspace whose header was zeroed ONCE stays usable (include/bm_gar.h, bm_pairwise_sqdist).
-constexpr int kTailGroup = 64;
-constexpr int kTailSlot = 100;    // counters: [kTailSlot] level 2, [kTailSlot + 1 + group] level 1 (<= 16 groups of 64)
-constexpr int kRankedSlot = 98;   // 1 when the launch ranked the rows itself (krum_rank_kernel then returns at once)
-
-// sq[i][j] = G_ii + G_jj - 2 G_ij in fp64, by one workgroup of kSqThreads lanes.  Also decides whether the Gram form
-// was accurate enough: its absolute error is ~eps_G * (G_ii + G_jj) (eps_G ~ 6e-9, measured), so a pair
-// whose squared distance is below tau * (G_ii + G_jj) — two rows that nearly coincide relative to
-// their (centred) norms — has lost relative accuracy eps_G / tau.  The rows of such pairs are listed in
-// `sub` (sub[0] = count, sub[1..] = indices, ascending); the caller recomputes the distances among them
-// with the direct-difference kernel (pairwise.hip), which has no cancellation: near-duplicate rows
-// lie close to EACH OTHER, so that sub-stack is exactly where the Gram form cannot be trusted.
-// Bitwise-equal rows (G_ii == G_jj == G_ij) are exact (d2 = 0) and never listed.
-constexpr int kSqThreads = 1024;
-constexpr int kArrivalSlot = 96;  // int slot of the 512-byte row-list area that counts the workgroups of the reduction
-// n rows in G (compact), n_full >= n rows in sq: rows n-1 .. n_full-1 of the full stack are ONE row of G (the aliased
-// Byzantine copies of a step: the Gram kernel contracted the row once); they are at distance exactly 0 of each other
-// and share every other distance, and if the gate lists one of them it lists them all.
-__device__ __forceinline__ void gram_to_sqdist(const double* __restrict__ gram, int n, double tau,
-                                               double* __restrict__ sq, int* __restrict__ sub, int* listed, int n_full) {
-  if (threadIdx.x < BM_MAX_ROWS) listed[threadIdx.x] = 0;
-  __syncthreads();
-  for (int e = threadIdx.x; e < n_full * n_full; e += (int)blockDim.x) {
-    const int i = e / n_full, j = e - i * n_full;
-    const int ci = i < n ? i : n - 1, cj = j < n ? j : n - 1;
-    if (ci == cj) {
-      // the diagonal (never read: 0) and pairs of aliased copies: exactly 0 when the row is finite; a row with a
-      // non-finite coordinate is at non-finite distance of everything, its own copies included (x - x = nan in
-      // krum.py:44-47, which the rules turn into +inf; bm_pairwise_sqdist on the expanded stack says NaN too)
-      const double gdd = gram[b3_tri_index(ci, ci, n)];
-      sq[e] = (i != j && !(fabs(gdd) < __builtin_inf())) ? __builtin_nan("") : 0.0;
-      continue;
-    }
-    const int lo = ci < cj ? ci : cj, hi = ci < cj ? cj : ci;
-    const double gii = gram[b3_tri_index(lo, lo, n)], gjj = gram[b3_tri_index(hi, hi, n)];
-    const double gij = gram[b3_tri_index(lo, hi, n)];
-    double v = (gii + gjj) - 2.0 * gij;
-    const bool same = (gii == gjj) && (gij == gii);
-    if (!same && v < tau * (gii + gjj)) {  // NaN compares false: non-finite rows are never listed
-      listed[i] = 1;                       // benign race: every writer stores 1
-      listed[j] = 1;
-    }
-    if (v < 0.0) v = 0.0;  // rounding of nearly identical rows; NaN stays NaN
-    sq[e] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0 && sub != nullptr) {
-    bool alias_listed = false;
-    for (int r = n - 1; r < n_full; ++r) alias_listed |= listed[r] != 0;
-    int count = 0;
-    for (int r = 0; r < n_full; ++r)
-      if (listed[r] || (alias_listed && r >= n - 1 && n_full > n)) sub[1 + count++] = r;
-    sub[0] = count;
-  }
-}
 
 template <int K, int NPL, bool ALIGNED>
 __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_partial_kernel(
     RowTable rows, int n, int64_t d, float inv_n, int centre, unsigned dither_seed, double* __restrict__ partial,
-    int* __restrict__ arrival, int steady, GramTail tail) {
+    int* __restrict__ arrival, int steady) {
   using S = B3Shape<K, NPL>;
   constexpr int RB = S::RB, NP = S::NP, NSETS = S::NSETS;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -445,44 +377,56 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
       __syncthreads();
       ++p;
     }
-  if (tail.gpart == nullptr) return;
-  // ---- the reduction over the workgroups, inside this launch (see GramTail) ----
-  int* sub = arrival - kArrivalSlot;  // the row-list area
-  __shared__ int last;
-  const int group = (int)blockIdx.x / kTailGroup;
-  const int ngroups = ((int)gridDim.x + kTailGroup - 1) / kTailGroup;
-  const int first = group * kTailGroup;
-  const int gsize = ((int)gridDim.x - first < kTailGroup) ? (int)gridDim.x - first : kTailGroup;
-  if (!arrive_last(sub + kTailSlot + 1 + group, gsize, &last)) return;
-  for (int e = tid; e < per_block; e += 64 * kB3Waves) {
-    double s = 0.0;
-#pragma unroll 8
-    for (int b = 0; b < gsize; ++b) s += partial[(int64_t)(first + b) * per_block + e];
-    tail.gpart[(int64_t)group * per_block + e] = s;
-  }
-  if (tid == 0) sub[kTailSlot + 1 + group] = 0;
-  if (!arrive_last(sub + kTailSlot, ngroups, &last)) return;
-  for (int e = tid; e < per_block; e += 64 * kB3Waves) {
-    double s = 0.0;
-    for (int gq = 0; gq < ngroups; ++gq) s += tail.gpart[(int64_t)gq * per_block + e];
-    tail.gram[e] = s;
-  }
-  __threadfence();
-  __syncthreads();  // (the workgroup's own global stores are visible to it after the fence and the barrier)
-  int* listed = reinterpret_cast<int*>(smem + S::kPtrBytes);  // BM_MAX_ROWS ints; the rank arrays follow the barrier below
-  gram_to_sqdist(tail.gram, n, tail.tau, tail.sq, sub, listed, tail.n_full);
-  __threadfence();
+}
+
+// sq[i][j] = G_ii + G_jj - 2 G_ij in fp64, by one workgroup of kSqThreads lanes.  Also decides whether the Gram form
+// was accurate enough: its absolute error is ~eps_G * (G_ii + G_jj) (eps_G ~ 6e-9, measured), so a pair
+// whose squared distance is below tau * (G_ii + G_jj) — two rows that nearly coincide relative to
+// their (centred) norms — has lost relative accuracy eps_G / tau.  The rows of such pairs are listed in
+// `sub` (sub[0] = count, sub[1..] = indices, ascending); the caller recomputes the distances among them
+// with the direct-difference kernel (pairwise.hip), which has no cancellation: near-duplicate rows
+// lie close to EACH OTHER, so that sub-stack is exactly where the Gram form cannot be trusted.
+// Bitwise-equal rows (G_ii == G_jj == G_ij) are exact (d2 = 0) and never listed.
+constexpr int kSqThreads = 1024;
+constexpr int kArrivalSlot = 96;  // int slot of the 512-byte row-list area that counts the workgroups of the reduction
+// n rows in G (compact), n_full >= n rows in sq: rows n-1 .. n_full-1 of the full stack are ONE row of G (the aliased
+// Byzantine copies of a step: the Gram kernel contracted the row once); they are at distance exactly 0 of each other
+// and share every other distance, and if the gate lists one of them it lists them all.
+__device__ __forceinline__ void gram_to_sqdist(const double* __restrict__ gram, int n, double tau,
+                                               double* __restrict__ sq, int* __restrict__ sub, int* listed, int n_full) {
+  if (threadIdx.x < BM_MAX_ROWS) listed[threadIdx.x] = 0;
   __syncthreads();
-  const bool do_rank = tail.rank != 0 && sub[0] == 0;
-  if (tid == 0) {
-    sub[kTailSlot] = 0;
-    sub[kArrivalSlot + 1] = 0;  // arrival counter of the gated direct kernel (pairwise.hip), next on the stream
-    sub[kRankedSlot] = do_rank ? 1 : 0;
+  for (int e = threadIdx.x; e < n_full * n_full; e += kSqThreads) {
+    const int i = e / n_full, j = e - i * n_full;
+    const int ci = i < n ? i : n - 1, cj = j < n ? j : n - 1;
+    if (ci == cj) {
+      // the diagonal (never read: 0) and pairs of aliased copies: exactly 0 when the row is finite; a row with a
+      // non-finite coordinate is at non-finite distance of everything, its own copies included (x - x = nan in
+      // krum.py:44-47, which the rules turn into +inf; bm_pairwise_sqdist on the expanded stack says NaN too)
+      const double gdd = gram[b3_tri_index(ci, ci, n)];
+      sq[e] = (i != j && !(fabs(gdd) < __builtin_inf())) ? __builtin_nan("") : 0.0;
+      continue;
+    }
+    const int lo = ci < cj ? ci : cj, hi = ci < cj ? cj : ci;
+    const double gii = gram[b3_tri_index(lo, lo, n)], gjj = gram[b3_tri_index(hi, hi, n)];
+    const double gij = gram[b3_tri_index(lo, hi, n)];
+    double v = (gii + gjj) - 2.0 * gij;
+    const bool same = (gii == gjj) && (gij == gii);
+    if (!same && v < tau * (gii + gjj)) {  // NaN compares false: non-finite rows are never listed
+      listed[i] = 1;                       // benign race: every writer stores 1
+      listed[j] = 1;
+    }
+    if (v < 0.0) v = 0.0;  // rounding of nearly identical rows; NaN stays NaN
+    sq[e] = v;
   }
-  if (do_rank) {
-    __syncthreads();
-    krum_rank_body(tail.sq, tail.n_full, tail.rank_f, tail.rank_m, tail.rank_mode, tail.order, tail.scores,
-                   reinterpret_cast<double*>(smem + S::kPtrBytes));
+  __syncthreads();
+  if (threadIdx.x == 0 && sub != nullptr) {
+    bool alias_listed = false;
+    for (int r = n - 1; r < n_full; ++r) alias_listed |= listed[r] != 0;
+    int count = 0;
+    for (int r = 0; r < n_full; ++r)
+      if (listed[r] || (alias_listed && r >= n - 1 && n_full > n)) sub[1 + count++] = r;
+    sub[0] = count;
   }
 }
 
@@ -538,7 +482,7 @@ int gram_arrival_slot() { return kArrivalSlot; }
 
 template <int K, int NPL>
 static int launch_gram3_planes(const RowTable& tab, int n, int64_t d, bool aligned, int centre, double* partial,
-                               int* arrival, int blocks, const GramTail& tail, hipStream_t s) {
+                               int* arrival, int blocks, hipStream_t s) {
   using S = B3Shape<K, NPL>;
   auto kern = aligned ? gram3_partial_kernel<K, NPL, true> : gram3_partial_kernel<K, NPL, false>;
   if (S::kLds > 64 * 1024) {
@@ -547,33 +491,27 @@ static int launch_gram3_planes(const RowTable& tab, int n, int64_t d, bool align
     if (e != hipSuccess) return hip_code(e);
   }
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * kB3Waves), S::kLds, s, tab, n, d, 1.0f / (float)n, centre,
-                     (unsigned)tuning().pair_dither, partial, arrival, tuning().gram_steady, tail);
+                     (unsigned)tuning().pair_dither, partial, arrival, tuning().gram_steady);
   BM_LAUNCH_CHECK();
   return 0;
 }
 
 template <int K>
 static int launch_gram3(const RowTable& tab, int n, int64_t d, bool aligned, int centre, int planes,
-                        double* partial, int* arrival, int blocks, const GramTail& tail, hipStream_t s) {
-  return planes == 2 ? launch_gram3_planes<K, 2>(tab, n, d, aligned, centre, partial, arrival, blocks, tail, s)
-                     : launch_gram3_planes<K, 3>(tab, n, d, aligned, centre, partial, arrival, blocks, tail, s);
+                        double* partial, int* arrival, int blocks, hipStream_t s) {
+  return planes == 2 ? launch_gram3_planes<K, 2>(tab, n, d, aligned, centre, partial, arrival, blocks, s)
+                     : launch_gram3_planes<K, 3>(tab, n, d, aligned, centre, partial, arrival, blocks, s);
 }
 
 constexpr int kB3MaxBlocks = 1024;
 
-// the per-workgroup partials, then the sums of the groups of kTailGroup workgroups (folded launches)
-int64_t gram3_partial_doubles(int n) {
-  return (int64_t)(kB3MaxBlocks + (kB3MaxBlocks + kTailGroup - 1) / kTailGroup) * ((int64_t)n * (n + 1) / 2);
-}
-int gram_ranked_slot() { return kRankedSlot; }
+int64_t gram3_partial_doubles(int n) { return (int64_t)kB3MaxBlocks * ((int64_t)n * (n + 1) / 2); }
 
 // Partial Gram matrices of the centred rows; returns the number of workgroups (= partial blocks)
 // through *blocks_out.  `partial` holds gram3_partial_doubles(n) doubles; `sub` is the 512-byte row-list area of the
 // accuracy gate, whose arrival counter (for gram_finish, next on the stream) this launch resets.
-// fold != NULL: the launch also reduces the partials and writes gram / sq / the gate's list (and the ranking when
-// fold->rank and the list is empty): the caller fills gram, sq, tau, n_full and the rank fields, gpart is set here.
 int gram3_partials(const float* const* rows, int n, int64_t d, int64_t d_total, double* partial, int* sub,
-                   int* blocks_out, hipStream_t s, const GramTail* fold) {
+                   int* blocks_out, hipStream_t s) {
   RowTable tab{};
   for (int i = 0; i < n; ++i) tab.p[i] = rows[i];
   const bool aligned = common_vec_width(reinterpret_cast<const void* const*>(rows), n, nullptr) == 4;
@@ -593,15 +531,10 @@ int gram3_partials(const float* const* rows, int n, int64_t d, int64_t d_total, 
   const int64_t need = (chunks + kB3Waves - 1) / kB3Waves;
   if (blocks > need) blocks = (int)(need > 0 ? need : 1);
   const int centre = 2;  // median of three rows (1 = row mean, 0 = none: measured alternatives)
-  GramTail tail{};
-  if (fold != nullptr) {
-    tail = *fold;
-    tail.gpart = partial + (int64_t)kB3MaxBlocks * ((int64_t)n * (n + 1) / 2);
-  }
   int rc;
   switch (K) {
 #define BM_B3_CASE(KK) \
-  case KK: rc = launch_gram3<KK>(tab, n, d, aligned, centre, planes, partial, sub + kArrivalSlot, blocks, tail, s); break;
+  case KK: rc = launch_gram3<KK>(tab, n, d, aligned, centre, planes, partial, sub + kArrivalSlot, blocks, s); break;
     BM_B3_CASE(1) BM_B3_CASE(2) BM_B3_CASE(3) BM_B3_CASE(4) BM_B3_CASE(5) BM_B3_CASE(6) BM_B3_CASE(7)
     BM_B3_CASE(8) BM_B3_CASE(9) BM_B3_CASE(10) BM_B3_CASE(11) BM_B3_CASE(12) BM_B3_CASE(13) BM_B3_CASE(14)
     BM_B3_CASE(15) BM_B3_CASE(16)

@@ -33,7 +33,6 @@
 //     a second tiny kernel — deterministic, no float atomics.
 #include "bm_common.h"
 #include "rank_body.h"
-#include "gram_tail.h"
 
 namespace bm {
 
@@ -140,6 +139,13 @@ __device__ __forceinline__ int row_offset_bytes(const PairGeom& g, int I, int a)
   return blk * kDmaPitch + (a % g.rb) * g.row_bytes;
 }
 
+// what a gated launch does on top of its own work when it belongs to bm_pairwise_rank (by value in the kernarg segment)
+struct RankArgs {
+  int on, f, m, mode;
+  int32_t* order;
+  double* scores;
+};
+
 constexpr int kRedWaves = 8;
 constexpr int kDirectArrivalSlot = 97;  // int slot of the gate's 512-byte row-list area: arrival counter of the gated call
 
@@ -179,15 +185,23 @@ __device__ __forceinline__ void pair_scatter(int e, double tot, const PairGeom& 
 template <bool ALIGNED, int ABLATE = 0>
 __global__ __launch_bounds__(kPairMaxThreads) void pairwise_partial_kernel(
     RowTable rows, PairGeom g, int64_t d, double* __restrict__ partial, int* __restrict__ sub, int n_full,
-    double* __restrict__ sq) {
+    double* __restrict__ sq, RankArgs rk) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   // sub (device, may be NULL): the rows the accuracy gate of the Gram path asks to recompute
   // (gram_to_sqdist_kernel): sub[0] = how many (0: this launch has nothing to do), sub[1..] = their
   // indices.  The kernel then works on that sub-stack with the geometry of ITS row count.
+  // rk.on (gated launches of bm_pairwise_rank): the launch also RANKS the rows from the final distances, so a
+  // single-GPU Krum / Bulyan has no rank launch of its own — workgroup 0 right here when nothing was listed (the
+  // common case: this launch did nothing at all before), else the workgroup that arrives last, after it has
+  // written the corrected distances.
   if (sub != nullptr) {
-    if (sub[0] == 0) return;
+    if (sub[0] == 0) {
+      if (rk.on && blockIdx.x == 0)
+        krum_rank_body(sq, n_full, rk.f, rk.m, rk.mode, rk.order, rk.scores, reinterpret_cast<double*>(smem));
+      return;
+    }
     g = pair_geometry(sub[0], 0);
   }
-  extern __shared__ __attribute__((aligned(16))) char smem[];
   const float** row_ptr = reinterpret_cast<const float**>(smem);  // 512 B pointer table
   char* tiles = smem + BM_MAX_ROWS * sizeof(float*);
   const int tid = threadIdx.x;
@@ -386,6 +400,11 @@ __global__ __launch_bounds__(kPairMaxThreads) void pairwise_partial_kernel(
     __syncthreads();
   }
   if (tid == 0) sub[kDirectArrivalSlot] = 0;
+  if (rk.on) {
+    __threadfence();
+    __syncthreads();  // the corrected distances of this workgroup's own stores are visible to all its lanes
+    krum_rank_body(sq, n_full, rk.f, rk.m, rk.mode, rk.order, rk.scores, reinterpret_cast<double*>(smem));
+  }
 }
 
 // Cross-workgroup reduction in a fixed order.  A workgroup of 8 waves owns 64 consecutive
@@ -426,15 +445,11 @@ static int pair_grid_blocks(const PairGeom& g, int64_t d) {
 // fp64 — the same sequence of additions as the reference's `sum(sorted(...)[:take])`.
 // ---------------------------------------------------------------------------
 constexpr int kRankThreads = 1024;
-// ranked: NULL, or a device flag that says "the Gram kernel's last workgroup has ranked this call already" (the fused
-// single-GPU path, gram_bf16.hip): the launch then has nothing to do.
 __global__ __launch_bounds__(kRankThreads) void krum_rank_kernel(const double* __restrict__ sq, int n,
                                                                  int f, int m, int mode,
                                                                  int32_t* __restrict__ order,
-                                                                 double* __restrict__ scores_out,
-                                                                 const int* __restrict__ ranked) {
+                                                                 double* __restrict__ scores_out) {
   __shared__ double lds[kRankLdsBytes / sizeof(double)];
-  if (ranked != nullptr && *ranked != 0) return;
   krum_rank_body(sq, n, f, m, mode, order, scores_out, lds);
 }
 
@@ -445,8 +460,7 @@ int gram_finish(const double* partial, int blocks, int n, int n_full, double* gr
                 hipStream_t s);
 int gram_arrival_slot();
 int gram3_partials(const float* const* rows, int n, int64_t d, int64_t d_total, double* partial, int* sub,
-                   int* blocks_out, hipStream_t s, const GramTail* fold);
-int gram_ranked_slot();
+                   int* blocks_out, hipStream_t s);
 int64_t gram3_partial_doubles(int n);
 
 // Workspace layout of bm_pairwise_sqdist: [row list of the gate: 512 B][Gram partials][Gram n(n+1)/2][direct partials]
@@ -457,7 +471,7 @@ static int64_t pair_gram_doubles(int n) { return gram3_partial_doubles(n) + (int
 // immediately when it is empty, else recompute exactly the pairs among the listed rows (device-side
 // decision, no host synchronisation; the launch is shaped for the worst case, all n rows).
 static int pairwise_direct(const float* const* rows, int n, int64_t d, double* sq_nxn, double* partial,
-                           int* sub, hipStream_t s) {
+                           int* sub, hipStream_t s, const RankArgs* rank = nullptr) {
   const PairGeom g = pair_geometry(n, 0);
   RowTable tab{};
   for (int i = 0; i < n; ++i) tab.p[i] = rows[i];
@@ -475,6 +489,12 @@ static int pairwise_direct(const float* const* rows, int n, int64_t d, double* s
     if (gk.width < min_width) min_width = gk.width;
   }
   lds_bytes += BM_MAX_ROWS * sizeof(float*);  // row pointer table in front
+  RankArgs rk{};
+  if (rank != nullptr && sub != nullptr) {
+    rk = *rank;
+    rk.on = 1;
+    if (lds_bytes < (size_t)kRankLdsBytes) lds_bytes = kRankLdsBytes;  // (the ranking's arrays alias the tiles)
+  }
   PairGeom gw = g;
   gw.width = (int)min_width;
   const int blocks = pair_grid_blocks(gw, d);
@@ -486,7 +506,7 @@ static int pairwise_direct(const float* const* rows, int n, int64_t d, double* s
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     if (e != hipSuccess) return hip_code(e);
   }
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds_bytes, s, tab, g, d, partial, sub, n, sq_nxn);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds_bytes, s, tab, g, d, partial, sub, n, sq_nxn, rk);
   BM_LAUNCH_CHECK();
   if (sub == nullptr) {
     hipLaunchKernelGGL(pairwise_reduce_kernel, dim3((per_block + 63) / 64), dim3(64 * kRedWaves), 0, s,
@@ -498,39 +518,24 @@ static int pairwise_direct(const float* const* rows, int n, int64_t d, double* s
 }  // namespace bm
 
 namespace bm {
-// The default distance pass (BM_PAIR_MODE 0) in TWO launches: the Gram kernel, whose last workgroups also sum the
-// partial matrices, form the squared distances and the accuracy gate's row list (and rank the rows when `rank` is
-// given and the list is empty), then the gated direct kernel, which returns at once unless rows were listed.
-// Round 3: Gram -> reduction + distances -> gated kernel (-> rank): the chain of small dependent launches that a
-// rank of an 8-GPU job spends a third of its time in.
-struct RankRequest {
-  int f, m, mode;
-  int32_t* order;
-  double* scores;
-};
+// The default distance pass (BM_PAIR_MODE 0): the Gram kernel, the reduction of its partial matrices with the
+// squared distances and the accuracy gate's row list (last-arriving workgroup), the gated direct kernel — which
+// returns at once unless rows were listed — and, with `rank`, the ranking of the rows inside that third launch.
 static int pairwise_gram_path(const float* const* rows, int n, int64_t d, int64_t d_total, double* sq_nxn, void* ws,
-                              const RankRequest* rank, hipStream_t s) {
+                              const RankArgs* rank, hipStream_t s) {
   int* flag = static_cast<int*>(ws);  // flag[0] = rows to recompute, flag[1..] = their indices; counters behind them
   double* gram_partial = reinterpret_cast<double*>(static_cast<char*>(ws) + 512);
   double* direct_partial = gram_partial + pair_gram_doubles(n);
   const double tau = tuning().pair_tau;
-  GramTail tail{};
-  tail.gram = gram_partial + gram3_partial_doubles(n);
-  tail.sq = sq_nxn;
-  tail.tau = tau;
-  tail.n_full = n;
-  if (rank != nullptr) {
-    tail.rank = 1;
-    tail.rank_f = rank->f;
-    tail.rank_m = rank->m;
-    tail.rank_mode = rank->mode;
-    tail.order = rank->order;
-    tail.scores = rank->scores;
-  }
   int blocks = 0;
-  int rc = gram3_partials(rows, n, d, d_total, gram_partial, flag, &blocks, s, &tail);
-  if (rc != 0 || tau <= 0.0) return rc;
-  return pairwise_direct(rows, n, d, sq_nxn, direct_partial, flag, s);
+  int rc = gram3_partials(rows, n, d, d_total, gram_partial, flag, &blocks, s);
+  if (rc != 0) return rc;
+  double* gram = gram_partial + gram3_partial_doubles(n);
+  rc = gram_finish(gram_partial, blocks, n, n, gram, sq_nxn, flag, tau, s);
+  if (rc != 0) return rc;
+  if (tau <= 0.0)  // no gate, no third launch: the ranking, if any, is a launch of its own
+    return rank == nullptr ? 0 : bm_krum_rank(sq_nxn, n, rank->f, rank->m, rank->mode, rank->order, rank->scores, s);
+  return pairwise_direct(rows, n, d, sq_nxn, direct_partial, flag, s, rank);
 }
 }  // namespace bm
 
@@ -583,7 +588,7 @@ extern "C" int bm_krum_rank(const double* sq_nxn, int n, int f, int m, int mode,
       (mode != BM_RANK_KRUM && mode != BM_RANK_BULYAN))
     return BM_EINVAL;
   hipLaunchKernelGGL(krum_rank_kernel, dim3(1), dim3(kRankThreads), 0, static_cast<hipStream_t>(stream),
-                     sq_nxn, n, f, m, mode, order_out, scores_out, static_cast<const int*>(nullptr));
+                     sq_nxn, n, f, m, mode, order_out, scores_out);
   BM_LAUNCH_CHECK();
   return 0;
 }
@@ -599,15 +604,8 @@ extern "C" int bm_pairwise_rank(const float* const* rows, int n, int64_t d, int6
     const int rc = bm_pairwise_sqdist_shard(rows, n, d, d_total, sq_nxn, ws, stream);
     return rc != 0 ? rc : bm_krum_rank(sq_nxn, n, f, m, mode, order_out, scores_out, stream);
   }
-  const RankRequest req{f, m, mode, order_out, scores_out};
-  const int rc = pairwise_gram_path(rows, n, d, d_total, sq_nxn, ws, &req, s);
-  if (rc != 0) return rc;
-  // the rows are ranked already unless the gate listed some (the direct kernel has then corrected their distances):
-  // this launch returns at once in the first case
-  hipLaunchKernelGGL(krum_rank_kernel, dim3(1), dim3(kRankThreads), 0, s, sq_nxn, n, f, m, mode, order_out, scores_out,
-                     static_cast<const int*>(static_cast<int*>(ws) + gram_ranked_slot()));
-  BM_LAUNCH_CHECK();
-  return 0;
+  const RankArgs req{1, f, m, mode, order_out, scores_out};
+  return pairwise_gram_path(rows, n, d, d_total, sq_nxn, ws, &req, s);
 }
 
 namespace bm {

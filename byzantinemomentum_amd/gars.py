@@ -62,14 +62,11 @@ class _Scratch:
 
   @classmethod
   def get(cls, device, name, nbytes=None, shape=None, dtype=torch.uint8):
-    """Workspaces are ZEROED when they are created: the distance pass keeps the arrival counters of its in-kernel
-    reductions in the first 512 bytes of its workspace and expects them zero at first use (include/bm_gar.h,
-    bm_pairwise_sqdist); the kernels leave them zero afterwards."""
     key = (device.index, torch.cuda.current_stream(device).cuda_stream, name)
     buf = cls._cache.get(key)
     want = (nbytes,) if shape is None else tuple(shape)
     if buf is None or buf.dtype != dtype or tuple(buf.shape) != want:
-      buf = torch.zeros(want, dtype=dtype, device=device)
+      buf = torch.empty(want, dtype=dtype, device=device)
       cls._cache[key] = buf
     return buf
 

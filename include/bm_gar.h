@@ -69,12 +69,7 @@ int64_t bm_workspace_bytes(int kind, int n, int64_t d);
  * zero diagonal.  Replaces the n(n-1)/2 x (sub, norm, .item()) loop of
  * aggregators/krum.py:41-48, bulyan.py:48-54, brute.py:43-45 (which take sqrt on top).
  * Deterministic: bitwise-equal rows give bitwise-equal distances.
- *
- * WORKSPACE HEADER.  The first 512 bytes of `ws` (here and wherever a workspace of this kind is part of a larger
- * one: bm_pairwise_rank, bm_sharded_krum / _bulyan, bm_step_worker, bm_momentum_stats_sqdist, bm_stack_stats_sqdist)
- * hold the accuracy gate's row list and the arrival counters of the in-kernel reductions.  They must be ZERO before
- * the first call that uses the buffer (one memset when it is allocated); every call leaves the counters zero, so
- * nothing has to be done between calls.  The rest of the workspace needs no initialisation. */
+ */
 int bm_pairwise_sqdist(const float* const* rows, int n, int64_t d,
                        double* sq_nxn, void* ws, void* stream);
 
@@ -98,10 +93,9 @@ int bm_krum_rank(const double* sq_nxn, int n, int f, int m, int mode,
                  int32_t* order_out, double* scores_out, void* stream);
 
 /* bm_pairwise_sqdist_shard + bm_krum_rank as one call for a single GPU (nothing to exchange between the two): the
- * last workgroups of the distance pass sum its partial matrices, form sq_nxn and, unless the accuracy gate listed
- * rows for the exact pass, rank the rows there and then — two launches (plus one that returns at once) instead of
- * four.  Same sq_nxn, order_out, scores_out as the two calls.  ws as bm_pairwise_sqdist (see its note on the
- * workspace header). */
+ * third launch of the distance pass — the gated exact pass, which has nothing to do unless the accuracy gate listed
+ * rows — ranks the rows from the final distances, so the ranking costs no launch of its own.  Same sq_nxn,
+ * order_out, scores_out as the two calls.  ws as bm_pairwise_sqdist. */
 int bm_pairwise_rank(const float* const* rows, int n, int64_t d, int64_t d_total, int f, int m, int mode,
                      double* sq_nxn, int32_t* order_out, double* scores_out, void* ws, void* stream);
 
