@@ -67,9 +67,12 @@ def parse():
   p.add_argument("--no-cpu-baseline", action="store_true")
   p.add_argument("--no-extras", action="store_true", help="N = 1: skip the per_gar measurements of C3/C4/C5")
   p.add_argument("--no-traffic", action="store_true", help="skip the live rocprofv3 FETCH_SIZE/WRITE_SIZE passes")
-  p.add_argument("--separate-rows", action="store_true",
-                 help="allocate every synthetic gradient with its own torch.empty instead of byzantinemomentum_amd."
-                      "layout.alloc_rows (rows of one allocation at a skewed stride): the placement A/B of DESIGN 3")
+  p.add_argument("--slab-rows", action="store_true",
+                 help="cut the rows of every synthetic stack out of ONE allocation at a skewed stride (byzantinemomentum_amd."
+                      "layout.alloc_rows) instead of one torch.empty per gradient.  The default is what a drop-in caller has "
+                      "(attack.py:676,803-804: one tensor per worker, wherever its allocator put it); the slab measured "
+                      "+3 %% on the column kernels in round 3 and is reported as a side entry (per_gar.*_slab_rows).")
+  p.add_argument("--separate-rows", action="store_true", help="(the default since round 4; kept for old command lines)")
   p.add_argument("--sharded-extras", action="store_true",
                  help="one rank under torch.distributed.run: run the per_gar legs of the N > 1 line (sharded Bulyan with "
                       "its all-reduce, all-gather, layout exchange) as well, so that their code is exercised on one GPU")
@@ -113,7 +116,7 @@ def make_stacks(n, f, d, device, count, seed, aliased):
   return stacks
 
 
-SEPARATE_ROWS = False  # --separate-rows: one torch.empty per row instead of byzantinemomentum_amd.layout.alloc_rows
+SEPARATE_ROWS = True  # one torch.empty per row (the drop-in caller's layout); --slab-rows: layout.alloc_rows
 
 
 def new_rows(count, d, device):
@@ -449,7 +452,7 @@ def sharded_extras(bm, agg, dist, device, world, rank, timer, args, rule_name, d
 def main():
   global SEPARATE_ROWS
   args = parse()
-  SEPARATE_ROWS = args.separate_rows
+  SEPARATE_ROWS = not args.slab_rows
   if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
     # `python bench.py --gpus N`: become N ranks, one per GPU (torch.distributed.run, RCCL over xGMI)
     import socket
@@ -663,7 +666,7 @@ def main():
       "dtype": "f32", "data": "synthetic",
       "config": {"workload": workload_name, "n_workers": n, "f": f, "d_total": d_total, "d_per_gpu": d,
                  "byzantine_rows": "aliased" if args.aliased_byz else "distinct buffers",
-                 "row_placement": "one torch.empty per row" if args.separate_rows else
+                 "row_placement": "one torch.empty per row (what a caller of the rules has)" if not args.slab_rows else
                                   "byzantinemomentum_amd.layout.alloc_rows (rows of one allocation, stride = 2 MB multiple + 4352 B) for the C2 / C3 / C4 stacks; one allocation per row for the C5 step",
                  "parallelism": f"dim-shard x{world}" if world > 1 else "single GPU",
                  "collectives": ("none" if not distributed else
@@ -750,10 +753,11 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
         c3_sample = _host_copy(stacks[0])  # the full-size host copy, for the CPU baseline at the very end
       # Brute at the same shape: C(51, 12) = 1.6e11 subsets, which the reference's loop (brute.py:47-68) cannot enumerate;
       # bm_brute_select answers from the threshold graphs of the distances
-      ms_b = timed_loop(lambda i: bm.brute(stacks[i & 1], f), 6, 2, timer, "brute_c3")
+      ms_b = timed_loop(lambda i: bm.brute(stacks[i & 1], f), 12, 3, timer, "brute_c3")
       out["brute_c3"] = entry(ms_b, 4 * d * n + 4 * d * (n - f + 1),
-                              config=f"brute.py:32-80, n={n}, f={f} (1.6e11 subsets: not enumerable; the subset of "
-                                     f"smallest diameter from the device's distances on the host, one synchronisation), d={d}")
+                              config=f"brute.py:32-80, n={n}, f={f} (1.6e11 subsets: not enumerable; the subset of smallest "
+                                     f"diameter searched by one wave on the device, bm_brute_select_device: no host round "
+                                     f"trip), d={d}")
     else:
       if cpu_baseline:
         c4_sample = _host_copy(stacks[0])
@@ -774,10 +778,23 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
                                      f"with the n row distances, then the selected mean")
       ms_c = timed_loop(lambda i: bm.cge(stacks[i & 1], f), 12, 3, timer, "cge_c2")
       out["cge_c2"] = entry(ms_c, 4 * d * n + 4 * d * (n - f + 1), config=f"cge.py:28-57, n={n}, f={f}, d={d}")
-      ms_b = timed_loop(lambda i: bm.brute(stacks[i & 1], f), 6, 2, timer, "brute_n25")
+      ms_b = timed_loop(lambda i: bm.brute(stacks[i & 1], f), 12, 3, timer, "brute_n25")
       out["brute_n25"] = entry(ms_b, 4 * d * n + 4 * d * (n - f + 1),
                                config=f"brute.py:32-80, n={n}, f={f} (the first of the 53 130 subsets of smallest diameter, found "
-                                      f"on the host from the device's distances without enumerating them: one synchronisation), d={d}")
+                                      f"by one wave on the device without enumerating them, bm_brute_select_device: no host "
+                                      f"round trip), d={d}")
+      if "BM_BENCH_CHILD" not in os.environ:
+        # the headline's column rules on the OTHER row placement, same process (what placement is worth)
+        global SEPARATE_ROWS
+        saved, SEPARATE_ROWS = SEPARATE_ROWS, not SEPARATE_ROWS
+        alt = make_stacks(n, f, d, device, 2, 1234, aliased)
+        SEPARATE_ROWS = saved
+        tag = "slab_rows" if saved else "separate_rows"
+        for rule, fn in (("median", lambda st: bm.median(st)), ("trmean", lambda st: bm.trmean(st, f))):
+          ms_alt = timed_loop(lambda i: fn(alt[i & 1]), 20, 3, timer, rule + "_alt")
+          out[f"{rule}_{tag}"] = entry(ms_alt, 4 * d * (n + 1), config=f"{rule}, n={n}, d={d}, rows " + (
+            "cut out of one allocation at a skewed stride (layout.alloc_rows)" if saved else "one torch.empty each"))
+        del alt
     del stacks
     torch.cuda.empty_cache()
   n, f, d = 25, 5, D_WRN
