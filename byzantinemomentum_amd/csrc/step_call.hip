@@ -35,7 +35,9 @@ struct StepScalars {
   float clipf[BM_MAX_ROWS];
 };
 
-__global__ void step_pack_kernel(StepScalars* sc, int has_attack, int has_past, int has_l2) {
+// direct_out: NULL, or stats_out when there is ONE rank — the reduction over the ranks is then the identity and costs
+// no launch of its own (step_reduce_kernel: a NaN maximum stays NaN, a sum of one term is the term)
+__global__ void step_pack_kernel(StepScalars* sc, int has_attack, int has_past, int has_l2, double* __restrict__ direct_out) {
   if (threadIdx.x != 0) return;
   double* m = sc->mine;
   const double* st = sc->study;
@@ -58,6 +60,8 @@ __global__ void step_pack_kernel(StepScalars* sc, int has_attack, int has_past, 
   m[kStatSums + 1] = sc->out6[5];
   m[kStatSums + 2] = st[21];
   m[kStatSums + 3] = has_attack ? st[20] : 0.0;
+  if (direct_out != nullptr)
+    for (int i = 0; i < kStatSlots; ++i) direct_out[i] = m[i];
 }
 
 // stats_out[slot] = sum over ranks in rank order (slots < kStatSums) or NaN-propagating maximum
@@ -208,8 +212,10 @@ extern "C" int bm_step_worker(bm_comm* comm, const bm_step_params* p, const floa
   if (rc != 0) return rc;
 
   // ---- one packed exchange of every scalar ----
-  hipLaunchKernelGGL(step_pack_kernel, dim3(1), dim3(64), 0, s, sc, fr > 0 ? 1 : 0, has_past ? 1 : 0, has_l2 ? 1 : 0);
+  hipLaunchKernelGGL(step_pack_kernel, dim3(1), dim3(64), 0, s, sc, fr > 0 ? 1 : 0, has_past ? 1 : 0, has_l2 ? 1 : 0,
+                     comm == nullptr ? stats_out : static_cast<double*>(nullptr));
   BM_LAUNCH_CHECK();
+  if (comm == nullptr) return 0;
   const int nranks = bm_comm_size(comm);
   if (nranks > BM_MAX_ROWS) return BM_EINVAL;
   const double* gathered = sc->mine;

@@ -338,6 +338,9 @@ __global__ __launch_bounds__(kStudyBurstThreads) void study_stats_burst_kernel(S
 __global__ __launch_bounds__(64) void study_finish_kernel(const double* __restrict__ partial, int nparts,
                                                           double* __restrict__ out) {
   const int slot = blockIdx.x, lane = threadIdx.x;  // slot < kStudyPartial
+  // slots 0..22 are written below on every call (zeros where a term does not apply); the spare ones here — the
+  // hipMemsetAsync this replaces was a launch of its own (5 us of a step)
+  if (slot == 0 && lane >= 23 && lane < BM_STUDY_SLOTS) out[lane] = 0.0;
   double tot = 0.0;
   bool nan = false;
   const bool is_max = slot >= kStudySums;
@@ -462,8 +465,6 @@ extern "C" int bm_study_stats(const float* sampled_avg, const float* honest_avg,
   const void* ptrs[10] = {a.s, a.h, a.def, a.byz, a.past, a.oldest, a.params, a.origin, a.curv, a.a_out};
   const int vec = common_vec_width(ptrs, 10, nullptr);  // null pointers do not constrain the width
   double* partial = static_cast<double*>(ws);
-  hipError_t e = hipMemsetAsync(out, 0, BM_STUDY_SLOTS * sizeof(double), s);
-  if (e != hipSuccess) return hip_code(e);
   int nparts = 0;
   int64_t body = 0;
   int rc = 0;
