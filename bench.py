@@ -733,6 +733,7 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
   """C3, C4 (one GPU) and C5 in a few iterations each: the driver-run record then carries every
   single-GPU configuration of BASELINE.json, not only the headline one."""
   from byzantinemomentum_amd.step import AggregationStep
+  global SEPARATE_ROWS
   out = {}
   d = D_RESNET18
   c3_sample = c4_sample = None
@@ -753,6 +754,16 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
         c3_sample = _host_copy(stacks[0])  # the full-size host copy, for the CPU baseline at the very end
       # Brute at the same shape: C(51, 12) = 1.6e11 subsets, which the reference's loop (brute.py:47-68) cannot enumerate;
       # bm_brute_select answers from the threshold graphs of the distances
+      if "BM_BENCH_CHILD" not in os.environ:  # the same rule on the other row placement
+        saved, SEPARATE_ROWS = SEPARATE_ROWS, not SEPARATE_ROWS
+        alt = make_stacks(n, f, d, device, 2, 4321, aliased)
+        SEPARATE_ROWS = saved
+        ms_alt = timed_loop(lambda i: bm.krum(alt[i & 1], f), 12, 3, timer, "krum_alt")
+        out["krum_c3_" + ("slab_rows" if saved else "separate_rows")] = entry(
+          ms_alt, 4 * d * n + 4 * d * (m + 1), config=f"multi-krum n={n}, f={f}, m={m}, d={d}, rows " + (
+            "cut out of one allocation at a skewed stride (layout.alloc_rows)" if saved else "one torch.empty each"))
+        del alt
+        torch.cuda.empty_cache()
       ms_b = timed_loop(lambda i: bm.brute(stacks[i & 1], f), 12, 3, timer, "brute_c3")
       out["brute_c3"] = entry(ms_b, 4 * d * n + 4 * d * (n - f + 1),
                               config=f"brute.py:32-80, n={n}, f={f} (1.6e11 subsets: not enumerable; the subset of smallest "
@@ -785,15 +796,17 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
                                       f"round trip), d={d}")
       if "BM_BENCH_CHILD" not in os.environ:
         # the headline's column rules on the OTHER row placement, same process (what placement is worth)
-        global SEPARATE_ROWS
         saved, SEPARATE_ROWS = SEPARATE_ROWS, not SEPARATE_ROWS
         alt = make_stacks(n, f, d, device, 2, 1234, aliased)
         SEPARATE_ROWS = saved
         tag = "slab_rows" if saved else "separate_rows"
+        how = "cut out of one allocation at a skewed stride (layout.alloc_rows)" if saved else "one torch.empty each"
         for rule, fn in (("median", lambda st: bm.median(st)), ("trmean", lambda st: bm.trmean(st, f))):
           ms_alt = timed_loop(lambda i: fn(alt[i & 1]), 20, 3, timer, rule + "_alt")
-          out[f"{rule}_{tag}"] = entry(ms_alt, 4 * d * (n + 1), config=f"{rule}, n={n}, d={d}, rows " + (
-            "cut out of one allocation at a skewed stride (layout.alloc_rows)" if saved else "one torch.empty each"))
+          out[f"{rule}_{tag}"] = entry(ms_alt, 4 * d * (n + 1), config=f"{rule}, n={n}, d={d}, rows " + how)
+        ms_alt = timed_loop(lambda i: bm.bulyan(alt[i & 1], f), 12, 3, timer, "bulyan_alt")
+        out[f"bulyan_c4_1gpu_{tag}"] = entry(ms_alt, 4 * d * n + 4 * d * (m + 1),
+                                             config=f"bulyan n={n}, f={f}, m={m}, d={d}, rows " + how)
         del alt
     del stacks
     torch.cuda.empty_cache()
