@@ -329,7 +329,7 @@ def traffic_kernels(d2, d5):
     "krum_c3.distances": ("gram3_partial_kernel<13, 2", 4 * d2 * 51),
     "bulyan_c4_1gpu.pass2": ("bulyan_pass2_kernel<25, 5, 4>", 4 * d2 * 19),  # (not its 2-column tail launch <25, 5, 1>)
     "step_c5.first_pass": ("momentum_gram_kernel", 4 * d5 * 63),  # (Krum step: first pass + distance pass in one kernel)
-    "step_c5.study": ("study_stats_kernel<true, 3, false, 4>", 4 * d5 * 8),
+    "step_c5.study": ("study_stats_burst_kernel<true, 3, false>", 4 * d5 * 8),
   }
 
 
