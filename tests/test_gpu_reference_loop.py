@@ -26,8 +26,9 @@ HEADER_COLUMNS = 24
 ACCEPT = HEADER_COLUMNS - 1  # "Attack acceptation ratio", printed with str()
 
 
-def _run_attack(outdir, gar, device, n, f, attack, attack_args, momentum_at, model="simples-full", dataset="mnist",
-                extra=()):
+def _start_attack(outdir, gar, device, n, f, attack, attack_args, momentum_at, model="simples-full", dataset="mnist",
+                  extra=()):
+  """Launch one run of the unmodified driver; returns (process, command line, result directory)."""
   env = dict(os.environ)
   env["PYTHONPATH"] = os.pathsep.join([ROOT, STUBS] + ([env["PYTHONPATH"]] if env.get("PYTHONPATH") else []))
   cmd = [sys.executable, "-OO", os.path.join(reference_loader.REFERENCE_DIR, "attack.py"),
@@ -36,13 +37,30 @@ def _run_attack(outdir, gar, device, n, f, attack, attack_args, momentum_at, mod
          "--attack-args", *attack_args, "--model", model, "--dataset", dataset, "--momentum-at", momentum_at,
          "--momentum", "0.9", "--evaluation-delta", "0", "--nb-for-study", "1", "--nb-for-study-past", "3",
          "--result-directory", str(outdir), *extra]
-  proc = subprocess.run(cmd, env=env, cwd=str(outdir.parent), capture_output=True, text=True, timeout=600)
-  assert proc.returncode == 0, f"{' '.join(cmd)}\n{proc.stdout[-3000:]}\n{proc.stderr[-3000:]}"
+  outdir.parent.mkdir(parents=True, exist_ok=True)
+  log = open(str(outdir) + ".log", "w")
+  proc = subprocess.Popen(cmd, env=env, cwd=str(outdir.parent), stdout=log, stderr=subprocess.STDOUT, text=True)
+  return proc, cmd, outdir
+
+
+def _finish_attack(started):
+  proc, cmd, outdir = started
+  try:
+    proc.wait(timeout=600)
+  except subprocess.TimeoutExpired:
+    proc.kill()
+    raise
+  tail = open(str(outdir) + ".log").read()[-4000:]
+  assert proc.returncode == 0, f"{' '.join(cmd)}\n{tail}"
   study = (outdir / "study").read_text().splitlines()
   assert study[0].startswith("# Step number") and len(study[0].split("\t")) == HEADER_COLUMNS
   rows = [line.split("\t") for line in study[1:] if line.strip()]
-  assert len(rows) == STEPS and all(len(r) == HEADER_COLUMNS for r in rows), proc.stdout[-2000:]
+  assert len(rows) == STEPS and all(len(r) == HEADER_COLUMNS for r in rows), tail[-2000:]
   return study[0].lstrip("# ").split("\t"), rows
+
+
+def _run_attack(*args, **kwargs):
+  return _finish_attack(_start_attack(*args, **kwargs))
 
 
 def _compare(names, want, got, rtol, accept_exact):
@@ -90,8 +108,11 @@ def test_unmodified_attack_py_with_native_rules(tmp_path, rule, n, f, attack, at
     # (the staged copy is git-ignored: it exists wherever __graft_entry__.build() ran with /root/reference present and
     #  travels with the working-tree snapshot; a bare clone has none)
     pytest.skip("no reference checkout here: scripts/stage_reference.sh (run by build()) stages it into oracle/_ref/")
-  names, want = _run_attack(tmp_path / "reference", rule, "cuda:0", n, f, attack, attack_args, momentum_at)
-  _, got = _run_attack(tmp_path / "native", f"native-{rule}", "cuda:0", n, f, attack, attack_args, momentum_at)
+  # (the two runs side by side: they are independent processes, most of their time is start-up)
+  first = _start_attack(tmp_path / "reference", rule, "cuda:0", n, f, attack, attack_args, momentum_at)
+  second = _start_attack(tmp_path / "native", f"native-{rule}", "cuda:0", n, f, attack, attack_args, momentum_at)
+  names, want = _finish_attack(first)
+  _, got = _finish_attack(second)
   worst = _compare(names, want, got, 1e-5, accept_exact)
   print(f"native-{rule} n={n} f={f} {attack}: worst relative difference over {STEPS} steps x 21 floats = "
         f"{worst[0]:.2e} ({worst[1]})")
