@@ -2,10 +2,10 @@
 // lanes): the body of krum_rank_kernel (pairwise.hip), also run by the last workgroup of the Gram kernel when the
 // accuracy gate lists nothing (gram_bf16.hip), so that a single-GPU Krum / Bulyan needs no rank launch of its own.
 //
-// Replaces the Python score / sort loops of aggregators/krum.py:50-62 and bulyan.py:56-69.  Distances of a row are
-// ranked by counting, then lane i adds the `take` smallest of row i in ascending order in fp64 — the same sequence of
-// additions as the reference's `sum(sorted(...)[:take])` — and the rows are ranked by score, ties to the lower index
-// (Python's stable sort).
+// Replaces the Python score / sort loops of aggregators/krum.py:50-62 and bulyan.py:56-69.  The distances of a row
+// are sorted across the lanes of one wave (bitonic network), then lane i adds the `take` smallest of row i in
+// ascending order in fp64 — the same sequence of additions as the reference's `sum(sorted(...)[:take])` — and the
+// rows are ranked by score, ties to the lower index (Python's stable sort).
 #pragma once
 #include "bm_common.h"
 
@@ -13,13 +13,6 @@ namespace bm {
 
 constexpr int kRankSrtDoubles = BM_MAX_ROWS * (BM_MAX_ROWS + 1);  // srt[i][r] = r-th smallest distance of row i
 constexpr int kRankLdsBytes = (kRankSrtDoubles + BM_MAX_ROWS) * (int)sizeof(double);
-
-__device__ __forceinline__ double rank_readlane_f64(double v, int lane) {
-  const unsigned long long bits = __builtin_bit_cast(unsigned long long, v);
-  const unsigned lo = __builtin_amdgcn_readlane((int)(unsigned)bits, lane);
-  const unsigned hi = __builtin_amdgcn_readlane((int)(unsigned)(bits >> 32), lane);
-  return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
-}
 
 // lds: kRankLdsBytes, 8-byte aligned.  Every lane of the workgroup must call (barriers inside).
 __device__ __forceinline__ void krum_rank_body(const double* __restrict__ sq, int n, int f, int m, int mode,
@@ -30,21 +23,28 @@ __device__ __forceinline__ void krum_rank_body(const double* __restrict__ sq, in
   const double kInf = __builtin_inf();
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int waves = (int)blockDim.x >> 6;
-  // One wave per row (n <= 64): lane j holds dist(i, j) = sqrt in fp64, non-finite -> +inf (krum.py:46-47); its rank
-  // among the row's other distances is counted against every lane's value broadcast from its register (v_readlane).
+  // One wave per row (n <= 64): lane j holds dist(i, j) = sqrt in fp64, non-finite -> +inf (krum.py:46-47), the
+  // row's own lane and the lanes past n hold +inf too; the 64 values are sorted ascending across the lanes by a
+  // bitonic network (21 compare-exchange steps of one cross-lane exchange each, whatever n — counting every value's
+  // rank against n broadcasts, as before, was n^3 / 64 fp64 compares per stack: 2.4 x the instructions at n = 51).
+  // Lanes 0 .. n-2 then hold the row's n - 1 distances in ascending order (equal values in either order: the sums
+  // below do not depend on it).
   for (int i = wave; i < n; i += waves) {
-    const bool mine = lane < n && lane != i;
     double v = kInf;
-    if (mine) {
+    if (lane < n && lane != i) {
       v = sqrt(sq[i * n + lane]);
       if (!(v == v) || v == kInf || v == -kInf) v = kInf;
     }
-    int rank = 0;
-    for (int l = 0; l < n; ++l) {  // wave-uniform
-      const double o = rank_readlane_f64(v, l);
-      rank += (l != i && (o < v || (o == v && l < lane))) ? 1 : 0;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        const double o = __shfl_xor(v, j, 64);
+        const bool keep_min = ((lane & k) == 0) == ((lane & j) == 0);
+        v = keep_min ? __builtin_fmin(v, o) : __builtin_fmax(v, o);
+      }
     }
-    if (mine) srt[i][rank] = v;
+    if (lane < n - 1) srt[i][lane] = v;
   }
   __syncthreads();
   if (tid < n) {
