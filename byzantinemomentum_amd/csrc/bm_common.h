@@ -281,6 +281,7 @@ struct Tuning {
   int study_burst;     // BM_STUDY_BURST: iterations per CU from which bm_study_stats takes its burst form (default 8; 0 = never, 1 = always: tests)
   int step_stagger_us; // BM_STEP_STAGGER_US: start every other workgroup of an XCD this many microseconds late in the fused first pass of a Krum / Bulyan step (0 = off)
   int gram_steady;     // BM_GRAM_STEADY: 1 (default) = the condition-free steady-state loop of the Gram kernel, 0 = the generic loop only (A/B)
+  int bulyan_short;    // BM_BULYAN_SHORT: 1 (default) = Bulyan pass 2 searches its window among the positions that straddle the median only (same bits), 0 = all positions (A/B)
 };
 const Tuning& tuning();
 }  // namespace bm

@@ -26,7 +26,8 @@ constexpr int kBulBlock = 256;
 // n = 15, profiles/r03_c_bulyan_pass2_burst_ab.txt.  It was removed.)
 template <int N, int F, int VEC>
 __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(
-    RowTable rows, const int32_t* __restrict__ order, int64_t nvec, int nt_result, float* __restrict__ out) {
+    RowTable rows, const int32_t* __restrict__ order, int64_t nvec, int nt_result, float* __restrict__ out,
+    int short_window) {
   constexpr int MMAX = N - F - 2;
   constexpr int THETA = N - 2 * F - 2;
   constexpr int BETA = THETA - 2 * F;
@@ -84,18 +85,43 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(
         has_nan |= (sel[i] != sel[i]);
       }
       sort_network<THETA>(sel);
-      const float med = sel[(THETA - 1) / 2];
-      // beta closest to the median: window [s, s+BETA) of the sorted values
-      int s0 = 0;
-#pragma unroll
-      for (int t = 0; t < THETA - BETA; ++t) {
-        const float dl = __builtin_fabsf(sel[t] - med);
-        const float dh = __builtin_fabsf(sel[t + BETA] - med);
-        s0 = (dl > dh) ? (t + 1) : s0;
-      }
+      constexpr int MED = (THETA - 1) / 2;
+      const float med = sel[MED];
+      // beta closest to the median: window [s, s+BETA) of the sorted values, s = 1 + the last t with
+      // |sel[t] - med| > |sel[t+BETA] - med|.  With a FINITE median and no NaN only the t whose window straddles the
+      // median can decide anything that shows in the result: for t + BETA <= MED both values lie at or below the
+      // median, the test is sel[t] < sel[t+BETA], and when such a t is the last one to fire every value from t+1 up to
+      // the median EQUALS the median — the window it selects and the default window [MED-BETA+1, MED] then hold the
+      // same BETA values; for t >= MED the test never fires.  So the short form looks at BETA-1 positions and sums
+      // over 2 BETA - 1 instead of THETA - BETA and THETA (n = 25, f = 5: 2 and 5 instead of 10 and 13): same bits,
+      // a fifth of the kernel's VALU work less.  A wave that holds a column with a non-finite median (or a NaN) takes
+      // the long form for all its columns (wave-uniform branch).
+      const bool odd = has_nan || !(__builtin_fabsf(med) < __builtin_inff());
       float w = 0.0f;
+      if (short_window != 0 && __builtin_amdgcn_ballot_w64(odd) == 0ull) {
+        constexpr int LO = (MED - BETA + 1 > 0) ? MED - BETA + 1 : 0;               // first t whose window reaches the median
+        constexpr int TEND = (MED < THETA - BETA) ? MED : THETA - BETA;             // t >= MED never fires
+        constexpr int IEND = (MED + BETA < THETA) ? MED + BETA : THETA;
+        int s0 = LO;
 #pragma unroll
-      for (int i = 0; i < THETA; ++i) w += (i >= s0 && i < s0 + BETA) ? sel[i] : 0.0f;
+        for (int t = LO; t < TEND; ++t) {
+          const float dl = __builtin_fabsf(sel[t] - med);
+          const float dh = __builtin_fabsf(sel[t + BETA] - med);
+          s0 = (dl > dh) ? (t + 1) : s0;
+        }
+#pragma unroll
+        for (int i = LO; i < IEND; ++i) w += (i >= s0 && i < s0 + BETA) ? sel[i] : 0.0f;
+      } else {
+        int s0 = 0;
+#pragma unroll
+        for (int t = 0; t < THETA - BETA; ++t) {
+          const float dl = __builtin_fabsf(sel[t] - med);
+          const float dh = __builtin_fabsf(sel[t + BETA] - med);
+          s0 = (dl > dh) ? (t + 1) : s0;
+        }
+#pragma unroll
+        for (int i = 0; i < THETA; ++i) w += (i >= s0 && i < s0 + BETA) ? sel[i] : 0.0f;
+      }
       const float res = div_small_int(w, (float)BETA, 1.0f / (float)BETA);
       r[c] = has_nan ? kNaN : res;
     }
@@ -179,14 +205,14 @@ static int launch_bulyan_fast(const float* const* rows_host, const int32_t* orde
       const int64_t nvec = d / 4;
       hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 4 ? 4 : 1)>),
                          dim3(stream_grid(nvec, kBulBlock, kColMaxBlocks)), dim3(kBulBlock), 0,
-                         s, tab, order, nvec, 1, out);
+                         s, tab, order, nvec, 1, out, tuning().bulyan_short);
       BM_LAUNCH_CHECK();
       body = nvec * 4;
     } else if (vec == 2 && kMaxVec >= 2 && d / 2 > 0) {
       const int64_t nvec = d / 2;
       hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 2 ? 2 : 1)>),
                          dim3(stream_grid(nvec, kBulBlock, kColMaxBlocks)), dim3(kBulBlock), 0,
-                         s, tab, order, nvec, 1, out);
+                         s, tab, order, nvec, 1, out, tuning().bulyan_short);
       BM_LAUNCH_CHECK();
       body = nvec * 2;
     }
@@ -196,7 +222,7 @@ static int launch_bulyan_fast(const float* const* rows_host, const int32_t* orde
       const int64_t rest = d - body;
       hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, 1>),
                          dim3(stream_grid(rest, kBulBlock, kColMaxBlocks)), dim3(kBulBlock), 0,
-                         s, tail, order, rest, 1, out + body);
+                         s, tail, order, rest, 1, out + body, tuning().bulyan_short);
       BM_LAUNCH_CHECK();
     }
   }
