@@ -370,7 +370,7 @@ def test_plugin_objects_on_gpu(bm):
 
 # ---------------------------------------------------------------------------- #
 # The simulation step (attack.py:757-878 mirror): every momentum placement, clipping, both attacks,
-# against the independent oracle loop of tests/step_reference.py
+# against the independent oracle loop of oracle/step_oracle.py
 
 STEP_CONFIGS = [
   dict(gar="krum", momentum_at="worker", clip=None, attack="empire", factor=1.1),

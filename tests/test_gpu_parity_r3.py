@@ -3,7 +3,7 @@
 * the STEADY STATE of the study block (attack.py:861-868): the deque of past sampled averages full and its
   oldest entry leaving, over nb_past + 5 iterations, for the single-call step (bm_step_worker), the
   kernel-by-kernel sequence and the other momentum placements, against the independent loop of
-  tests/step_reference.py; and at C5 size against fp64 torch reductions of the deque itself;
+  oracle/step_oracle.py; and at C5 size against fp64 torch reductions of the deque itself;
 * STRUCTURED stacks through the default distance path (krum.py:41-63): rows with few distinct values (constant
   + small noise, sign, int8-quantised, top-1 % sparsified with exact zeros) at the lengths where the two-plane
   split of gram_bf16.hip is in use, every squared distance within 1e-5 of fp64 direct differences;
@@ -567,7 +567,7 @@ def explained(got, value, tie, scale, tol=4e-6):
 def test_step_with_the_rule_fed_from_the_first_pass(bm, gar, f):
   """n = 25, f = 5 or 11, d = 4 300 802 (the fused kernels run: 20 / 14 honest workers, long enough for the burst form, a
   two-column tail): the single-call step and the kernel-by-kernel sequence give the same bits, and both match the
-  independent loop of tests/step_reference.py (oracle arithmetic on the CPU) over two steps (the second with a
+  independent loop of oracle/step_oracle.py (oracle arithmetic on the CPU) over two steps (the second with a
   non-zero momentum buffer and a past average)."""
   from byzantinemomentum_amd.step import AggregationStep
   from tests.step_reference import ReferenceLoop, assert_floats_close
@@ -612,7 +612,7 @@ def test_step_with_the_rule_fed_from_the_first_pass(bm, gar, f):
 def test_update_placement_with_the_rule_fed_from_the_statistics_pass(bm, gar, f):
   """`--momentum-at update` (the reference's default), n = 25, d = 4 300 800: the rule (or its distance pass) rides along
   with the pass that forms the statistics and the Byzantine vector of the sampled stack; two steps against the independent
-  loop of tests/step_reference.py, and the fused entry points against the stand-alone kernels."""
+  loop of oracle/step_oracle.py, and the fused entry points against the stand-alone kernels."""
   from byzantinemomentum_amd.step import AggregationStep
   from tests.step_reference import ReferenceLoop, assert_floats_close
   n, d = 25, 4300800

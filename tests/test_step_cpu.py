@@ -1,5 +1,5 @@
 """Host logic of byzantinemomentum_amd.step.AggregationStep on CPU: every momentum placement, clipping,
-both attacks and several rules against the independent loop of tests/step_reference.py, with the
+both attacks and several rules against the independent loop of oracle/step_oracle.py, with the
 oracle-backed compute legs; then the same step dim-sharded over two gloo ranks against one rank."""
 
 import math
