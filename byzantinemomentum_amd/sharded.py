@@ -231,22 +231,33 @@ class ShardedAggregator:
           raise RuntimeError(f"libbm_gar RCCL communicator unavailable on at least one rank ({failure})")
         warnings.warn(f"libbm_gar RCCL communicator unavailable ({failure}); using torch.distributed collectives")
         self.single_call = False
-    self._totals = {}
+    self._total = None        # (length of the whole vectors, this rank's shard length when it was determined)
 
   def total_length(self, d_local, d_total=None):
     """Length of the WHOLE vectors (all shards), the number every rank must hand to the distance pass so that a
-    short or empty trailing shard plans it exactly like its peers (bm_gar.h, bm_sharded_krum).  Stated by the caller
-    (`d_total`) or, once per local length, summed over the ranks (one tiny all-reduce; every rank must then make its
-    first call with a new shard length at the same point, which a dim-sharded job does by construction)."""
+    short or empty trailing shard plans it exactly like its peers (bm_gar.h, bm_sharded_krum).
+
+    Stated by the caller (`d_total`), or determined ONCE per aggregator: the first call sums the shard lengths over
+    the ranks (one tiny all-reduce, which every rank enters because every rank makes its first call), later calls
+    return that number without any communication.  An aggregator therefore serves ONE vector length; a rank that
+    notices another shard length raises instead of guessing — deciding locally whether to repeat the collective could
+    leave ranks whose shard length did not change outside of it (a hang).  For another length pass `d_total`, call
+    `reset_total_length()` on every rank, or use another aggregator."""
     if d_total is not None:
       return int(d_total)
     if not self.collective:
       return int(d_local)
-    total = self._totals.get(d_local)
-    if total is None:
-      total = int(self.backend.sum_over_ranks(self, int(d_local)))
-      self._totals[d_local] = total
-    return total
+    if self._total is None:
+      self._total = (int(self.backend.sum_over_ranks(self, int(d_local))), int(d_local))
+    elif self._total[1] != int(d_local):
+      raise ValueError(f"this ShardedAggregator determined the total length {self._total[0]} from shards of "
+                       f"{self._total[1]} coordinates and is now given a shard of {d_local}: pass d_total=, or call "
+                       f"reset_total_length() on every rank")
+    return self._total[0]
+
+  def reset_total_length(self):
+    """Forget the total length (collective-free; the next distance pass determines it again, on every rank)."""
+    self._total = None
 
   def _create_native(self, group):
     """The library's own communicator, on EVERY rank or on none: a rank that fell back alone would issue

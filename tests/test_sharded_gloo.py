@@ -49,6 +49,16 @@ def _worker(rank, world, port, queue):
     res["sq"] = agg.global_sqdist(local)
     # every distance pass of every rank was handed the TRUE total length (not d_local x ranks: the last shard is short)
     res["totals_ok"] = bool(agg.backend.totals_seen) and all(t == D for t in agg.backend.totals_seen)
+    # the total is determined once per aggregator; another shard length is refused locally (never a lone collective),
+    # an explicit d_total or a reset on every rank serves another vector length
+    try:
+      agg.total_length((hi - lo) + 64)
+      res["refuses_other_length"] = False
+    except ValueError:
+      res["refuses_other_length"] = True
+    res["explicit_total"] = agg.total_length((hi - lo) + 64, d_total=D + 128)
+    agg.reset_total_length()
+    res["total_after_reset"] = agg.total_length(hi - lo)
     # numpy arrays are pickled by value; torch tensors would be shared through file descriptors of
     # this process, which may already have exited when the parent rebuilds them
     queue.put((rank, {k: (v.detach().numpy().copy() if torch.is_tensor(v) else v) for k, v in res.items()}))
@@ -91,6 +101,9 @@ def test_two_rank_sharded_aggregation_matches_single_process():
     assert torch.allclose(got["sq"], d64, rtol=1e-12)
   assert torch.equal(results[0]["sq"], results[1]["sq"])   # every rank ranks the same bits
   assert results[0]["totals_ok"] and results[1]["totals_ok"]
+  for r in range(world):
+    assert results[r]["refuses_other_length"] and results[r]["explicit_total"] == D + 128
+    assert results[r]["total_after_reset"] == D
 
 
 def _a2a_worker(rank, world, port, n, d, queue):
