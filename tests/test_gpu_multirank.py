@@ -12,7 +12,6 @@ tests, against the oracle.  SURVEY.md §8e; BASELINE.json configs[3], configs[4]
 
 import math
 import os
-import socket
 
 import pytest
 import torch
@@ -25,12 +24,6 @@ pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
 N, F = 25, 5
-
-
-def _free_port():
-  with socket.socket() as s:
-    s.bind(("127.0.0.1", 0))
-    return s.getsockname()[1]
 
 
 def _staged_aggregator():
@@ -77,11 +70,23 @@ def _close(a, b, tol, what):
   assert err <= tol * scale, (what, err, scale)
 
 
-def _worker(rank, world, port, d, queue):
+def _worker(rank, world, rendezvous, d, queue):
+  """Everything a rank does; whatever goes wrong travels to the parent as text (a bare exit code explains nothing)."""
+  import traceback
+  try:
+    _rank_body(rank, world, rendezvous, d, queue)
+  except BaseException:  # noqa: BLE001
+    queue.put((rank, {"error": traceback.format_exc()}))
+    raise
+
+
+def _rank_body(rank, world, rendezvous, d, queue):
   import datetime
-  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-  # (a short timeout: a rank that fails an assertion leaves its peers in a collective; they must not wait for long)
-  dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=180))
+  os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")  # the box's hostname may not resolve: loopback, explicitly
+  # file rendezvous (no port to lose a race for); a short timeout: a rank that fails an assertion leaves its peers in a
+  # collective, they must not wait for long
+  dist.init_process_group("gloo", init_method=f"file://{rendezvous}", rank=rank, world_size=world,
+                          timeout=datetime.timedelta(seconds=180))
   try:
     torch.cuda.set_device(0)
     import byzantinemomentum_amd as bm
@@ -174,10 +179,11 @@ def test_multi_rank_sharded_path_on_the_hip_kernels(world, d):
   kernels' tail paths); world 3, d = 130: shards of 64, 64 and 2 coordinates; world 4, d = 300: 128, 128, 44 and an
   EMPTY one; world 4, d = 2^20: the length at which the distance pass changes its split plan — every rank must plan
   from the total, not from its 262 144 coordinates."""
+  import tempfile
   ctx = mp.get_context("spawn")
   queue = ctx.Queue()
-  port = _free_port()
-  procs = [ctx.Process(target=_worker, args=(r, world, port, d, queue)) for r in range(world)]
+  rendezvous = os.path.join(tempfile.mkdtemp(prefix="bm_multirank_"), "store")
+  procs = [ctx.Process(target=_worker, args=(r, world, rendezvous, d, queue)) for r in range(world)]
   for p in procs:
     p.start()
   import queue as queue_mod
@@ -198,6 +204,8 @@ def test_multi_rank_sharded_path_on_the_hip_kernels(world, d):
       if p.is_alive():
         p.terminate()
         p.join(timeout=10)
+  errors = {r: rep["error"] for r, rep in results.items() if "error" in rep}
+  assert not errors, "\n".join(f"--- rank {r} ---\n{text}" for r, text in sorted(errors.items()))
   assert len(results) == world and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
   # every rank decoded the same floats from the same packed exchange
   keys = [k for k in results[0] if k != "shard"]
