@@ -277,3 +277,126 @@ def test_graphed_call_needs_a_gpu():
     pytest.skip("GPU present: covered by tests/test_gpu_parity_r3.py")
   with pytest.raises(RuntimeError, match="HIP graphs"):
     bm.graphs.GraphedCall(lambda: None)
+
+
+# ---------------------------------------------------------------------------- #
+# The device form of the Brute search (csrc/brute.hip), step by step in Python
+
+def _device_brute_emulation(sq, n, f):
+  """The control flow of brute_select_kernel with Python integers for the 64-bit row sets: threshold graphs,
+  the search tree with its reduction rule (rows with more non-neighbours than removals left all go at once) and its
+  branching rule (most non-neighbours, lowest index), the quickselect-style bisection (pivot = the middle open candidate
+  of the middle row that still has one), the lexicographically first subset.  Returns (selection or None, probes)."""
+  k = n - f
+  fin = lambda v: abs(v) < math.inf  # noqa: E731
+  dist = [[0.0] * n for _ in range(n)]
+  for i in range(n):
+    for j in range(n):
+      if i != j:
+        v = sq[min(i, j)][max(i, j)]
+        dist[i][j] = math.sqrt(v) if (v == v and v != math.inf and v >= 0) else (v if v == v else math.nan)
+
+  def build(t):
+    return [sum(1 << j for j in range(n) if j != i and fin(dist[i][j]) and dist[i][j] <= t) for i in range(n)] + [0] * (64 - n)
+
+  def has_clique(adj, cand, need):
+    stack, have = [], True
+    while True:
+      if not have:
+        if not stack:
+          return False
+        cand = stack.pop()
+      have = False
+      count = bin(cand).count("1")
+      if count < need:
+        continue
+      if need <= 1:
+        return True
+      missing = [bin(cand & ~adj[l] & ~(1 << l)).count("1") if cand >> l & 1 else 0 for l in range(64)]
+      if not any(m > 0 for m in missing):
+        return True
+      budget = count - need
+      if budget == 0:
+        continue
+      forced = sum(1 << l for l in range(64) if missing[l] > budget)
+      if forced:
+        cand &= ~forced
+        have = True
+        continue
+      worst = max(range(64), key=lambda l: (missing[l], -l))
+      if missing[worst] <= budget:
+        stack.append(cand & ~(1 << worst))
+        cand &= adj[worst] | (1 << worst)
+      else:
+        cand &= ~(1 << worst)
+      have = True
+
+  everyone = (1 << n) - 1
+  vmax = max([dist[i][j] for i in range(n) for j in range(i + 1, n) if fin(dist[i][j])] + [0.0])
+  if not has_clique(build(vmax), everyone, k):
+    return None, 0
+  lo, hi, probes = -1.0, vmax, 0
+  if has_clique(build(0.0), everyone, k):
+    hi = 0.0
+  else:
+    lo = 0.0
+    while True:
+      per = [[dist[i][j] for j in range(i + 1, n) if fin(dist[i][j]) and lo < dist[i][j] < hi] for i in range(n)]
+      holders = [i for i in range(n) if per[i]]
+      if not holders:
+        break
+      src = holders[len(holders) // 2]
+      pivot = per[src][len(per[src]) // 2]
+      probes += 1
+      if has_clique(build(pivot), everyone, k):
+        hi = pivot
+      else:
+        lo = pivot
+  adj = build(hi)
+  cand, sel = everyone, []
+  for c in range(n):
+    if len(sel) >= k:
+      break
+    if not cand >> c & 1:
+      continue
+    nxt = cand & adj[c] & ~((1 << (c + 1)) - 1)
+    if has_clique(adj, nxt, k - len(sel) - 1):
+      sel.append(c)
+      cand = nxt
+  return (sel if len(sel) == k else None), probes
+
+
+def test_device_brute_algorithm_equals_the_host_search():
+  """The algorithm of the device kernel (emulated) against bm_brute_select — itself pinned on exhaustive enumeration
+  above — on random matrices, matrices of few distinct values, clusters with aliased rows, rows at non-finite distance
+  and the case without any finite subset.  (The kernel itself is compared with the host search on the same 88
+  matrices on the GPU, tests/test_gpu_parity_r4.py.)"""
+  from byzantinemomentum_amd import gars
+  gen = torch.Generator().manual_seed(7)
+  worst = 0
+  for n, f in ((4, 1), (7, 2), (11, 2), (11, 4), (25, 5), (25, 11), (33, 8), (51, 12), (64, 20), (64, 1), (9, 0)):
+    for variant in range(8):
+      if variant % 4 == 0:
+        pts = torch.randn(n, 6, generator=gen, dtype=torch.float64)
+      elif variant % 4 == 1:
+        pts = torch.randint(0, 3, (n, 4), generator=gen).double()
+      elif variant % 4 == 2:
+        pts = torch.randn(n, 5, generator=gen, dtype=torch.float64)
+        pts[: n - f] *= 0.01
+        pts[-1] = pts[-2]
+      else:
+        pts = torch.rand(n, 3, generator=gen, dtype=torch.float64).round(decimals=1)
+      sq = (pts[:, None, :] - pts[None, :, :]).pow(2).sum(dim=2)
+      if variant >= 4 and f >= 1:
+        for r in range(min(f, 2) if variant < 6 else f + 1):
+          row = (3 * r + 1) % n
+          sq[row, :] = math.nan if r % 2 == 0 else math.inf
+          sq[:, row] = sq[row, :]
+      try:
+        want = gars.brute_select_host(sq.sqrt().contiguous(), n, f)
+      except RuntimeError:
+        want = None
+      got, probes = _device_brute_emulation(sq.tolist(), n, f)
+      assert got == want, (n, f, variant, got, want)
+      worst = max(worst, probes)
+  assert worst <= 24  # the bisection stays logarithmic on these inputs (2 016 candidates at n = 64)
