@@ -179,6 +179,8 @@ def _rank_body(rank, world, rendezvous, d, queue):
 def _run_ranks(world, d):
   """One attempt: spawn the ranks, collect their reports.  Returns (reports by rank, exit codes)."""
   import tempfile
+  import time
+  time.sleep(2.0)  # (let the processes of a previous case finish tearing down their device contexts)
   ctx = mp.get_context("spawn")
   queue = ctx.Queue()
   rendezvous = os.path.join(tempfile.mkdtemp(prefix="bm_multirank_"), "store")
@@ -186,7 +188,6 @@ def _run_ranks(world, d):
   for p in procs:
     p.start()
   import queue as queue_mod
-  import time
   results = {}
   deadline = time.time() + 800
   try:
