@@ -93,3 +93,31 @@ def test_new_entry_points_validate_arguments_without_gpu(lib):
   assert lib.bm_pairwise_sqdist_shard(rows, 3, 10, 5, None, None, None) == _lib.EINVAL  # d_total < d
   assert lib.bm_workspace_bytes(_lib.WS_STUDY, 1, 1000) > 0
   assert b"RCCL" in lib.bm_error_string(_lib.ENOCOMM) and b"RCCL" in lib.bm_error_string(_lib.ECOMM)
+
+
+def test_round4_entry_points_validate_arguments_without_gpu(lib):
+  """bm_brute_select_device, bm_colwise_eval, bm_pairwise_rank: bad arguments are refused before any HIP call."""
+  from byzantinemomentum_amd import _lib
+  rows = (ctypes.c_void_p * 64)()
+  buf = (ctypes.c_double * 8)()
+  # the device Brute search: n within 1..64, 0 <= f < n, non-NULL buffers
+  assert lib.bm_brute_select_device(None, 25, 5, rows, rows, None) == _lib.EINVAL
+  assert lib.bm_brute_select_device(buf, 0, 0, rows, rows, None) == _lib.EINVAL
+  assert lib.bm_brute_select_device(buf, 65, 5, rows, rows, None) == _lib.EINVAL
+  assert lib.bm_brute_select_device(buf, 25, 25, rows, rows, None) == _lib.EINVAL
+  assert lib.bm_brute_select_device(buf, 25, 5, rows, None, None) == _lib.EINVAL
+  # the evaluate-only search: instances for the trimmed mean / phocas / meamed at n = 11, 25, 51 only
+  assert lib.bm_colwise_eval_supported(_lib.OP_TRMEAN, 25) == 1 and lib.bm_colwise_eval_supported(_lib.OP_MEAMED, 51) == 1
+  assert lib.bm_colwise_eval_supported(_lib.OP_PHOCAS, 11) == 1
+  assert lib.bm_colwise_eval_supported(_lib.OP_MEDIAN, 25) == 0 and lib.bm_colwise_eval_supported(_lib.OP_TRMEAN, 24) == 0
+  assert lib.bm_colwise_eval_workspace_bytes() >= 2 * 8
+  args = (rows, 20, 5, 1000, 5, rows, rows, ctypes.c_float(1.0), rows, rows, None)
+  assert lib.bm_colwise_eval(_lib.OP_MEDIAN, *args) == _lib.EINVAL            # no such instance
+  assert lib.bm_colwise_eval(_lib.OP_TRMEAN, rows, 19, 5, *args[3:]) == _lib.EINVAL   # n = 24
+  assert lib.bm_colwise_eval(_lib.OP_TRMEAN, rows, 20, 0, *args[3:]) == _lib.EINVAL   # no Byzantine copy
+  assert lib.bm_colwise_eval(_lib.OP_TRMEAN, rows, 20, 5, 1000, 13, *args[5:]) == _lib.EINVAL  # n < 2 f + 1
+  assert lib.bm_colwise_eval(_lib.OP_TRMEAN, rows, 20, 5, 1000, 5, None, rows, ctypes.c_float(1.0), rows, rows, None) == _lib.EINVAL
+  # distances + ranking in one call
+  assert lib.bm_pairwise_rank(rows, 25, 1000, 999, 5, 18, _lib.RANK_KRUM, rows, rows, None, rows, None) == _lib.EINVAL  # d_total < d
+  assert lib.bm_pairwise_rank(rows, 25, 1000, 1000, 5, 18, 7, rows, rows, None, rows, None) == _lib.EINVAL            # mode
+  assert lib.bm_pairwise_rank(rows, 25, 1000, 1000, 5, 18, _lib.RANK_KRUM, rows, None, None, rows, None) == _lib.EINVAL  # no order
