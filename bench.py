@@ -76,6 +76,10 @@ def parse():
   p.add_argument("--sharded-extras", action="store_true",
                  help="one rank under torch.distributed.run: run the per_gar legs of the N > 1 line (sharded Bulyan with "
                       "its all-reduce, all-gather, layout exchange) as well, so that their code is exercised on one GPU")
+  p.add_argument("--extras-timeout", type=float, default=240.0,
+                 help="N > 1: seconds the exchange legs that follow the timed headline (the library's own RCCL communicator, the "
+                      "sharded rule, all-gather, layout exchange) may take on every rank before the line is printed without them "
+                      "(`exchange.error`) and the job ends: a hang there must not cost the headline (0 = no limit)")
   p.add_argument("--graph-replay", action="store_true",
                  help="N > 1 (or one rank under torch.distributed.run): also time the sharded rule recorded into a HIP "
                       "graph, one graph per synthetic stack (byzantinemomentum_amd/graphs.py) -> per_gar.<rule>_graph_replay")
@@ -335,16 +339,24 @@ def traffic_kernels(d2, d5):
 
 # ---------------------------------------------------------------------------- #
 
-def sharded_extras(bm, agg, dist, device, world, rank, timer, args, rule_name, d_total, extra, time_rule):
+def sharded_extras(bm, agg, dist, device, world, rank, timer, args, rule_name, d_total, extra, time_rule, out):
   """The dim-sharded path with its one real exchange, on a FIXED vector of d_total coordinates split across the ranks by
   shard_bounds (strong scaling): the rule in one C call with the all-reduce of the n x n fp64 partials inside
   (BASELINE.json configs[3] for Bulyan), the optional all-gather of the output, the worker-parallel layout exchange, and
   the unsharded rule on rank 0 alone for the speed-up of this exact workload.  Every figure is the max over the ranks.
-  Returns per_gar entries; `extra` receives single_gpu_same_workload."""
+  The per_gar entries go into `out` and the top-level `exchange` object into `extra` leg by leg, so that a deadline that
+  fires in a later leg keeps what the earlier ones measured; `extra` also receives single_gpu_same_workload."""
   from byzantinemomentum_amd.sharded import owned_workers, shard_bounds
-  out = {}
   n, f = (51, 12) if rule_name == "krum" else (25, 5)
   m = n - f - 2
+  # the path's one real exchange, at the top level of the line (a SCALE record then carries it, not only the
+  # embarrassingly parallel headline): BASELINE.json configs[3] for Bulyan — strong scaling of a fixed d
+  exchange = extra["exchange"] = {
+    "workload": f"{rule_name} n={n} f={f}, total d={d_total} dim-sharded over {world} ranks (strong scaling), one all-reduce "
+                f"of the {n}x{n} fp64 squared-distance partials inside the call",
+    "ms": None, "agg_per_s": None, "allreduce_us": None, "allreduce_bytes": 8 * n * n, "allgather_output_ms": None,
+    "layout_exchange_ms": None, "single_gpu_ms": None, "speedup_vs_1gpu": None,
+    "collectives": "libbm_gar's own RCCL communicator" if agg.native is not None else "torch.distributed (RCCL)"}
   lo, hi = shard_bounds(d_total, world, rank)
   stacks = make_stacks(n, f, hi - lo, device, 2, 4321 + rank, args.aliased_byz)
   rule = agg.krum if rule_name == "krum" else agg.bulyan
@@ -372,6 +384,7 @@ def sharded_extras(bm, agg, dist, device, world, rank, timer, args, rule_name, d
       ms, rule_bytes, gpus=world, config=f"{rule_name}, one C call per aggregation with the all-reduce of the {n}x{n} fp64 partial "
                                          f"matrix inside ({'libbm_gar RCCL communicator' if agg.native is not None else 'torch.distributed'}), "
                                          f"{tag}; wall clock of {args.steps} calls between barriers", scaling="strong")
+    exchange["ms"], exchange["agg_per_s"] = ms, 1e3 / ms
   result = rule(stacks[0], f)
   # the exchange itself: the n x n fp64 matrix through the same collective the rule uses (latency-bound: 5 KB)
   probe = torch.zeros((n, n), dtype=torch.float64, device=device)
@@ -382,7 +395,9 @@ def sharded_extras(bm, agg, dist, device, world, rank, timer, args, rule_name, d
   else:
     reduce_once = lambda i: agg.all_reduce_sum(probe)  # noqa: E731
   us_ar = over_ranks(timed_loop(reduce_once, 50, 5, timer, "x_allreduce")) * 1e3
+  exchange["allreduce_us"] = us_ar
   ms3 = over_ranks(timed_loop(lambda i: agg.all_gather_output(result, d_total), 10, 2, timer, "x_allgather"))
+  exchange["allgather_output_ms"] = ms3
   out["allgather_output"] = entry(ms3, 4 * d_total, gpus=world, config=f"all-gather of the output slices, {tag}")
   if args.graph_replay:
     # the launch-bound regime: the whole aggregation — kernels and the all-reduce — as ONE graph launch.
@@ -406,23 +421,6 @@ def sharded_extras(bm, agg, dist, device, world, rank, timer, args, rule_name, d
     del graphs
   del stacks, result
   torch.cuda.empty_cache()
-  # worker-parallel production (SURVEY 8e/f4): every rank holds the FULL-length gradients of its own workers
-  # (rank p runs workers p, p + P, ...); ONE all-to-all turns worker-major into dimension-major, then the rule
-  mine = owned_workers(n, world, rank)
-  gen = torch.Generator(device=device).manual_seed(999 + rank)
-  produced = new_rows(max(len(mine), 1), d_total, device)[:len(mine)]
-  for r in produced:
-    r.copy_(0.1 * torch.randn(d_total, device=device, generator=gen))
-  ms_a2a = over_ranks(timed_loop(lambda i: agg.to_dim_sharded(produced, n, d_total), 8, 2, timer, "x_a2a"))
-  ms_wp = over_ranks(timed_loop(lambda i: rule(agg.to_dim_sharded(produced, n, d_total), f), 8, 2, timer, "x_wp"))
-  sent = 4 * d_total * len(owned_workers(n, world, 0)) * (world - 1) // world
-  for key, val in (("layout_exchange", ms_a2a), (rule_name + "_from_worker_parallel", ms_wp)):
-    out[key] = dict(entry(val, 4 * d_total * n + (4 * d_total * (m + 1) if key != "layout_exchange" else 0), gpus=world,
-                          config=f"worker-major -> dimension-major by one all-to-all (RCCL), {tag}"
-                                 + ("" if key == "layout_exchange" else f", then {rule_name}")),
-                    bytes_sent_per_rank=sent)
-  del produced
-  torch.cuda.empty_cache()
   single = None
   if rank == 0:
     full = make_stacks(n, f, d_total, device, 2, 4321, args.aliased_byz)
@@ -434,19 +432,92 @@ def sharded_extras(bm, agg, dist, device, world, rank, timer, args, rule_name, d
   if rank == 0:
     extra["single_gpu_same_workload"] = {"value": 1e3 / single, "unit": "agg/s", "ms": single,
                                          "note": f"the unsharded {rule_name} on rank 0 alone, same total d = {d_total}"}
-    # the path's one real exchange, at the top level of the line (a SCALE record then carries it, not only the
-    # embarrassingly parallel headline): BASELINE.json configs[3] for Bulyan — strong scaling of a fixed d
-    key = f"{rule_name}_{'c3' if rule_name == 'krum' else 'c4'}_sharded"
-    sharded_ms = out[key]["avg_ms"] if key in out else None
-    extra["exchange"] = {
-      "workload": f"{rule_name} n={n} f={f}, total d={d_total} dim-sharded over {world} ranks (strong scaling), one all-reduce "
-                  f"of the {n}x{n} fp64 squared-distance partials inside the call",
-      "ms": sharded_ms, "agg_per_s": None if sharded_ms is None else 1e3 / sharded_ms,
-      "allreduce_us": us_ar, "allreduce_bytes": 8 * n * n,
-      "allgather_output_ms": ms3, "layout_exchange_ms": ms_a2a,
-      "single_gpu_ms": single, "speedup_vs_1gpu": None if sharded_ms is None else single / sharded_ms,
-      "collectives": "libbm_gar's own RCCL communicator" if agg.native is not None else "torch.distributed (RCCL)"}
+    exchange["single_gpu_ms"] = single
+    if exchange["ms"] is not None:
+      exchange["speedup_vs_1gpu"] = single / exchange["ms"]
+  # worker-parallel production (SURVEY 8e/f4): every rank holds the FULL-length gradients of its own workers
+  # (rank p runs workers p, p + P, ...); ONE all-to-all turns worker-major into dimension-major, then the rule
+  mine = owned_workers(n, world, rank)
+  gen = torch.Generator(device=device).manual_seed(999 + rank)
+  produced = new_rows(max(len(mine), 1), d_total, device)[:len(mine)]
+  for r in produced:
+    r.copy_(0.1 * torch.randn(d_total, device=device, generator=gen))
+  ms_a2a = over_ranks(timed_loop(lambda i: agg.to_dim_sharded(produced, n, d_total), 8, 2, timer, "x_a2a"))
+  exchange["layout_exchange_ms"] = ms_a2a
+  ms_wp = over_ranks(timed_loop(lambda i: rule(agg.to_dim_sharded(produced, n, d_total), f), 8, 2, timer, "x_wp"))
+  sent = 4 * d_total * len(owned_workers(n, world, 0)) * (world - 1) // world
+  for key, val in (("layout_exchange", ms_a2a), (rule_name + "_from_worker_parallel", ms_wp)):
+    out[key] = dict(entry(val, 4 * d_total * n + (4 * d_total * (m + 1) if key != "layout_exchange" else 0), gpus=world,
+                          config=f"worker-major -> dimension-major by one all-to-all (RCCL), {tag}"
+                                 + ("" if key == "layout_exchange" else f", then {rule_name}")),
+                    bytes_sent_per_rank=sent)
+  del produced
+  torch.cuda.empty_cache()
   return out
+
+
+def make_aggregator(bm, dist, device, world, rank, distributed):
+  """The sharded aggregator of this job.  With more than one rank (or one rank under torch.distributed.run) the HIP
+  backend gets the library's own RCCL communicator, which must work on EVERY rank or be left by every rank together (a
+  rank falling back alone would issue different collectives): one tiny all-reduce through it, then a vote."""
+  from byzantinemomentum_amd.sharded import ShardedAggregator
+  agg = ShardedAggregator(force_collectives=distributed)
+  if distributed and agg.native is not None:
+    ok = 1.0
+    try:
+      probe = torch.ones(4, dtype=torch.float64, device=device)
+      bm._lib.check(bm._lib.load().bm_allreduce_sum_f64(agg.native.handle, probe.data_ptr(), 4,
+                                                         torch.cuda.current_stream().cuda_stream), "bm_allreduce_sum_f64")
+      torch.cuda.synchronize()
+      ok = 1.0 if float(probe[0].item()) == float(world) else 0.0
+    except Exception as err:  # noqa: BLE001
+      print(f"[bench rank {rank}] native communicator failed its probe: {err}", file=sys.stderr)
+      ok = 0.0
+    vote = torch.tensor([ok], dtype=torch.float64, device=device)
+    dist.all_reduce(vote, op=dist.ReduceOp.MIN)
+    if vote.item() < 1.0:
+      agg = ShardedAggregator(force_collectives=distributed, native_comm=False)
+  return agg
+
+
+class Deadline:
+  """A limit on a leg that must not cost the line: when `seconds` pass before `cancel()`, `emit()` runs (rank 0
+  prints what it has) and the process ends at once with status 0 — on every rank at about the same moment (they arm
+  their deadlines right after a barrier), so that no rank waits in a collective for peers that left.  A thread, not a
+  signal: a rank stuck inside RCCL or a ctypes call runs no Python signal handler, but both release the GIL."""
+
+  def __init__(self, seconds, emit):
+    import threading
+    self.lock = threading.Lock()
+    self.done = False
+    self.emit = emit
+    self.timer = None
+    if seconds and seconds > 0:
+      self.timer = threading.Timer(seconds, self._expire)
+      self.timer.daemon = True
+      self.timer.start()
+
+  def _expire(self):
+    with self.lock:
+      if self.done:
+        return
+      self.done = True
+      try:
+        self.emit()
+        sys.stdout.flush()
+        sys.stderr.flush()
+      finally:
+        os._exit(0)
+
+  def cancel(self):
+    """True when the caller may go on and print the line itself (the deadline did not fire)."""
+    with self.lock:
+      if self.done:
+        return False
+      self.done = True
+    if self.timer is not None:
+      self.timer.cancel()
+    return True
 
 
 def main():
@@ -498,24 +569,9 @@ def main():
     d_total = base_d
     lo, hi = shard_bounds(d_total, world, rank)
     d = hi - lo  # this rank's coordinates
-  agg = ShardedAggregator(force_collectives=distributed)
-  if distributed and agg.native is not None:
-    # the library's own RCCL communicator must work on EVERY rank, or every rank leaves it together (a rank
-    # falling back alone would issue different collectives): one tiny all-reduce through it, then a vote
-    ok = 1.0
-    try:
-      probe = torch.ones(4, dtype=torch.float64, device=device)
-      bm._lib.check(bm._lib.load().bm_allreduce_sum_f64(agg.native.handle, probe.data_ptr(), 4,
-                                                         torch.cuda.current_stream().cuda_stream), "bm_allreduce_sum_f64")
-      torch.cuda.synchronize()
-      ok = 1.0 if float(probe[0].item()) == float(world) else 0.0
-    except Exception as err:  # noqa: BLE001
-      print(f"[bench rank {rank}] native communicator failed its probe: {err}", file=sys.stderr)
-      ok = 0.0
-    vote = torch.tensor([ok], dtype=torch.float64, device=device)
-    dist.all_reduce(vote, op=dist.ReduceOp.MIN)
-    if vote.item() < 1.0:
-      agg = ShardedAggregator(force_collectives=distributed, native_comm=False)
+  # colwise (the default) has no exchange step: its aggregator — with the library's own RCCL communicator — is only
+  # needed by the exchange legs AFTER the timed headline, and is created there, under a deadline
+  agg = None if workload == "colwise" else make_aggregator(bm, dist if distributed else None, device, world, rank, distributed)
   timer = KernelTimer()
   per_gar = {}
   extra = {}
@@ -608,20 +664,91 @@ def main():
     per_gar[name] = entry(ms, nbytes, gpus=world, units=aggs_per_step // 2 if workload == "colwise" else 1,
                           config=workload_name)
 
+  def make_line(traffic=None, per_kernel=None):
+    """The JSON line from what has been measured so far (rank 0)."""
+    dominant = max(algo_bytes, key=lambda k: per_gar[k]["avg_ms"])
+    dk = per_gar[dominant]
+    if not distributed:
+      collectives = "none"
+    elif workload == "colwise":
+      collectives = "none inside the timed region (the coordinate-wise rules have no exchange step); see `exchange`"
+    elif agg is not None and agg.native is not None:
+      collectives = "libbm_gar's own RCCL communicator, one C call per aggregation"
+    else:
+      collectives = "torch.distributed (RCCL)"
+    line = {
+      "metric": "aggregations/sec (Byzantine-robust GAR over n workers x d dims; achieved HBM GB/s per GAR in roofline/per_gar)",
+      "value": aggs_per_step * args.steps / elapsed,
+      "unit": "agg/s",
+      "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+      "ms_per_step": elapsed / args.steps * 1e3,
+      "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+      "dtype": "f32", "data": "synthetic",
+      "config": {"workload": workload_name, "n_workers": n, "f": f, "d_total": d_total, "d_per_gpu": d,
+                 "byzantine_rows": "aliased" if args.aliased_byz else "distinct buffers",
+                 "row_placement": "one torch.empty per row (what a caller of the rules has)" if not args.slab_rows else
+                                  "byzantinemomentum_amd.layout.alloc_rows (rows of one allocation, stride = 2 MB multiple + 4352 B) for the C2 / C3 / C4 stacks; one allocation per row for the C5 step",
+                 "parallelism": f"dim-shard x{world}" if world > 1 else "single GPU",
+                 "collectives": collectives},
+      "roofline": {"bound": "hbm", "kernel": dominant, "achieved": dk["gbps"], "peak": HBM_PEAK_GBPS * world,
+                   "unit": "GB/s", "frac": dk["gbps"] / (HBM_PEAK_GBPS * world), "traffic": traffic,
+                   "traffic_source": None if traffic is None else
+                   f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, kernel {dominant_kernel}"
+                   f"{' (' + dominant + ')' if per_kernel is not None else ''}: 1024*(2*FETCH_SIZE + WRITE_SIZE) per launch"},
+      "per_gar": per_gar,
+    }
+    if per_kernel is not None:
+      line["roofline"]["traffic_per_kernel"] = per_kernel
+    line.update(extra)
+    return line
+
   # ---- N > 1: the path's real exchange (sharded Bulyan / Krum with its all-reduce), all-gather, layout exchange ----
   # (also one rank under torchrun with --sharded-extras or --workload bulyan|krum: the same code path, testable on one GPU)
+  # The headline above is complete at this point.  What follows creates the library's own RCCL communicator (colwise
+  # did not need one) and runs collectives no single-GPU box can exercise with real peers: under a deadline, so that a
+  # failure there costs the `exchange` object of the line and not the line.
   cpu_sample = None
   if world == 1 and rank == 0 and not args.no_cpu_baseline and workload in ("bulyan", "krum"):
     cpu_sample = _host_copy(stacks[0])  # (the device stacks go before the extras run)
-  if distributed and workload in ("bulyan", "krum"):
+  exchange_rule = (workload if workload in ("bulyan", "krum") else
+                   "bulyan" if workload == "colwise" and not args.no_extras and (world > 1 or args.sharded_extras) else None)
+  if distributed and exchange_rule is not None:
     del stacks
-    torch.cuda.empty_cache()
-    per_gar.update(sharded_extras(bm, agg, dist, device, world, rank, timer, args, workload, base_d, extra, time_rule=False))
-  elif distributed and workload == "colwise" and not args.no_extras and (world > 1 or args.sharded_extras):
-    del stacks
-    torch.cuda.empty_cache()
-    per_gar.update(sharded_extras(bm, agg, dist, device, world, rank, timer, args, "bulyan", D_RESNET18, extra, time_rule=True))
     stacks = None
+    torch.cuda.empty_cache()
+    barrier()  # every rank arms its deadline at about the same moment
+
+    def give_up():
+      extra.setdefault("exchange", {})["error"] = (
+        f"the exchange legs did not finish within {args.extras_timeout:.0f} s (rank {rank} gave up; a rank stuck in a "
+        f"collective, most likely): the legs that did finish are filled in, the others are null.  The headline was "
+        f"measured before them and stands.")
+      if rank == 0:
+        print(json.dumps(make_line()), flush=True)
+    deadline = Deadline(args.extras_timeout, give_up)
+    try:
+      if agg is None:
+        agg = make_aggregator(bm, dist, device, world, rank, distributed)
+      sharded_extras(bm, agg, dist, device, world, rank, timer, args, exchange_rule,
+                     base_d if workload != "colwise" else D_RESNET18, extra, time_rule=(workload == "colwise"), out=per_gar)
+    except Exception as err:  # noqa: BLE001
+      if deadline.timer is None:
+        raise
+      import traceback
+      traceback.print_exc()
+      print(f"[bench rank {rank}] the exchange legs failed: {err!r}", file=sys.stderr, flush=True)
+      if deadline.cancel():
+        # peers may be inside a collective this rank has left: they end at their own deadlines; this rank ends now
+        extra.setdefault("exchange", {})["error"] = f"rank {rank}: {err!r}"
+        if rank == 0:
+          print(json.dumps(make_line()), flush=True)
+        sys.stderr.flush()
+        os._exit(0)
+      time.sleep(60)  # (the deadline is printing the line and ends the process)
+      os._exit(0)
+    if not deadline.cancel():
+      time.sleep(60)
+      os._exit(0)
 
   # ---- N = 1: the other single-GPU configurations, briefly ----
   if world == 1 and workload == "colwise" and not args.no_extras and rank == 0 and stacks is not None:
@@ -639,7 +766,6 @@ def main():
 
   if rank == 0:
     dominant = max(algo_bytes, key=lambda k: per_gar[k]["avg_ms"])
-    dk = per_gar[dominant]
     traffic, per_kernel = None, None
     # (not under torch.distributed.run: the child processes would inherit the launcher's rendezvous environment)
     if world == 1 and not distributed and not args.no_traffic and "BM_BENCH_CHILD" not in os.environ:
@@ -656,33 +782,7 @@ def main():
       else:
         got = measure_traffic(child, {"dominant": dominant_kernel})
         traffic = None if got is None else got.get("dominant")
-    line = {
-      "metric": "aggregations/sec (Byzantine-robust GAR over n workers x d dims; achieved HBM GB/s per GAR in roofline/per_gar)",
-      "value": aggs_per_step * args.steps / elapsed,
-      "unit": "agg/s",
-      "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-      "ms_per_step": elapsed / args.steps * 1e3,
-      "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-      "dtype": "f32", "data": "synthetic",
-      "config": {"workload": workload_name, "n_workers": n, "f": f, "d_total": d_total, "d_per_gpu": d,
-                 "byzantine_rows": "aliased" if args.aliased_byz else "distinct buffers",
-                 "row_placement": "one torch.empty per row (what a caller of the rules has)" if not args.slab_rows else
-                                  "byzantinemomentum_amd.layout.alloc_rows (rows of one allocation, stride = 2 MB multiple + 4352 B) for the C2 / C3 / C4 stacks; one allocation per row for the C5 step",
-                 "parallelism": f"dim-shard x{world}" if world > 1 else "single GPU",
-                 "collectives": ("none" if not distributed else
-                                 "libbm_gar's own RCCL communicator, one C call per aggregation" if agg.native is not None
-                                 else "torch.distributed (RCCL)")},
-      "roofline": {"bound": "hbm", "kernel": dominant, "achieved": dk["gbps"], "peak": HBM_PEAK_GBPS * world,
-                   "unit": "GB/s", "frac": dk["gbps"] / (HBM_PEAK_GBPS * world), "traffic": traffic,
-                   "traffic_source": None if traffic is None else
-                   f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, kernel {dominant_kernel}"
-                   f"{' (' + dominant + ')' if per_kernel is not None else ''}: 1024*(2*FETCH_SIZE + WRITE_SIZE) per launch"},
-      "per_gar": per_gar,
-    }
-    if per_kernel is not None:
-      line["roofline"]["traffic_per_kernel"] = per_kernel
-    line.update(extra)
-    print(json.dumps(line))
+    print(json.dumps(make_line(traffic, per_kernel)), flush=True)
   if distributed:
     dist.destroy_process_group()
 

@@ -67,3 +67,30 @@ def test_step_byte_model():
   assert bench.step_algorithmic_bytes(d, n, f, "krum") == 4 * d * ((3 * h + 3) + (m + 1) + 8)  # the distance pass rides along
   assert bench.step_algorithmic_bytes(d, n, f, "median") == 4 * d * ((3 * h + 3) + 1 + 8)  # the rule rides along
   assert bench.entry(2.0, 4_000_000_000)["gbps"] == pytest.approx(2000.0)
+
+
+def test_deadline_prints_what_it_has_and_ends_the_process():
+  """A rank stuck in a collective after the timed headline: the deadline's thread prints the line built so far and the
+  process leaves with status 0 (bench.Deadline; the main thread never returns from its blocking call)."""
+  import subprocess
+  code = (
+    "import importlib.util, sys, time\n"
+    f"spec = importlib.util.spec_from_file_location('b', r'{ROOT / 'bench.py'}')\n"
+    "b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)\n"
+    "d = b.Deadline(0.3, lambda: print('{\"value\": 1}'))\n"
+    "time.sleep(60)\n"           # stands for a call that never returns (it releases the GIL, as RCCL / ctypes do)
+    "print('never')\n")
+  done = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+  assert done.returncode == 0, done.stderr
+  assert done.stdout.strip().splitlines() == ['{"value": 1}']
+
+
+def test_deadline_cancelled_in_time_does_nothing():
+  import time
+  bench = load_bench()
+  fired = []
+  d = bench.Deadline(0.5, lambda: fired.append(1))
+  assert d.cancel() is True
+  time.sleep(0.8)
+  assert fired == []
+  assert bench.Deadline(0, lambda: fired.append(2)).cancel() is True and fired == []  # 0 = no limit
