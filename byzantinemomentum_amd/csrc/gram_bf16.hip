@@ -87,7 +87,10 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const float** row_ptr = reinterpret_cast<const float**>(smem);
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63;
+  // (the wave index as a SCALAR: the chunk counters gw / c / nw and every loop condition then live in SGPRs — 20 VALU
+  //  instructions fewer per pair of chunks at K = 7, 8-24 VGPRs fewer, and the K = 7 two-plane instance no longer
+  //  parks `wave` in scratch across its main loop at the 168 VGPRs of three workgroups per CU)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   char* wbase = smem + S::kPtrBytes + wave * S::WS;
 
   // Row pointers: one per-lane load from the kernarg segment (the table is the first kernel
@@ -95,7 +98,10 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
   if (tid < BM_MAX_ROWS) {
     typedef const float* __attribute__((address_space(4))) const* KargTable;
     KargTable karg = (KargTable)__builtin_amdgcn_kernarg_segment_ptr();
-    row_ptr[tid] = (const float*)karg[tid < n ? tid : 0];
+    // (slots past the stack point at its LAST row: the one load instruction that can reach a padded row — k = K - 1,
+    //  rows n .. 4K-1 — then needs no clamp of its row index, a loop invariant the K = 6 three-plane instance parked
+    //  in scratch; what a padded row holds is discarded at the end: gj < n)
+    row_ptr[tid] = (const float*)karg[tid < n ? tid : n - 1];
   }
   // the arrival counter of this call's reduction (gram_reduce_sqdist_kernel, next on the stream) starts from zero
   if (blockIdx.x == 0 && tid == 0 && arrival != nullptr) *arrival = 0;
@@ -142,16 +148,14 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
     if (ALIGNED && (c + 1) * kB3Chunk <= d) {
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        int r = 4 * k + rho;
-        if (k == K - 1) r = r < n ? r : n - 1;
+        const int r = 4 * k + rho;  // (rows >= n: the table repeats row n - 1)
         v[k] = __builtin_nontemporal_load(reinterpret_cast<const GlobalF4*>((GlobalF)row_ptr[r] + coord));
       }
     } else {
       // ragged last chunk / rows that are not 16-byte aligned: guarded scalar loads, zero fill
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        int r = 4 * k + rho;
-        if (k == K - 1) r = r < n ? r : n - 1;
+        const int r = 4 * k + rho;  // (rows >= n: the table repeats row n - 1)
         GlobalF src = (GlobalF)row_ptr[r] + coord;
         const int64_t left = d - coord;
         f32x4 t = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -311,8 +315,7 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
       const int64_t coord = cc * kB3Chunk + 4 * x;
 #pragma unroll
       for (int k = 0; k < K; ++k) {
-        int r = 4 * k + rho;
-        if (k == K - 1) r = r < n ? r : n - 1;
+        const int r = 4 * k + rho;  // (rows >= n: the table repeats row n - 1)
         v[k] = __builtin_nontemporal_load(reinterpret_cast<const GlobalF4*>((GlobalF)row_ptr[r] + coord));
       }
     };

@@ -1,0 +1,44 @@
+"""Code-object metadata of the kernels behind the bench line (no GPU needed: hipcc cross-compiles, the notes of the
+gfx950 code objects inside libbm_gar.so say what the register allocator did).  A scratch spill inside one of these
+kernels is a regression the GPU tests would not notice (same bits, slower)."""
+
+import importlib.util
+import pathlib
+import re
+
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+# (regex on the demangled name, VGPR ceiling): the ceiling is what the launch bounds of the kernel aim at
+# (168 = three workgroups of 256 lanes per CU, 128 = one workgroup of 1024 lanes per CU ... DESIGN 4)
+HOT = [
+  (r"colwise_burst_kernel<25, 0, 4>", 128),          # C2 median
+  (r"colwise_burst_kernel<25, 1, 4>", 128),          # C2 trimmed mean
+  (r"gram3_partial_kernel<7, 2, true>", 168),        # C4 distance pass (n = 25, two planes)
+  (r"gram3_partial_kernel<13, 2, true>", 256),       # C3 distance pass (n = 51)
+  (r"bulyan_pass2_kernel<25, 5, 4>", 128),           # C4 pass 2
+  (r"selected_mean_burst_kernel", 128),              # C3 average of the selected rows
+  (r"momentum_gram_kernel<20, false, false>", 256),  # C5 first pass with the distance pass riding along
+  (r"study_stats_burst_kernel<true, 3, false>", 128),  # C5 study block
+]
+
+
+@pytest.fixture(scope="module")
+def kernels():
+  spec = importlib.util.spec_from_file_location("kernel_meta", ROOT / "scripts" / "kernel_meta.py")
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  if not mod.LIB.exists() or not (mod.LLVM / "llvm-objdump").exists():
+    pytest.skip("libbm_gar.so or the LLVM tools are not here")
+  return mod.kernels()
+
+
+@pytest.mark.parametrize("pattern,ceiling", HOT)
+def test_hot_kernels_keep_their_registers(kernels, pattern, ceiling):
+  hits = [k for k in kernels if re.search(pattern, k["demangled"])]
+  assert hits, f"no kernel matches {pattern}"
+  for k in hits:
+    assert k["vgpr_spill"] == 0 and k["scratch"] == 0, (k["demangled"], k["vgpr_spill"], k["scratch"])
+    assert k["sgpr_spill"] == 0, (k["demangled"], k["sgpr_spill"])
+    assert k["vgpr"] <= ceiling, (k["demangled"], k["vgpr"], ceiling)
