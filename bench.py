@@ -864,6 +864,10 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
             "cut out of one allocation at a skewed stride (layout.alloc_rows)" if saved else "one torch.empty each"))
         del alt
         torch.cuda.empty_cache()
+      if "BM_BENCH_CHILD" not in os.environ:
+        # classic Krum (m = 1): the same distance pass, then ONE row copied out
+        ms_1 = timed_loop(lambda i: bm.krum(stacks[i & 1], f, 1), 12, 3, timer, "krum_m1")
+        out["krum_c3_m1"] = entry(ms_1, 4 * d * n + 4 * d * 2, config=f"classic krum (m=1), n={n}, f={f}, d={d}, one GPU")
       ms_b = timed_loop(lambda i: bm.brute(stacks[i & 1], f), 12, 3, timer, "brute_c3")
       out["brute_c3"] = entry(ms_b, 4 * d * n + 4 * d * (n - f + 1),
                               config=f"brute.py:32-80, n={n}, f={f} (1.6e11 subsets: not enumerable; the subset of smallest "
@@ -930,6 +934,21 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
                                   config=f"full step mirror, rule {gar}, n={n}, f={f}, d={d}, one GPU")
     del runner
   if "BM_BENCH_CHILD" not in os.environ:
+    # the two other rules SURVEY 8d lists for C5: Bulyan (its distance pass rides along with the first pass like
+    # Krum's, pass 2 over the 18 ranked rows remains) and the trimmed mean (rides along like the median)
+    for gar in ("bulyan", "trmean"):
+      try:
+        runner = AggregationStep(n, f, f, gar=gar, momentum=0.99, dampening=0.99, attack_factor=1.1, nb_past=25)
+
+        def one_more(i):
+          runner.run(sets[i & 1])
+          runner.floats()
+        ms = timed_loop(one_more, 8, 27, timer, "step_" + gar)
+        out[f"step_c5_{gar}"] = entry(ms, step_algorithmic_bytes(d, n, f, gar),
+                                      config=f"full step mirror, rule {gar}, n={n}, f={f}, d={d}, one GPU")
+        del runner
+      except Exception as err:  # noqa: BLE001  (a side entry must not take the line down)
+        out[f"step_c5_{gar}"] = {"error": repr(err)}
     # the same step with the momentum at the update, the reference's default placement (attack.py:809-810,837-839): the
     # honest rows are the sampled rows, statistics + Byzantine vector + rule (or its distance pass) are one pass over them
     for gar in ("krum", "median"):
