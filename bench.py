@@ -866,8 +866,11 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
         torch.cuda.empty_cache()
       if "BM_BENCH_CHILD" not in os.environ:
         # classic Krum (m = 1): the same distance pass, then ONE row copied out
-        ms_1 = timed_loop(lambda i: bm.krum(stacks[i & 1], f, 1), 12, 3, timer, "krum_m1")
-        out["krum_c3_m1"] = entry(ms_1, 4 * d * n + 4 * d * 2, config=f"classic krum (m=1), n={n}, f={f}, d={d}, one GPU")
+        try:
+          ms_1 = timed_loop(lambda i: bm.krum(stacks[i & 1], f, 1), 12, 3, timer, "krum_m1")
+          out["krum_c3_m1"] = entry(ms_1, 4 * d * n + 4 * d * 2, config=f"classic krum (m=1), n={n}, f={f}, d={d}, one GPU")
+        except Exception as err:  # noqa: BLE001  (a side entry must not take the line down)
+          out["krum_c3_m1"] = {"error": repr(err)}
       ms_b = timed_loop(lambda i: bm.brute(stacks[i & 1], f), 12, 3, timer, "brute_c3")
       out["brute_c3"] = entry(ms_b, 4 * d * n + 4 * d * (n - f + 1),
                               config=f"brute.py:32-80, n={n}, f={f} (1.6e11 subsets: not enumerable; the subset of smallest "
