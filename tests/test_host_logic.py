@@ -400,3 +400,84 @@ def test_device_brute_algorithm_equals_the_host_search():
       assert got == want, (n, f, variant, got, want)
       worst = max(worst, probes)
   assert worst <= 24  # the bisection stays logarithmic on these inputs (2 016 candidates at n = 64)
+
+
+# ---------------------------------------------------------------------------- #
+# The device ranking (csrc/rank_body.h), step by step in Python
+
+def _device_rank_emulation(sq, n, f, m, krum_mode):
+  """krum_rank_body with Python floats: per row, the 64 lanes hold sqrt(sq) (non-finite -> +inf, own lane and lanes
+  past n +inf), the bitonic network of the kernel (same k / j loops, same keep-min predicate) sorts them across the
+  lanes, lane i adds the `take` smallest of row i in ascending order, rows are ranked by (score, index)."""
+  inf = math.inf
+  srt = []
+  for i in range(n):
+    v = [inf] * 64
+    for lane in range(n):
+      if lane != i:
+        s = sq[i][lane]
+        r = math.sqrt(s) if s >= 0 else math.nan  # (sqrt of NaN / negative: NaN, as the device's sqrt)
+        v[lane] = inf if (r != r or abs(r) == inf) else r
+    k = 2
+    while k <= 64:
+      j = k >> 1
+      while j > 0:
+        o = [v[lane ^ j] for lane in range(64)]
+        keep_min = [((lane & k) == 0) == ((lane & j) == 0) for lane in range(64)]
+        v = [min(v[lane], o[lane]) if keep_min[lane] else max(v[lane], o[lane]) for lane in range(64)]
+        j >>= 1
+      k <<= 1
+    assert all(v[t] <= v[t + 1] for t in range(63)), "the network does not sort"
+    srt.append(v[:n - 1])
+  take = max(0, min(n - 1, (n - f - 1) if krum_mode else m))
+  scores = []
+  for i in range(n):
+    s = 0.0
+    for t in range(take):
+      s += srt[i][t]
+    scores.append(s)
+  order = [None] * n
+  for i in range(n):
+    rank = sum(1 for j in range(n) if scores[j] < scores[i] or (scores[j] == scores[i] and j < i))
+    order[rank] = i
+  return order, scores
+
+
+def test_device_rank_algorithm_equals_the_oracle():
+  """The algorithm of krum_rank_body (emulated: bitonic network across 64 lanes, ascending fp64 sums, rank by counting)
+  against the oracle's restatement of krum.py:50-62 / bulyan.py:56-62 on random matrices, matrices with exact ties
+  (aliased rows, few distinct values), rows at non-finite distance, and the smallest stacks.  (The kernel itself is
+  compared with the oracle on the GPU, tests/test_gpu_parity*.py.)"""
+  gen = torch.Generator().manual_seed(11)
+  for n, f in ((1, 0), (2, 0), (3, 0), (5, 1), (7, 2), (11, 2), (11, 4), (25, 5), (25, 11), (33, 8), (51, 12), (64, 20), (64, 30)):
+    for variant in range(6):
+      if variant % 3 == 0:
+        pts = torch.randn(n, 6, generator=gen, dtype=torch.float64)
+      elif variant % 3 == 1:
+        pts = torch.randint(0, 3, (n, 3), generator=gen).double()  # few distinct distances: exact score ties
+      else:
+        pts = torch.randn(n, 5, generator=gen, dtype=torch.float64)
+        if n >= 3:
+          pts[-1] = pts[-2]                                           # aliased rows: zero distance, tied scores
+      sq = (pts[:, None, :] - pts[None, :, :]).pow(2).sum(dim=2)
+      if variant >= 3 and n >= 3:
+        row = (3 * variant + 1) % n
+        sq[row, :] = math.nan if variant % 2 else math.inf
+        sq[:, row] = sq[row, :]
+      # (math.sqrt like the emulation: torch's vectorised fp64 sqrt is not correctly rounded on every CPU path, and the
+      #  subject here is the ranking, not the square root)
+      dist = np.array([[math.sqrt(v) if v >= 0 else math.nan for v in row] for row in sq.tolist()])
+      dist[~np.isfinite(dist)] = math.inf                             # krum.py:46-47
+      np.fill_diagonal(dist, 0.0)
+      m = max(1, n - f - 2)
+      # Krum scores: n-f-1 smallest of the n-1 others (krum.py:59-60); Bulyan: m smallest (bulyan.py:58-61)
+      for krum_mode in (True, False):
+        got_order, got_scores = _device_rank_emulation(sq.tolist(), n, f, m, krum_mode)
+        if krum_mode:
+          want_scores = O.krum_scores(dist, f) if n - f - 1 >= 0 else None
+        else:
+          want_scores = [O._sum_smallest([dist[i, j] if j != i else math.inf for j in range(n)], min(m, n - 1)) for i in range(n)]
+        if want_scores is None:
+          continue
+        assert got_scores == list(want_scores), (n, f, variant, krum_mode)
+        assert got_order == O._stable_order(list(want_scores)), (n, f, variant, krum_mode)
