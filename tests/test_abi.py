@@ -121,3 +121,49 @@ def test_round4_entry_points_validate_arguments_without_gpu(lib):
   assert lib.bm_pairwise_rank(rows, 25, 1000, 999, 5, 18, _lib.RANK_KRUM, rows, rows, None, rows, None) == _lib.EINVAL  # d_total < d
   assert lib.bm_pairwise_rank(rows, 25, 1000, 1000, 5, 18, 7, rows, rows, None, rows, None) == _lib.EINVAL            # mode
   assert lib.bm_pairwise_rank(rows, 25, 1000, 1000, 5, 18, _lib.RANK_KRUM, rows, None, None, rows, None) == _lib.EINVAL  # no order
+
+
+def test_header_is_plain_c_and_a_c_host_links_and_runs(tmp_path):
+  """The boundary is a C ABI: include/bm_gar.h compiles as C99 (gcc, -pedantic, no C++ in sight), a C host links
+  against libbm_gar.so, reads the version and an error string, and every argument check answers BM_EINVAL — without a
+  GPU, because validation comes before any HIP call."""
+  import shutil
+  import subprocess
+  gcc = shutil.which("gcc")
+  if gcc is None:
+    pytest.skip("gcc not here")
+  from byzantinemomentum_amd import build
+  lib_path = build.LIB_PATH
+  src = tmp_path / "host.c"
+  src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "bm_gar.h"
+int main(void) {
+  const float* rows[2] = {0, 0};
+  float out[1];
+  int rc;
+  printf("abi %d\n", bm_abi_version());
+  if (strlen(bm_error_string(BM_EINVAL)) == 0) return 2;
+  rc = bm_colwise(BM_OP_MEDIAN, rows, 0, 1, 0, out, 0);           /* n < 1 */
+  if (rc != BM_EINVAL) return 3;
+  rc = bm_colwise(BM_OP_MEDIAN, rows, BM_MAX_ROWS + 1, 1, 0, out, 0); /* too many rows */
+  if (rc != BM_EINVAL) return 4;
+  rc = bm_colwise(99, rows, 2, 1, 0, out, 0);                      /* unknown rule */
+  if (rc != BM_EINVAL) return 5;
+  if (bm_workspace_bytes(BM_WS_PAIRWISE, 25, 1000) <= 0) return 6;
+  printf("ok\n");
+  return 0;
+}
+''')
+  exe = tmp_path / "host"
+  include = pathlib.Path(build.INCLUDE_DIR)
+  subprocess.run([gcc, "-std=c99", "-pedantic", "-Wall", "-Werror", "-fsyntax-only", "-I", str(include), str(src)],
+                 check=True, capture_output=True)
+  done = subprocess.run([gcc, "-std=c99", "-I", str(include), str(src), "-o", str(exe), str(lib_path),
+                         f"-Wl,-rpath,{lib_path.parent}", "-Wl,-rpath,/opt/rocm/lib"], capture_output=True, text=True)
+  assert done.returncode == 0, done.stderr
+  run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+  assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
+  from byzantinemomentum_amd import _lib
+  assert run.stdout.split() == ["abi", str(_lib.ABI_VERSION), "ok"]
