@@ -76,7 +76,7 @@ def parse():
   p.add_argument("--sharded-extras", action="store_true",
                  help="one rank under torch.distributed.run: run the per_gar legs of the N > 1 line (sharded Bulyan with "
                       "its all-reduce, all-gather, layout exchange) as well, so that their code is exercised on one GPU")
-  p.add_argument("--extras-timeout", type=float, default=240.0,
+  p.add_argument("--extras-timeout", type=float, default=180.0,
                  help="N > 1: seconds the exchange legs that follow the timed headline (the library's own RCCL communicator, the "
                       "sharded rule, all-gather, layout exchange) may take on every rank before the line is printed without them "
                       "(`exchange.error`) and the job ends: a hang there must not cost the headline (0 = no limit)")
