@@ -502,12 +502,19 @@ class Deadline:
       if self.done:
         return
       self.done = True
+      status = 0
       try:
         self.emit()
-        sys.stdout.flush()
-        sys.stderr.flush()
+      except BaseException:  # noqa: BLE001  (nothing may keep this thread from ending the process)
+        import traceback
+        traceback.print_exc()
+        status = 1  # the line could not be printed: do not look like a success
       finally:
-        os._exit(0)
+        try:
+          sys.stdout.flush()
+          sys.stderr.flush()
+        finally:
+          os._exit(status)
 
   def cancel(self):
     """True when the caller may go on and print the line itself (the deadline did not fire)."""
