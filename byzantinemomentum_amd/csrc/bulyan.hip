@@ -27,7 +27,7 @@ constexpr int kBulBlock = 256;
 template <int N, int F, int VEC>
 __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(
     RowTable rows, const int32_t* __restrict__ order, int64_t nvec, int nt_result, float* __restrict__ out,
-    int short_window) {
+    int short_window, int reverse) {
   constexpr int MMAX = N - F - 2;
   constexpr int THETA = N - 2 * F - 2;
   constexpr int BETA = THETA - 2 * F;
@@ -59,7 +59,6 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(
   }
   const float kNaN = __builtin_nanf("");
   const uint32_t nv = (uint32_t)nvec;  // nvec * VEC * 4 < 2^32: the host splits longer gradients
-  const uint32_t stride = gridDim.x * kBulBlock;
   auto load_group = [&](uint32_t off, float (&x)[VEC][MMAX]) {
 #pragma unroll
     for (int t = 0; t < MMAX; ++t) {
@@ -127,12 +126,22 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(
     }
   };
   {
-    for (uint32_t v = blockIdx.x * kBulBlock + threadIdx.x; v < nv; v += stride) {
-      const uint32_t off = v * (uint32_t)(VEC * sizeof(float));
-      float x[VEC][MMAX], r[VEC];
-      load_group(off, x);
-      rule(x, r);
-      store_result_policy<VEC>(reinterpret_cast<float*>(reinterpret_cast<char*>(out) + off), r, nt_result);
+    // Blocks of kBulBlock column groups, walked from the LAST one when `reverse` is set (BM_SECOND_PASS_REVERSE, the
+    // default): the distance pass that ranked the rows read them from the first coordinate to the last, so what the
+    // 256 MB Infinity Cache still holds when this kernel starts is the TAIL of every row (256 MB / 25 rows = 2.5 M
+    // coordinates at n = 25: 184 MB of this kernel's 804 MB of reads) — walking forward would evict it before
+    // reaching it.  Workgroups are dispatched in index order, so workgroup 0 takes the last block.  The arithmetic of
+    // a column does not depend on where the walk starts: same bits.
+    const uint32_t nblk = (nv + kBulBlock - 1) / kBulBlock;
+    for (uint32_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+      const uint32_t v = (reverse != 0 ? nblk - 1 - b : b) * kBulBlock + threadIdx.x;
+      if (v < nv) {
+        const uint32_t off = v * (uint32_t)(VEC * sizeof(float));
+        float x[VEC][MMAX], r[VEC];
+        load_group(off, x);
+        rule(x, r);
+        store_result_policy<VEC>(reinterpret_cast<float*>(reinterpret_cast<char*>(out) + off), r, nt_result);
+      }
     }
   }
 }
@@ -205,14 +214,16 @@ static int launch_bulyan_fast(const float* const* rows_host, const int32_t* orde
       const int64_t nvec = d / 4;
       hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 4 ? 4 : 1)>),
                          dim3(stream_grid(nvec, kBulBlock, kColMaxBlocks)), dim3(kBulBlock), 0,
-                         s, tab, order, nvec, 1, out, tuning().bulyan_short);
+                         s, tab, order, nvec, 1, out, tuning().bulyan_short,
+                         tuning().second_pass_reverse);
       BM_LAUNCH_CHECK();
       body = nvec * 4;
     } else if (vec == 2 && kMaxVec >= 2 && d / 2 > 0) {
       const int64_t nvec = d / 2;
       hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 2 ? 2 : 1)>),
                          dim3(stream_grid(nvec, kBulBlock, kColMaxBlocks)), dim3(kBulBlock), 0,
-                         s, tab, order, nvec, 1, out, tuning().bulyan_short);
+                         s, tab, order, nvec, 1, out, tuning().bulyan_short,
+                         tuning().second_pass_reverse);
       BM_LAUNCH_CHECK();
       body = nvec * 2;
     }
@@ -222,7 +233,8 @@ static int launch_bulyan_fast(const float* const* rows_host, const int32_t* orde
       const int64_t rest = d - body;
       hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, 1>),
                          dim3(stream_grid(rest, kBulBlock, kColMaxBlocks)), dim3(kBulBlock), 0,
-                         s, tail, order, rest, 1, out + body, tuning().bulyan_short);
+                         s, tail, order, rest, 1, out + body, tuning().bulyan_short,
+                         tuning().second_pass_reverse);
       BM_LAUNCH_CHECK();
     }
   }

@@ -22,12 +22,16 @@ template <int VEC>
 __global__ __launch_bounds__(kRedBlock) void selected_mean_kernel(RowTable rows,
                                                                   const int32_t* __restrict__ idx,
                                                                   int m, int64_t nvec, float fm, int nt_result,
-                                                                  float* __restrict__ out) {
+                                                                  float* __restrict__ out, int reverse) {
   __shared__ const float* sel[BM_MAX_ROWS];
   if (threadIdx.x < m) sel[threadIdx.x] = rows.p[idx[threadIdx.x]];
   __syncthreads();
-  const int64_t stride = (int64_t)gridDim.x * kRedBlock;
-  for (int64_t v = (int64_t)blockIdx.x * kRedBlock + threadIdx.x; v < nvec; v += stride) {
+  // (`reverse`: blocks of kRedBlock column groups walked from the last one — the pass that selected the rows read them
+  //  from the first coordinate to the last, the Infinity Cache holds their tail; see bulyan_pass2_kernel.  Same bits.)
+  const int64_t nblk = (nvec + kRedBlock - 1) / kRedBlock;
+  for (int64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+    const int64_t v = (reverse != 0 ? nblk - 1 - b : b) * kRedBlock + threadIdx.x;
+    if (v >= nvec) continue;
     float acc[VEC];
 #pragma unroll
     for (int c = 0; c < VEC; ++c) acc[c] = 0.0f;
@@ -53,7 +57,7 @@ constexpr int kMeanBurstSlots = 9;  // 9 x 1024 x 16 B = 144 KB of results next 
 __global__ __launch_bounds__(kMeanBurstThreads) void selected_mean_burst_kernel(RowTable rows,
                                                                                 const int32_t* __restrict__ idx, int m,
                                                                                 int64_t nvec, float fm,
-                                                                                float* __restrict__ out) {
+                                                                                float* __restrict__ out, int reverse) {
   using V = typename VecLoad<4>::T;
   __shared__ V stage[kMeanBurstSlots * kMeanBurstThreads];
   __shared__ const float* sel[BM_MAX_ROWS];
@@ -67,7 +71,8 @@ __global__ __launch_bounds__(kMeanBurstThreads) void selected_mean_burst_kernel(
   for (uint32_t p0 = 0; p0 < iters; p0 += kMeanBurstSlots) {
     const uint32_t p1 = (p0 + kMeanBurstSlots < iters) ? p0 + kMeanBurstSlots : iters;
     for (uint32_t it = p0; it < p1; ++it) {
-      const uint32_t v = it * span + first;
+      // (`reverse`: the iterations walk the columns from the end, see selected_mean_kernel; the staging slot keeps `it`)
+      const uint32_t v = (reverse != 0 ? iters - 1 - it : it) * span + first;
       if (v < nv) {
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 8
@@ -85,7 +90,7 @@ __global__ __launch_bounds__(kMeanBurstThreads) void selected_mean_burst_kernel(
     }
     __syncthreads();  // what makes the stores below a burst
     for (uint32_t it = p0; it < p1; ++it) {
-      const uint32_t v = it * span + first;
+      const uint32_t v = (reverse != 0 ? iters - 1 - it : it) * span + first;
       if (v < nv) __builtin_nontemporal_store(stage[(it - p0) * kMeanBurstThreads + tid], reinterpret_cast<V*>(out) + v);
     }
   }
@@ -102,14 +107,14 @@ static int launch_selected_mean(const RowTable& tab, const int32_t* idx, int m, 
     if (tuning().mean_burst > 0 && m >= 12 && nvec < ((int64_t)1 << 30) &&
         nvec / ((int64_t)cus * kMeanBurstThreads) >= tuning().mean_burst) {
       hipLaunchKernelGGL(selected_mean_burst_kernel, dim3(cus), dim3(kMeanBurstThreads), 0, s, tab, idx, m, nvec,
-                         (float)m, out);
+                         (float)m, out, tuning().second_pass_reverse);
       BM_LAUNCH_CHECK();
       return 0;
     }
   }
   const int grid = stream_grid(nvec, kRedBlock, 256 * 32);
   hipLaunchKernelGGL(selected_mean_kernel<VEC>, dim3(grid), dim3(kRedBlock), 0, s, tab, idx, m, nvec,
-                     (float)m, 1, out);
+                     (float)m, 1, out, tuning().second_pass_reverse);
   BM_LAUNCH_CHECK();
   return 0;
 }
