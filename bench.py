@@ -205,6 +205,20 @@ def _cpu_reference():
     return None
 
 
+def _host_facts():
+  """CPU model, hardware threads and torch version of the box the baseline runs on (BASELINE.md section 2 asks for them)."""
+  model = None
+  try:
+    with open("/proc/cpuinfo") as fh:
+      for line in fh:
+        if line.lower().startswith("model name"):
+          model = line.split(":", 1)[1].strip()
+          break
+  except OSError:
+    pass
+  return {"cpu_model": model, "hardware_threads": os.cpu_count(), "torch": torch.__version__}
+
+
 def _host_copy(stack):
   seen = {}
   return [seen.setdefault(id(g), g.cpu()) for g in stack]
@@ -233,7 +247,7 @@ def cpu_baseline_colwise(stack, f):
   for _ in range(reps):
     pair(rows)
   dt = (time.perf_counter() - t0) / reps
-  return {"value": 2.0 / dt, "unit": "agg/s", "cores": threads, "kind": "reference" if gars is not None else "port",
+  return {"value": 2.0 / dt, "unit": "agg/s", "cores": threads, "kind": "reference" if gars is not None else "port", "host": _host_facts(),
           "sample": f"{what} on the same n={len(rows)} x d={d} stack (full size, nothing scaled), {reps} passes of "
                     f"median+trmean, {dt:.3f} s per pass, {threads} torch threads (fastest of 16/32/64/"
                     f"{(os.cpu_count() or 2) // 2}/{os.cpu_count()} on a d/16 sample; host has {os.cpu_count()} "
@@ -259,7 +273,7 @@ def cpu_baseline_rule(rows, f, rule):
   t0 = time.perf_counter()
   fn(rows)
   dt = time.perf_counter() - t0
-  return {"value": 1.0 / dt, "unit": "agg/s", "cores": threads, "kind": "reference" if gars is not None else "port",
+  return {"value": 1.0 / dt, "unit": "agg/s", "cores": threads, "kind": "reference" if gars is not None else "port", "host": _host_facts(),
           "sample": f"{what} on the same n={n}, f={f}, d={d} stack (full size, nothing scaled), one aggregation "
                     f"{dt:.2f} s on {threads} torch threads"}
 
@@ -278,7 +292,7 @@ def cpu_baseline_step(sampled, n, f, gar):
   t0 = time.perf_counter()
   loop.step(rows, params, origin)
   dt = time.perf_counter() - t0
-  return {"value": 1.0 / dt, "unit": "steps/s", "cores": threads, "kind": "port",
+  return {"value": 1.0 / dt, "unit": "steps/s", "cores": threads, "kind": "port", "host": _host_facts(),
           "sample": f"one full-size step (n={n}, f={f}, d={d}, worker momentum 0.99, empire 1.1, rule {gar}, study "
                     f"block; the first step of a run: no past gradient in the deque yet) of the f32 loop-body "
                     f"restatement, {dt:.2f} s on {threads} torch threads"}

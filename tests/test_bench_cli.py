@@ -94,3 +94,27 @@ def test_deadline_cancelled_in_time_does_nothing():
   time.sleep(0.8)
   assert fired == []
   assert bench.Deadline(0, lambda: fired.append(2)).cancel() is True and fired == []  # 0 = no limit
+
+
+def test_cpu_baseline_legs_on_a_small_stack():
+  """The three cpu_baseline legs of the line (the reference's own aggregators when its checkout is here, else the
+  oracle's pinned port; the loop-body restatement for the step) on a small stack: the records carry value, unit, cores,
+  kind, the sample description and the host facts BASELINE.md asks for."""
+  import torch
+  from oracle import gar_oracle as O
+  bench = load_bench()
+  threads = torch.get_num_threads()
+  try:
+    rows, h = O.make_stack("hetero", 25, 5, 4096, seed=99)
+    col = bench.cpu_baseline_colwise(rows, 5)
+    krum = bench.cpu_baseline_rule(rows, 5, "krum")
+    bul = bench.cpu_baseline_rule(rows, 5, "bulyan")
+    step = bench.cpu_baseline_step(rows[:h], 25, 5, "krum")
+  finally:
+    torch.set_num_threads(threads)
+  for rec, unit in ((col, "agg/s"), (krum, "agg/s"), (bul, "agg/s"), (step, "steps/s")):
+    assert rec["value"] > 0 and rec["unit"] == unit and rec["cores"] >= 1 and rec["kind"] in ("reference", "port")
+    assert "full size" in rec["sample"] or "full-size" in rec["sample"]
+    assert rec["host"]["hardware_threads"] == os.cpu_count() and rec["host"]["torch"] == torch.__version__
+  from oracle import reference_loader
+  assert col["kind"] == ("reference" if reference_loader.available() else "port")
