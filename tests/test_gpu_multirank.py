@@ -239,21 +239,24 @@ def test_multi_rank_sharded_path_on_the_hip_kernels(world, d):
   EMPTY one; world 4, d = 2^20: the length at which the distance pass changes its split plan — every rank must plan
   from the total, not from its 262 144 coordinates."""
   import warnings
-  results, codes, words = _run_ranks(world, d)
-  errors = {r: rep["error"] for r, rep in results.items() if "error" in rep}
-  if errors or len(results) < world or any(c != 0 for c in codes):
-    # Seen in about one sequence run in five on the gpurun boxes, only in the 4-rank 2^20 case and never when that case
-    # runs alone: one rank dies and its peers report "Connection closed by peer" from their next gloo collective.  The
-    # cause is not established (DESIGN 8).  One retry, with the first attempt's tracebacks in the warning summary;
-    # a second failure fails the test with both.
-    # (exit codes: a negative one is the signal that killed the rank; the stderr files hold what Python never saw)
-    first = (f"exit codes {codes}\n" + "\n".join(f"--- rank {r} ---\n{text}" for r, text in sorted(errors.items()))
-             + "\n" + words)
-    warnings.warn(f"multi-rank attempt 1 failed (world {world}, d {d}); retrying once.\n{first}")
+  # Seen in about one sequence run in five on the gpurun boxes, only in the 4-rank 2^20 case and never when that case
+  # runs alone: one rank dies and its peers report "Connection closed by peer" from their next gloo collective.  The
+  # cause is not established (DESIGN 8).  An attempt in which a rank DIED (no traceback of its own, or only the
+  # transport's complaint about a peer that left) is repeated, twice at most, with every failed attempt in the warning
+  # summary.  An attempt in which a rank reports a failed ASSERTION is a parity failure and is never repeated.
+  history = []
+  for attempt in range(3):
     results, codes, words = _run_ranks(world, d)
     errors = {r: rep["error"] for r, rep in results.items() if "error" in rep}
-    assert not errors, first + f"\n=== second attempt: exit codes {codes} ===\n" + "\n".join(
-      f"--- rank {r} ---\n{text}" for r, text in sorted(errors.items())) + "\n" + words
+    if not errors and len(results) == world and all(c == 0 for c in codes):
+      break
+    # (exit codes: a negative one is the signal that killed the rank; the stderr files hold what Python never saw)
+    report = (f"=== attempt {attempt + 1}: exit codes {codes} ===\n"
+              + "\n".join(f"--- rank {r} ---\n{text}" for r, text in sorted(errors.items())) + "\n" + words)
+    history.append(report)
+    assert not any("AssertionError" in text for text in list(errors.values()) + [words]), "\n".join(history)
+    assert attempt < 2, "\n".join(history)
+    warnings.warn(f"multi-rank attempt {attempt + 1} lost a rank (world {world}, d {d}); repeating.\n{report}")
   assert len(results) == world and all(c == 0 for c in codes), (codes, words)
   # every rank decoded the same floats from the same packed exchange
   keys = [k for k in results[0] if k != "shard"]
