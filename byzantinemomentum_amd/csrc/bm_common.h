@@ -91,7 +91,8 @@ __device__ __forceinline__ void sort_network(float (&x)[N]) {
 
 // Correctly rounded x / m for a small positive integer m given rm = 1.0f/m (Markstein
 // correction): three VALU ops instead of the ~10-op IEEE division sequence, same bits as
-// torch's `.div_(m)` (aggregators/krum.py:80, bulyan.py:70) except for subnormal quotients.
+// torch's `.div_(m)` (aggregators/krum.py:80, bulyan.py:70) except for subnormal quotients and the sign of a zero
+// quotient (-0 / m comes out as +0: equal as a value; tests/test_split_model.py checks the rest on a model).
 __device__ __forceinline__ float div_small_int(float x, float m, float rm) {
   const float q = x * rm;
   const float r = __builtin_fmaf(-q, m, x);

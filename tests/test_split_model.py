@@ -88,3 +88,38 @@ def test_structured_stacks_stay_within_1e5_with_the_dither():
   for name, rows in M.stacks(13, 1 << 16, rng).items():
     worst, _ = M.worst(rows, "dither")
     assert worst <= 1e-5, (name, worst)
+
+
+def test_markstein_division_by_a_small_integer_is_the_ieee_quotient():
+  """div_small_int (csrc/bm_common.h): q = x * (1/m), r = fma(-q, m, x), q1 = fma(r, 1/m, q) — three VALU ops in
+  place of the IEEE division sequence — gives the correctly rounded x / m, the bits of torch's `.div_(m)` (but for the sign of a zero quotient)
+  (aggregators/krum.py:80, bulyan.py:70, trmean.py:33), for every count m = 1..64 the rules divide by; non-finite
+  inputs keep the plain product.  Model: fp32 operations with the fused multiply-adds evaluated exactly (64-bit
+  mantissa: the 48-bit product and the cancelling sum are exact) and rounded once."""
+  f32 = np.float32
+  assert np.finfo(np.longdouble).nmant >= 63
+
+  def fma32(a, b, c):
+    return (a.astype(np.longdouble) * b.astype(np.longdouble) + c.astype(np.longdouble)).astype(np.float32)
+
+  def div_small_int(x, m):
+    mm = np.full_like(x, m, dtype=np.float32)
+    rm = (f32(1.0) / mm).astype(np.float32)
+    q = (x * rm).astype(np.float32)
+    with np.errstate(invalid="ignore"):
+      r = fma32(-q, mm, x)
+      q1 = fma32(r, rm, q)
+    return np.where(q1 == q1, q1, q)
+
+  rng = np.random.default_rng(0)
+  for m in range(1, 65):
+    x = (rng.standard_normal(60000) * np.exp2(rng.integers(-30, 30, 60000))).astype(np.float32)
+    x[:6] = np.array([0.0, -0.0, 1.0, float(m), 3.0 * m, 16777215.0], dtype=np.float32)
+    got, want = div_small_int(x, m), (x / f32(m)).astype(np.float32)
+    nonzero = want != 0
+    assert np.array_equal(got.view(np.uint32)[nonzero], want.view(np.uint32)[nonzero]), m
+    # a zero quotient comes out as +0 whatever its sign (fma(+0, m, -0) = +0): equal as a value, the one bit that differs
+    assert np.array_equal(got[~nonzero], np.zeros(int((~nonzero).sum()), dtype=np.float32)) and not np.signbit(got[~nonzero]).any()
+    edge = np.array([np.inf, -np.inf, np.nan], dtype=np.float32)
+    ge = div_small_int(edge, m)
+    assert ge[0] == np.inf and ge[1] == -np.inf and np.isnan(ge[2])
