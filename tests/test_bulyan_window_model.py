@@ -1,0 +1,78 @@
+"""Bulyan pass 2, the choice of the beta values closest to the median (aggregators/bulyan.py:79-82: `topk` of the
+smallest |selected - median| per column) as csrc/bulyan.hip makes it on a SORTED column — a model of its two forms:
+
+  long  : s = 1 + the last t in [0, theta-beta) with |sel[t] - med| > |sel[t+beta] - med|  (0 if none), window [s, s+beta);
+  short : the same search restricted to the t whose window straddles the median (BM_BULYAN_SHORT, the default).
+
+Checked here without a GPU, on every Bulyan shape the reference runs (and a few more) and on columns with ties,
+repeated medians and infinite values: (1) the two forms select windows holding the same values, and their fp32 sums
+— masked accumulation in index order, as the kernel writes it — have the same bits; (2) the window is a valid answer
+of the reference's `topk`: no value outside it is strictly closer to the median than a value inside it."""
+
+import numpy as np
+import pytest
+
+SHAPES = [(11, 2), (15, 3), (19, 2), (19, 4), (25, 5), (25, 3), (35, 5), (35, 8), (51, 12), (51, 5), (63, 15), (64, 1)]
+
+
+def _windows(sel, theta, beta):
+  """(start of the long form, start of the short form, fp32 sums of both) for one sorted column."""
+  med_i = (theta - 1) // 2
+  med = sel[med_i]
+  s_long = 0
+  for t in range(theta - beta):
+    if abs(sel[t] - med) > abs(sel[t + beta] - med):
+      s_long = t + 1
+  lo = max(med_i - beta + 1, 0)
+  tend = min(med_i, theta - beta)
+  iend = min(med_i + beta, theta)
+  s_short = lo
+  for t in range(lo, tend):
+    if abs(sel[t] - med) > abs(sel[t + beta] - med):
+      s_short = t + 1
+  w_long = np.float32(0.0)
+  for i in range(theta):
+    w_long = np.float32(w_long + (sel[i] if s_long <= i < s_long + beta else np.float32(0.0)))
+  w_short = np.float32(0.0)
+  for i in range(lo, iend):
+    w_short = np.float32(w_short + (sel[i] if s_short <= i < s_short + beta else np.float32(0.0)))
+  return s_long, s_short, w_long, w_short
+
+
+def _columns(rng, theta, count):
+  kinds = []
+  x = rng.standard_normal((count, theta)).astype(np.float32)
+  kinds.append(x)
+  kinds.append((np.round(x * 2) / 2).astype(np.float32))                          # ties everywhere
+  y = x.copy()
+  y[:, theta // 3: 2 * theta // 3 + 1] = y[:, [theta // 2]]                        # the median repeated
+  kinds.append(y)
+  z = x.copy()
+  z[:, :2] = -np.inf                                                             # infinite values at the ends (finite median)
+  z[:, -1:] = np.inf
+  kinds.append(z)
+  kinds.append(np.where(rng.random((count, theta)) < 0.5, np.float32(-0.0), np.float32(0.0)))  # zeros of both signs
+  kinds.append(rng.integers(-2, 3, (count, theta)).astype(np.float32))             # few distinct values
+  return np.sort(np.concatenate(kinds), axis=1)
+
+
+@pytest.mark.parametrize("n,f", SHAPES)
+def test_short_window_search_selects_what_the_long_one_selects(n, f):
+  theta, beta = n - 2 * f - 2, n - 4 * f - 2
+  assert beta >= 1
+  rng = np.random.default_rng(100 * n + f)
+  cols = _columns(rng, theta, 300)
+  med_i = (theta - 1) // 2
+  with np.errstate(invalid="ignore"):
+    for sel in cols:
+      if not np.isfinite(sel[med_i]):
+        continue  # (a wave that holds such a column takes the long form)
+      s_long, s_short, w_long, w_short = _windows(sel, theta, beta)
+      assert np.array_equal(sel[s_long:s_long + beta], sel[s_short:s_short + beta]), (n, f, sel, s_long, s_short)
+      assert w_long.tobytes() == w_short.tobytes(), (n, f, sel)
+      # a valid `topk` of the smallest deviations: nothing outside the window is strictly closer to the median
+      dev = np.abs(sel - sel[med_i])
+      inside = dev[s_long:s_long + beta]
+      outside = np.concatenate([dev[:s_long], dev[s_long + beta:]])
+      if outside.size:
+        assert inside.max() <= outside.min(), (n, f, sel, s_long)
