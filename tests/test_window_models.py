@@ -76,3 +76,30 @@ def test_short_window_search_selects_what_the_long_one_selects(n, f):
       outside = np.concatenate([dev[:s_long], dev[s_long + beta:]])
       if outside.size:
         assert inside.max() <= outside.min(), (n, f, sel, s_long)
+
+
+@pytest.mark.parametrize("n,f", [(5, 1), (11, 2), (11, 4), (25, 5), (25, 11), (51, 12), (51, 24), (64, 20), (64, 31)])
+def test_closest_to_centre_window_of_phocas_and_meamed_is_a_valid_topk(n, f):
+  """csrc/colwise_kernels.h, column_rule<PHOCAS|MEAMED>: on the sorted column the n - f values closest to the centre c
+  (trimmed mean or median: aggregators/trmean.py:35-50, `topk` of the smallest |g - c|) are the window [s, s + m) with
+  s = 1 + the last t < f such that |x[t] - c| > |x[t + m] - c|.  Model check: nothing outside that window is strictly
+  closer to c than something inside it — for centres that are column values (median), means of a part of the column
+  (trimmed mean) and arbitrary numbers, with ties and infinite values."""
+  m = n - f
+  rng = np.random.default_rng(7 * n + f)
+  cols = _columns(rng, n, 200)
+  with np.errstate(invalid="ignore", over="ignore"):
+    for x in cols:
+      centres = [x[(n - 1) // 2], np.float32(x[f:n - f].astype(np.float64).mean()), np.float32(rng.standard_normal())]
+      for c in centres:
+        if not np.isfinite(c):
+          continue
+        s = 0
+        for t in range(f):
+          if abs(x[t] - c) > abs(x[t + m] - c):
+            s = t + 1
+        dev = np.abs(x - c)
+        inside, outside = dev[s:s + m], np.concatenate([dev[:s], dev[s + m:]])
+        assert 0 <= s <= f and inside.size == m
+        if outside.size:
+          assert inside.max() <= outside.min(), (n, f, c, x, s)
