@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported before the CDLL, see above)
 _PKG_DIR = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _PKG_DIR / "libbm_gar.so"
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 MAX_ROWS = 64
 EINVAL = -100000
 ENOCOMM, ECOMM = -100001, -100002
@@ -46,6 +46,8 @@ SIGNATURES = {
                                       ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
   "bm_bulyan_pass2": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
+  "bm_bulyan_pass2_walk": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
   "bm_aksel_pass1": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
   "bm_stack_stats": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
@@ -108,6 +110,9 @@ SIGNATURES = {
   "bm_colwise_eval": (ctypes.c_int, [ctypes.c_int, _c_float_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p]),
+  "bm_colwise_eval_walk": (ctypes.c_int, [ctypes.c_int, _c_float_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p]),
   "bm_pairwise_rank": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_void_p]),

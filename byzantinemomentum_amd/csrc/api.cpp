@@ -27,7 +27,7 @@ const Tuning& tuning() {
 }
 }  // namespace bm
 
-extern "C" int bm_abi_version(void) { return 16; }
+extern "C" int bm_abi_version(void) { return 17; }
 
 extern "C" const char* bm_error_string(int code) {
   if (code == 0) return "success";

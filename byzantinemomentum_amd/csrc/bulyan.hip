@@ -198,7 +198,7 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_generic_kernel(
 
 template <int N, int F>
 static int launch_bulyan_fast(const float* const* rows_host, const int32_t* order, int64_t d_all,
-                              float* out_all, hipStream_t s) {
+                              float* out_all, int reverse, hipStream_t s) {
   constexpr int MMAX = N - F - 2;
   constexpr int kMaxVec = (MMAX <= 20) ? 4 : (MMAX <= 44 ? 2 : 1);
   int vec = common_vec_width(reinterpret_cast<const void* const*>(rows_host), N, out_all);
@@ -215,7 +215,7 @@ static int launch_bulyan_fast(const float* const* rows_host, const int32_t* orde
       hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 4 ? 4 : 1)>),
                          dim3(stream_grid(nvec, kBulBlock, kColMaxBlocks)), dim3(kBulBlock), 0,
                          s, tab, order, nvec, 1, out, tuning().bulyan_short,
-                         tuning().second_pass_reverse);
+                         reverse);
       BM_LAUNCH_CHECK();
       body = nvec * 4;
     } else if (vec == 2 && kMaxVec >= 2 && d / 2 > 0) {
@@ -223,7 +223,7 @@ static int launch_bulyan_fast(const float* const* rows_host, const int32_t* orde
       hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 2 ? 2 : 1)>),
                          dim3(stream_grid(nvec, kBulBlock, kColMaxBlocks)), dim3(kBulBlock), 0,
                          s, tab, order, nvec, 1, out, tuning().bulyan_short,
-                         tuning().second_pass_reverse);
+                         reverse);
       BM_LAUNCH_CHECK();
       body = nvec * 2;
     }
@@ -234,7 +234,7 @@ static int launch_bulyan_fast(const float* const* rows_host, const int32_t* orde
       hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, 1>),
                          dim3(stream_grid(rest, kBulBlock, kColMaxBlocks)), dim3(kBulBlock), 0,
                          s, tail, order, rest, 1, out + body, tuning().bulyan_short,
-                         tuning().second_pass_reverse);
+                         reverse);
       BM_LAUNCH_CHECK();
     }
   }
@@ -357,9 +357,12 @@ int64_t pairwise_workspace_bytes(int n, int64_t d);  // pairwise.hip
 
 }  // namespace bm
 
-extern "C" int bm_bulyan_pass2(const float* const* rows, int n, const int32_t* order, int f, int m,
-                               int64_t d, float* out, void* stream) {
+// walk: 0 = from the first column, 1 = from the last one, < 0 = the library's default (BM_SECOND_PASS_REVERSE).  The
+// register-resident instances honour it; the generic kernel walks forward.  The output does not depend on it.
+extern "C" int bm_bulyan_pass2_walk(const float* const* rows, int n, const int32_t* order, int f, int m,
+                                    int64_t d, float* out, int walk, void* stream) {
   using namespace bm;
+  const int reverse = walk < 0 ? tuning().second_pass_reverse : (walk != 0 ? 1 : 0);
   if (rows == nullptr || order == nullptr || (out == nullptr && d > 0) || n < 1 || n > BM_MAX_ROWS || f < 1 ||
       n < 4 * f + 3 || m < 1 || m > n - f - 2 || d < 0)
     return BM_EINVAL;
@@ -370,7 +373,7 @@ extern "C" int bm_bulyan_pass2(const float* const* rows, int n, const int32_t* o
     // register-resident instances for the (n, f) grid the reference exercises
     // (reproduce.py:139,182; reproduce-appendix.py:121-158) and their neighbours
 #define BM_BULYAN_CASE(NN, FF) \
-  if (n == NN && f == FF) return launch_bulyan_fast<NN, FF>(rows, order, d, out, s);
+  if (n == NN && f == FF) return launch_bulyan_fast<NN, FF>(rows, order, d, out, reverse, s);
     BM_BULYAN_CASE(11, 2)
     BM_BULYAN_CASE(15, 3)
     BM_BULYAN_CASE(19, 4)
@@ -401,6 +404,11 @@ extern "C" int bm_bulyan_pass2(const float* const* rows, int n, const int32_t* o
                      f, m, d, out);
   BM_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int bm_bulyan_pass2(const float* const* rows, int n, const int32_t* order, int f, int m,
+                               int64_t d, float* out, void* stream) {
+  return bm_bulyan_pass2_walk(rows, n, order, f, m, d, out, -1, stream);
 }
 
 extern "C" int bm_aksel_pass1(const float* const* rows, int n, int64_t d, float* median_out,

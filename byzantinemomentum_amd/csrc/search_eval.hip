@@ -26,7 +26,8 @@ constexpr int kEvalMaxBlocks = 2048;
 template <int N, int OP, int VEC>
 __global__ __launch_bounds__(kColBlock) void colwise_eval_kernel(RowTable rows, int h, const float* __restrict__ avg,
                                                                  const float* __restrict__ dir, float t, int64_t nvec,
-                                                                 int f, float inv_keep, double* __restrict__ partial) {
+                                                                 int f, float inv_keep, double* __restrict__ partial,
+                                                                 int reverse) {
   constexpr bool kNeedsLds = (OP == BM_OP_PHOCAS || OP == BM_OP_MEAMED);
   __shared__ float scratch[kNeedsLds ? N * kColBlock : 1];
   __shared__ double red[kColBlock / 64];
@@ -34,8 +35,14 @@ __global__ __launch_bounds__(kColBlock) void colwise_eval_kernel(RowTable rows, 
   float acc = 0.0f;
   double wide = 0.0;
   int since = 0;
-  const int64_t stride = (int64_t)gridDim.x * kColBlock;
-  for (int64_t v = (int64_t)blockIdx.x * kColBlock + threadIdx.x; v < nvec; v += stride) {
+  // Blocks of kColBlock column groups; `reverse` walks them from the last one (bm_colwise_eval_walk): the evaluations
+  // of a search read the same rows again and again, and a pass that starts where the previous one ended finds its
+  // first 256 MB in the Infinity Cache.  A lane then adds its columns in the opposite order: the objective agrees
+  // with the forward walk to the rounding of that sum (fp32 over <= 64 elements, fp64 beyond), not bit for bit.
+  const int64_t nblk = (nvec + kColBlock - 1) / kColBlock;
+  for (int64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+    const int64_t v = (reverse != 0 ? nblk - 1 - b : b) * kColBlock + threadIdx.x;
+    if (v >= nvec) continue;
     const int64_t j = v * VEC;
     float x[VEC][N];
     float a[VEC], dr[VEC];
@@ -85,7 +92,7 @@ __global__ __launch_bounds__(kEvalFinishThreads) void eval_finish_kernel(const d
 
 template <int N, int OP>
 static int launch_eval(const float* const* rows, int h, int64_t d, int f, const float* avg, const float* dir, float t,
-                       double* out, double* partial, hipStream_t s) {
+                       double* out, double* partial, int reverse, hipStream_t s) {
   constexpr int kMaxVec = (N <= 28) ? 4 : 2;
   const int keep = (OP == BM_OP_TRMEAN) ? (N - 2 * f) : (N - f);
   const float inv_keep = 1.0f / (float)(keep > 0 ? keep : 1);
@@ -103,10 +110,10 @@ static int launch_eval(const float* const* rows, int h, int64_t d, int f, const 
     const int grid = stream_grid(nvec, kColBlock, kEvalMaxBlocks);
     if (vec == 4)
       hipLaunchKernelGGL((colwise_eval_kernel<N, OP, (kMaxVec >= 4 ? 4 : 2)>), dim3(grid), dim3(kColBlock), 0, s, tab, h,
-                         avg, dir, t, nvec, f, inv_keep, partial);
+                         avg, dir, t, nvec, f, inv_keep, partial, reverse);
     else
       hipLaunchKernelGGL((colwise_eval_kernel<N, OP, 2>), dim3(grid), dim3(kColBlock), 0, s, tab, h, avg, dir, t, nvec,
-                         f, inv_keep, partial);
+                         f, inv_keep, partial, reverse);
     BM_LAUNCH_CHECK();
     nparts = grid;
     body = nvec * vec;
@@ -117,7 +124,7 @@ static int launch_eval(const float* const* rows, int h, int64_t d, int f, const 
     const int64_t rest = d - body;
     const int grid = (body == 0) ? stream_grid(rest, kColBlock, kEvalMaxBlocks) : 1;
     hipLaunchKernelGGL((colwise_eval_kernel<N, OP, 1>), dim3(grid), dim3(kColBlock), 0, s, tail, h, avg + body, dir + body,
-                       t, rest, f, inv_keep, partial + nparts);
+                       t, rest, f, inv_keep, partial + nparts, reverse);
     BM_LAUNCH_CHECK();
     nparts += grid;
   }
@@ -129,11 +136,11 @@ static int launch_eval(const float* const* rows, int h, int64_t d, int f, const 
 
 template <int N>
 static int launch_eval_op(int op, const float* const* rows, int h, int64_t d, int f, const float* avg, const float* dir,
-                          float t, double* out, double* partial, hipStream_t s) {
+                          float t, double* out, double* partial, int reverse, hipStream_t s) {
   switch (op) {
-    case BM_OP_TRMEAN: return launch_eval<N, BM_OP_TRMEAN>(rows, h, d, f, avg, dir, t, out, partial, s);
-    case BM_OP_PHOCAS: return launch_eval<N, BM_OP_PHOCAS>(rows, h, d, f, avg, dir, t, out, partial, s);
-    case BM_OP_MEAMED: return launch_eval<N, BM_OP_MEAMED>(rows, h, d, f, avg, dir, t, out, partial, s);
+    case BM_OP_TRMEAN: return launch_eval<N, BM_OP_TRMEAN>(rows, h, d, f, avg, dir, t, out, partial, reverse, s);
+    case BM_OP_PHOCAS: return launch_eval<N, BM_OP_PHOCAS>(rows, h, d, f, avg, dir, t, out, partial, reverse, s);
+    case BM_OP_MEAMED: return launch_eval<N, BM_OP_MEAMED>(rows, h, d, f, avg, dir, t, out, partial, reverse, s);
     default: return BM_EINVAL;
   }
 }
@@ -146,9 +153,11 @@ extern "C" int bm_colwise_eval_supported(int op, int n) {
 
 extern "C" int64_t bm_colwise_eval_workspace_bytes(void) { return (int64_t)(2 * bm::kEvalMaxBlocks) * (int64_t)sizeof(double); }
 
-extern "C" int bm_colwise_eval(int op, const float* const* honests, int h, int copies, int64_t d, int f,
-                               const float* avg, const float* dir, float t, double* out, void* ws, void* stream) {
+extern "C" int bm_colwise_eval_walk(int op, const float* const* honests, int h, int copies, int64_t d, int f,
+                                    const float* avg, const float* dir, float t, int walk, double* out, void* ws,
+                                    void* stream) {
   using namespace bm;
+  const int reverse = walk != 0 ? 1 : 0;
   const int n = h + copies;
   if (honests == nullptr || out == nullptr || ws == nullptr || h < 1 || copies < 1 || n > BM_MAX_ROWS || d < 0 || f < 0 ||
       n < 2 * f + 1 || (d > 0 && (avg == nullptr || dir == nullptr)) || !bm_colwise_eval_supported(op, n))
@@ -156,8 +165,13 @@ extern "C" int bm_colwise_eval(int op, const float* const* honests, int h, int c
   hipStream_t s = static_cast<hipStream_t>(stream);
   double* partial = static_cast<double*>(ws);
   switch (n) {
-    case 11: return launch_eval_op<11>(op, honests, h, d, f, avg, dir, t, out, partial, s);
-    case 25: return launch_eval_op<25>(op, honests, h, d, f, avg, dir, t, out, partial, s);
-    default: return launch_eval_op<51>(op, honests, h, d, f, avg, dir, t, out, partial, s);
+    case 11: return launch_eval_op<11>(op, honests, h, d, f, avg, dir, t, out, partial, reverse, s);
+    case 25: return launch_eval_op<25>(op, honests, h, d, f, avg, dir, t, out, partial, reverse, s);
+    default: return launch_eval_op<51>(op, honests, h, d, f, avg, dir, t, out, partial, reverse, s);
   }
+}
+
+extern "C" int bm_colwise_eval(int op, const float* const* honests, int h, int copies, int64_t d, int f,
+                               const float* avg, const float* dir, float t, double* out, void* ws, void* stream) {
+  return bm_colwise_eval_walk(op, honests, h, copies, d, f, avg, dir, t, 0, out, ws, stream);
 }

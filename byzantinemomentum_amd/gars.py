@@ -234,16 +234,22 @@ def bulyan_ranking(gradients, f, m=None, **kwargs):
   return order[:n].tolist()
 
 
-def bulyan_pass2(gradients, order, f, m):
-  """Second pass of Bulyan given the device-resident ranking (aggregators/bulyan.py:64-84)."""
+def bulyan_pass2(gradients, order, f, m, walk=None):
+  """Second pass of Bulyan given the device-resident ranking (aggregators/bulyan.py:64-84).
+  walk: None = the library's default (from the last column: where the distance pass finished), 0 / 1 = from the first /
+  last column (bm_bulyan_pass2_walk; same output — a caller that repeats the pass over the same rows alternates it)."""
   n, d, device = _validate(gradients)
   lib = _lib.load()
   out = torch.empty(d, dtype=torch.float32, device=device)
   if d == 0:
     return out
   with torch.cuda.device(device):
-    _lib.check(lib.bm_bulyan_pass2(_lib.pointer_table(gradients), n, _ptr(order), f, m, d, _ptr(out),
-                                   _stream(device)), "bm_bulyan_pass2")
+    if walk is None:
+      _lib.check(lib.bm_bulyan_pass2(_lib.pointer_table(gradients), n, _ptr(order), f, m, d, _ptr(out),
+                                     _stream(device)), "bm_bulyan_pass2")
+    else:
+      _lib.check(lib.bm_bulyan_pass2_walk(_lib.pointer_table(gradients), n, _ptr(order), f, m, d, _ptr(out),
+                                          1 if walk else 0, _stream(device)), "bm_bulyan_pass2_walk")
   return out
 
 

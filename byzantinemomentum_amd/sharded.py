@@ -115,8 +115,8 @@ class HipBackend:
   def selected_mean(self, gradients, order, m):
     return self.gars.selected_mean(gradients, order, m)
 
-  def bulyan_pass2(self, gradients, order, f, m):
-    return self.gars.bulyan_pass2(gradients, order, f, m)
+  def bulyan_pass2(self, gradients, order, f, m, walk=None):
+    return self.gars.bulyan_pass2(gradients, order, f, m, walk)
 
   def colwise(self, rule, gradients, f):
     return getattr(self.gars, rule)(gradients, f=f) if rule != "median" else self.gars.median(gradients)

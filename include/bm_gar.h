@@ -112,6 +112,13 @@ int bm_selected_mean(const float* const* rows, int n, const int32_t* idx, int m,
  * order is the DEVICE output of bm_krum_rank(mode BULYAN). */
 int bm_bulyan_pass2(const float* const* rows, int n, const int32_t* order, int f, int m,
                     int64_t d, float* out, void* stream);
+/* The same with the walk stated: 0 = from the first column, 1 = from the last one, < 0 = the library's default
+ * (bm_bulyan_pass2: from the last one, where the distance pass that produced `order` finished and whose neighbourhood
+ * the 256 MB Infinity Cache still holds).  The output does not depend on it; a caller that runs pass 2 repeatedly
+ * over the same rows (the factor search of attacks/identical.py:67-77 against Bulyan) alternates it, so that every
+ * pass starts where the previous one ended. */
+int bm_bulyan_pass2_walk(const float* const* rows, int n, const int32_t* order, int f, int m,
+                         int64_t d, float* out, int walk, void* stream);
 
 /* Aksel pass 1 (aggregators/aksel.py:35-41): coordinate-wise lower median
  * (written to median_out if non-NULL) and sq[i] = sum_j (rows[i][j]-median[j])^2. */
@@ -362,6 +369,12 @@ int bm_colwise_eval_supported(int op, int n);
 int64_t bm_colwise_eval_workspace_bytes(void);
 int bm_colwise_eval(int op, const float* const* honests, int h, int copies, int64_t d, int f, const float* avg,
                     const float* dir, float t, double* out, void* ws, void* stream);
+/* The same with the walk stated (0 = from the first column, as bm_colwise_eval; 1 = from the last one): the
+ * evaluations of one search read the same honest rows again and again, alternating the walk lets each start in what
+ * the previous one left in the Infinity Cache.  A lane adds its columns in the order of the walk: the two walks agree
+ * to the rounding of the objective's sum (fp32 over <= 64 elements per lane, fp64 beyond), not bit for bit. */
+int bm_colwise_eval_walk(int op, const float* const* honests, int h, int copies, int64_t d, int f, const float* avg,
+                         const float* dir, float t, int walk, double* out, void* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The factor search of the "identical" attacks (attacks/identical.py:67-77, the reference's default

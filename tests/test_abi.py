@@ -167,3 +167,19 @@ int main(void) {
   assert run.returncode == 0, (run.returncode, run.stdout, run.stderr)
   from byzantinemomentum_amd import _lib
   assert run.stdout.split() == ["abi", str(_lib.ABI_VERSION), "ok"]
+
+
+def test_walk_entry_points_validate_arguments_without_gpu(lib):
+  """bm_bulyan_pass2_walk, bm_colwise_eval_walk (ABI 17): the argument checks of the entry points they extend."""
+  from byzantinemomentum_amd import _lib
+  rows = (ctypes.c_void_p * 64)()
+  for walk in (-1, 0, 1):
+    assert lib.bm_bulyan_pass2_walk(rows, 25, None, 5, 18, 1000, rows, walk, None) == _lib.EINVAL      # no ranking
+    assert lib.bm_bulyan_pass2_walk(rows, 22, rows, 5, 15, 1000, rows, walk, None) == _lib.EINVAL      # n < 4 f + 3
+    assert lib.bm_bulyan_pass2_walk(rows, 25, rows, 5, 19, 1000, rows, walk, None) == _lib.EINVAL      # m > n - f - 2
+    assert lib.bm_bulyan_pass2_walk(rows, 25, rows, 5, 18, 0, None, walk, None) == 0                   # an empty shard
+  tail = (rows, rows, ctypes.c_float(1.0))
+  assert lib.bm_colwise_eval_walk(_lib.OP_MEDIAN, rows, 20, 5, 1000, 5, *tail, 1, rows, rows, None) == _lib.EINVAL
+  assert lib.bm_colwise_eval_walk(_lib.OP_TRMEAN, rows, 19, 5, 1000, 5, *tail, 1, rows, rows, None) == _lib.EINVAL
+  assert lib.bm_colwise_eval_walk(_lib.OP_TRMEAN, rows, 20, 5, 1000, 5, None, rows, ctypes.c_float(1.0), 0, rows, rows, None) == _lib.EINVAL
+  assert lib.bm_abi_version() == 17
