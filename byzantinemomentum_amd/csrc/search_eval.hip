@@ -23,11 +23,10 @@ namespace bm {
 
 constexpr int kEvalMaxBlocks = 2048;
 
-template <int N, int OP, int VEC>
+template <int N, int OP, int VEC, bool REV = false>
 __global__ __launch_bounds__(kColBlock) void colwise_eval_kernel(RowTable rows, int h, const float* __restrict__ avg,
                                                                  const float* __restrict__ dir, float t, int64_t nvec,
-                                                                 int f, float inv_keep, double* __restrict__ partial,
-                                                                 int reverse) {
+                                                                 int f, float inv_keep, double* __restrict__ partial) {
   constexpr bool kNeedsLds = (OP == BM_OP_PHOCAS || OP == BM_OP_MEAMED);
   __shared__ float scratch[kNeedsLds ? N * kColBlock : 1];
   __shared__ double red[kColBlock / 64];
@@ -35,14 +34,19 @@ __global__ __launch_bounds__(kColBlock) void colwise_eval_kernel(RowTable rows, 
   float acc = 0.0f;
   double wide = 0.0;
   int since = 0;
-  // Blocks of kColBlock column groups; `reverse` walks them from the last one (bm_colwise_eval_walk): the evaluations
-  // of a search read the same rows again and again, and a pass that starts where the previous one ended finds its
-  // first 256 MB in the Infinity Cache.  A lane then adds its columns in the opposite order: the objective agrees
-  // with the forward walk to the rounding of that sum (fp32 over <= 64 elements, fp64 beyond), not bit for bit.
-  const int64_t nblk = (nvec + kColBlock - 1) / kColBlock;
-  for (int64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
-    const int64_t v = (reverse != 0 ? nblk - 1 - b : b) * kColBlock + threadIdx.x;
-    if (v >= nvec) continue;
+  // REV (bm_colwise_eval_walk with walk = 1, its own instances: the forward kernel is the code it always was): the
+  // blocks of kColBlock column groups are walked from the last one.  The evaluations of a search read the same rows
+  // again and again, and a pass that starts where the previous one ended finds its first 256 MB in the Infinity
+  // Cache.  A lane then adds its columns in the opposite order: the objective agrees with the forward walk to the
+  // rounding of that sum (fp32 over <= 64 elements, fp64 beyond), not bit for bit.
+  const int64_t stride = (int64_t)gridDim.x * kColBlock;
+  const int64_t top = ((nvec + kColBlock - 1) / kColBlock) * kColBlock;
+  for (int64_t v0 = (int64_t)blockIdx.x * kColBlock + threadIdx.x; v0 < (REV ? top : nvec); v0 += stride) {
+    int64_t v = v0;
+    if constexpr (REV) {
+      v = top - kColBlock - v0 + 2 * (int64_t)threadIdx.x;  // block nblk - 1 - b, same lane
+      if (v >= nvec) continue;
+    }
     const int64_t j = v * VEC;
     float x[VEC][N];
     float a[VEC], dr[VEC];
@@ -108,12 +112,10 @@ static int launch_eval(const float* const* rows, int h, int64_t d, int f, const 
   if (vec >= 2 && d / vec > 0) {
     const int64_t nvec = d / vec;
     const int grid = stream_grid(nvec, kColBlock, kEvalMaxBlocks);
-    if (vec == 4)
-      hipLaunchKernelGGL((colwise_eval_kernel<N, OP, (kMaxVec >= 4 ? 4 : 2)>), dim3(grid), dim3(kColBlock), 0, s, tab, h,
-                         avg, dir, t, nvec, f, inv_keep, partial, reverse);
-    else
-      hipLaunchKernelGGL((colwise_eval_kernel<N, OP, 2>), dim3(grid), dim3(kColBlock), 0, s, tab, h, avg, dir, t, nvec,
-                         f, inv_keep, partial, reverse);
+    auto kern = vec == 4 ? (reverse ? colwise_eval_kernel<N, OP, (kMaxVec >= 4 ? 4 : 2), true>
+                                    : colwise_eval_kernel<N, OP, (kMaxVec >= 4 ? 4 : 2), false>)
+                         : (reverse ? colwise_eval_kernel<N, OP, 2, true> : colwise_eval_kernel<N, OP, 2, false>);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kColBlock), 0, s, tab, h, avg, dir, t, nvec, f, inv_keep, partial);
     BM_LAUNCH_CHECK();
     nparts = grid;
     body = nvec * vec;
@@ -123,8 +125,9 @@ static int launch_eval(const float* const* rows, int h, int64_t d, int f, const 
     for (int i = 0; i < h; ++i) tail.p[i] = rows[i] + body;
     const int64_t rest = d - body;
     const int grid = (body == 0) ? stream_grid(rest, kColBlock, kEvalMaxBlocks) : 1;
+    // (the ragged tail — at most three columns behind a vector body — walks forward whatever the walk)
     hipLaunchKernelGGL((colwise_eval_kernel<N, OP, 1>), dim3(grid), dim3(kColBlock), 0, s, tail, h, avg + body, dir + body,
-                       t, rest, f, inv_keep, partial + nparts, reverse);
+                       t, rest, f, inv_keep, partial + nparts);
     BM_LAUNCH_CHECK();
     nparts += grid;
   }
