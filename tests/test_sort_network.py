@@ -108,3 +108,46 @@ def test_networks_sort_floats_with_ties_infinities_and_signed_zeros(tables):
     assert np.array_equal(got, np.sort(x, axis=1)), n           # (-0.0 == 0.0 compare equal: any order of the two passes)
     # the rules read ranks of the sorted column: lower median (n-1)//2 (median.py:39), ranks f..n-f-1 (trmean.py:33)
     assert np.array_equal(got[:, (n - 1) // 2], np.sort(x, axis=1)[:, (n - 1) // 2])
+
+
+TRI = r'''
+#include <cstdio>
+#include "gram_split.h"
+int main() {
+  for (int n = 1; n <= 64; ++n) {
+    printf("%d", n);
+    for (int i = 0; i < n; ++i)
+      for (int j = i; j < n; ++j) printf(" %d", bm::b3_tri_index(i, j, n));
+    printf("\n");
+  }
+  // launch-shape helpers of bm_common.h
+  printf("grid %d %d %d %d\n", bm::stream_grid(0, 256, 16384), bm::stream_grid(1, 256, 16384),
+         bm::stream_grid(257, 256, 16384), bm::stream_grid((int64_t)1 << 40, 256, 16384));
+  const void* p[3] = {(void*)0x1000, (void*)0x2010, (void*)0x3020};
+  const void* q[2] = {(void*)0x1008, (void*)0x2010};
+  const void* r[2] = {(void*)0x1004, (void*)0x2010};
+  printf("vec %d %d %d %d\n", bm::common_vec_width(p, 3, nullptr), bm::common_vec_width(q, 2, nullptr),
+         bm::common_vec_width(r, 2, nullptr), bm::common_vec_width(p, 3, (void*)0x4004));
+  return 0;
+}
+'''
+
+
+def test_triangle_index_and_launch_helpers_of_the_headers(tmp_path):
+  """b3_tri_index (csrc/gram_split.h) — where the Gram kernel, its reduction and the distance kernel all look up entry
+  (i, j) of the compact upper triangle — is a bijection onto 0 .. n(n+1)/2 - 1 in row-major order for every n <= 64;
+  stream_grid and common_vec_width (csrc/bm_common.h) answer as documented.  Host-only compilation of the headers."""
+  hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+  if not pathlib.Path(hipcc).exists():
+    pytest.skip("hipcc not here")
+  (tmp_path / "tri.cpp").write_text(TRI)
+  subprocess.run([hipcc, "-std=c++17", "-O1", "-x", "hip", "--offload-host-only", "-I",
+                  str(ROOT / "byzantinemomentum_amd" / "csrc"), str(tmp_path / "tri.cpp"), "-o", str(tmp_path / "tri")],
+                 check=True, capture_output=True)
+  lines = subprocess.run([str(tmp_path / "tri")], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+  for line in lines[:64]:
+    nums = list(map(int, line.split()))
+    n, idx = nums[0], nums[1:]
+    assert idx == list(range(n * (n + 1) // 2)), n   # row-major over i <= j: consecutive, no gap, no repeat
+  assert lines[64].split() == ["grid", "1", "1", "2", "16384"]
+  assert lines[65].split() == ["vec", "4", "2", "1", "1"]
