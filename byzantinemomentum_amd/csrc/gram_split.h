@@ -54,7 +54,7 @@ __device__ __forceinline__ void split3(const f32x4 x, u32x2& h, u32x2& m, u32x2&
 // the accuracy gate) instead of a random walk sqrt(d) times smaller.  All rows share the dither of a
 // coordinate, so bitwise-equal rows still give bitwise-equal planes (exact ties survive), and rows that are
 // close get the same rounding direction most of the time (their l's largely cancel in l_i - l_j).
-__device__ __forceinline__ unsigned dither_pair(unsigned coord) {
+__host__ __device__ __forceinline__ unsigned dither_pair(unsigned coord) {  // (host too: tests/test_sort_network.py pins the numpy model on it)
   // two 16-bit words for coordinates coord, coord + 1 from one 32-bit mix of the (even) coordinate index
   unsigned z = coord * 0x9E3779B1u + 0x7F4A7C15u;
   z ^= z >> 15;

@@ -151,3 +151,38 @@ def test_triangle_index_and_launch_helpers_of_the_headers(tmp_path):
     assert idx == list(range(n * (n + 1) // 2)), n   # row-major over i <= j: consecutive, no gap, no repeat
   assert lines[64].split() == ["grid", "1", "1", "2", "16384"]
   assert lines[65].split() == ["vec", "4", "2", "1", "1"]
+
+
+DITHER = r'''
+#include <cstdio>
+#include "gram_split.h"
+int main() {
+  const unsigned coords[] = {0u, 2u, 4u, 62u, 64u, 1000u, 11173960u, 36546978u, 0x7ffffffeu, 0xfffffffeu};
+  for (unsigned c : coords) printf("%u %u\n", c, bm::dither_pair(c));
+  return 0;
+}
+'''
+
+
+def test_numpy_model_of_the_dither_is_the_kernels_hash(tmp_path):
+  """dither_pair (csrc/gram_split.h: two 16-bit dither words for coordinates c, c + 1 from one mix of the even
+  coordinate index) compiled for the host, against dither16 of scripts/probes/dither_model.py — the model on which
+  tests/test_split_model.py checks the split's properties is the kernel's own hash."""
+  import importlib.util
+  hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+  if not pathlib.Path(hipcc).exists():
+    pytest.skip("hipcc not here")
+  (tmp_path / "dither.cpp").write_text(DITHER)
+  subprocess.run([hipcc, "-std=c++17", "-O1", "-x", "hip", "--offload-host-only", "-I",
+                  str(ROOT / "byzantinemomentum_amd" / "csrc"), str(tmp_path / "dither.cpp"), "-o", str(tmp_path / "dither")],
+                 check=True, capture_output=True)
+  out = subprocess.run([str(tmp_path / "dither")], check=True, capture_output=True, text=True).stdout.split()
+  spec = importlib.util.spec_from_file_location("dither_model", ROOT / "scripts" / "probes" / "dither_model.py")
+  model = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(model)
+  pairs = list(zip(map(int, out[0::2]), map(int, out[1::2])))
+  assert len(pairs) == 10
+  for coord, z in pairs:
+    lo, hi = z & 0xFFFF, z >> 16
+    got = model.dither16(np.array([coord, coord + 1], dtype=np.uint64))
+    assert [int(got[0]), int(got[1])] == [lo, hi], coord
