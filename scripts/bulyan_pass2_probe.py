@@ -1,7 +1,11 @@
-"""A/B of Bulyan pass 2 forms: `BM_BUL_BURST=0|8 python scripts/bulyan_pass2_probe.py` in ONE gpurun call — the checksums
-of the two runs must agree to the last digit before the burst form may become the default.
-Time bm_bulyan_pass2 alone at C4 (n=25, f=5, d=11 173 962) or C-like sizes; run it once per value of an
-environment knob (the library reads its knobs once per process) for A/B comparisons inside one gpurun call."""
+"""Time bm_bulyan_pass2 ALONE (given rankings) at C4 (n=25, f=5, d=11 173 962) and two neighbours, once per value of an
+environment knob of the library — which reads its knobs once per process — for A/B comparisons inside ONE gpurun call:
+
+    for v in 0 1 0 1; do BM_BULYAN_SHORT=$v python scripts/bulyan_pass2_probe.py; done
+
+(knobs of this kernel: BM_BULYAN_SHORT, the window search; BM_SECOND_PASS_REVERSE, where the walk starts — for the
+latter use scripts/second_pass_walk_probe.py, which runs the distance pass before it: the walk only matters through what
+that pass leaves in the Infinity Cache).  The checksums of the runs must agree to the last digit."""
 import os
 import sys
 
@@ -43,7 +47,7 @@ def main():
       us.append(a.elapsed_time(b) * 1e3 / reps)
     us.sort()
     nbytes = 4 * d * (m + 1)
-    print(f"lib={os.environ.get('BM_PROBE_LIB', 'in-tree')} BM_BUL_BURST={os.environ.get('BM_BUL_BURST', 'default')} n={n} f={f}: pass 2 {us[rounds // 2]:.1f} us per call "
+    print(f"lib={os.environ.get('BM_PROBE_LIB', 'in-tree')} BM_BULYAN_SHORT={os.environ.get('BM_BULYAN_SHORT', 'default')} n={n} f={f}: pass 2 {us[rounds // 2]:.1f} us per call "
           f"(best round {us[0]:.1f}) = {nbytes / us[rounds // 2] / 1e3:.0f} GB/s for {m}+1 rows; checksum {float(out.double().sum()):.9f}")
     del stacks
     torch.cuda.empty_cache()
