@@ -22,7 +22,7 @@ const Tuning& tuning() {
                            env_int("BM_PAIR_PLANES", 0), env_int("BM_PAIR_DITHER", 0), env_double("BM_PAIR_TAU", 2e-3),
                            env_int("BM_STUDY_BURST", 8), env_int("BM_STEP_STAGGER_US", 0),
                            env_int("BM_GRAM_STEADY", 1), env_int("BM_BULYAN_SHORT", 1),
-                           env_int("BM_SECOND_PASS_REVERSE", 1)};
+                           env_int("BM_PAIR_LOAD_NT", 1), env_int("BM_SECOND_PASS_REVERSE", 1)};
   return t;
 }
 }  // namespace bm

@@ -283,6 +283,7 @@ struct Tuning {
   int step_stagger_us; // BM_STEP_STAGGER_US: start every other workgroup of an XCD this many microseconds late in the fused first pass of a Krum / Bulyan step (0 = off)
   int gram_steady;     // BM_GRAM_STEADY: 1 (default) = the condition-free steady-state loop of the Gram kernel, 0 = the generic loop only (A/B)
   int bulyan_short;    // BM_BULYAN_SHORT: 1 (default) = Bulyan pass 2 searches its window among the positions that straddle the median only (same bits), 0 = all positions (A/B)
+  int pair_load_nt;    // BM_PAIR_LOAD_NT: 1 (default) = the Gram kernel's row loads carry the non-temporal hint, 0 = default cache policy (aligned rows; A/B with BM_SECOND_PASS_REVERSE: does the tail of the rows stay in the Infinity Cache for the second pass?)
   int second_pass_reverse;  // BM_SECOND_PASS_REVERSE: 1 (default) = the second pass of a two-pass rule (selected mean, Bulyan pass 2) walks the columns from the END: the distance pass before it finished there, and what the 256 MB Infinity Cache still holds of the rows is their tail (same bits; 0 = from the start, A/B)
 };
 const Tuning& tuning();

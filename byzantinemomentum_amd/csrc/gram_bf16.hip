@@ -78,7 +78,11 @@ struct B3Shape {
   static constexpr int kLds = kPtrBytes + (kB3Waves * WS > kRedBytes ? kB3Waves * WS : kRedBytes);
 };
 
-template <int K, int NPL, bool ALIGNED>
+// NT: the 16-byte row loads carry the non-temporal hint (the default: every byte is read once by this kernel).  The
+// NT = false instances (BM_PAIR_LOAD_NT=0, aligned rows only, experiments) load with the default policy: the second
+// pass of Krum / Bulyan reads the same rows again, starting where this kernel finished, and whether the Infinity Cache
+// still holds that tail may depend on the hint — unmeasured.  The NT = true code is the code it always was.
+template <int K, int NPL, bool ALIGNED, bool NT = true>
 __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_partial_kernel(
     RowTable rows, int n, int64_t d, float inv_n, int centre, unsigned dither_seed, double* __restrict__ partial,
     int* __restrict__ arrival, int steady) {
@@ -149,7 +153,10 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const int r = 4 * k + rho;  // (rows >= n: the table repeats row n - 1)
-        v[k] = __builtin_nontemporal_load(reinterpret_cast<const GlobalF4*>((GlobalF)row_ptr[r] + coord));
+        if constexpr (NT)
+          v[k] = __builtin_nontemporal_load(reinterpret_cast<const GlobalF4*>((GlobalF)row_ptr[r] + coord));
+        else
+          v[k] = *reinterpret_cast<const GlobalF4*>((GlobalF)row_ptr[r] + coord);
       }
     } else {
       // ragged last chunk / rows that are not 16-byte aligned: guarded scalar loads, zero fill
@@ -316,7 +323,10 @@ __global__ __launch_bounds__(64 * kB3Waves, (B3Shape<K, NPL>::MINW)) void gram3_
 #pragma unroll
       for (int k = 0; k < K; ++k) {
         const int r = 4 * k + rho;  // (rows >= n: the table repeats row n - 1)
-        v[k] = __builtin_nontemporal_load(reinterpret_cast<const GlobalF4*>((GlobalF)row_ptr[r] + coord));
+        if constexpr (NT)
+          v[k] = __builtin_nontemporal_load(reinterpret_cast<const GlobalF4*>((GlobalF)row_ptr[r] + coord));
+        else
+          v[k] = *reinterpret_cast<const GlobalF4*>((GlobalF)row_ptr[r] + coord);
       }
     };
     if (steady != 0 && c + (2 * NSETS - 1) * nw < full) {  // (steady == 0: BM_GRAM_STEADY=0, the A/B against the generic loop)
@@ -487,7 +497,9 @@ template <int K, int NPL>
 static int launch_gram3_planes(const RowTable& tab, int n, int64_t d, bool aligned, int centre, double* partial,
                                int* arrival, int blocks, hipStream_t s) {
   using S = B3Shape<K, NPL>;
-  auto kern = aligned ? gram3_partial_kernel<K, NPL, true> : gram3_partial_kernel<K, NPL, false>;
+  auto kern = aligned ? (tuning().pair_load_nt != 0 ? gram3_partial_kernel<K, NPL, true, true>
+                                                    : gram3_partial_kernel<K, NPL, true, false>)
+                      : gram3_partial_kernel<K, NPL, false, true>;
   if (S::kLds > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, S::kLds);

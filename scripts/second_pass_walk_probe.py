@@ -1,11 +1,12 @@
 """A/B of the walking order of the second pass of the two-pass rules:
 
-    for r in 0 1 0 1; do BM_SECOND_PASS_REVERSE=$r python scripts/second_pass_walk_probe.py; done
+    for nt in 1 0; do for r in 0 1 0 1; do BM_PAIR_LOAD_NT=$nt BM_SECOND_PASS_REVERSE=$r python scripts/second_pass_walk_probe.py; done; done
 
 in ONE gpurun call (the library reads its knobs once per process; boxes differ by more than the effect).  Whole rules —
 distance pass, ranking, second pass — on two alternating stacks at the bench's shapes, so that the second pass of a
 call finds in the Infinity Cache what the distance pass of the SAME call left there and nothing of the previous call;
-plus the 2-rank and 8-rank shard lengths of C4 (where 46 % / all of the shard is still cached).  The checksums of the two
+plus the 2-rank and 8-rank shard lengths of C4 (where 46 % / all of the shard is still cached).  BM_PAIR_LOAD_NT=0 makes the distance pass load with the default cache
+policy instead of the non-temporal hint (the hint may be what keeps the rows out of the cache).  The checksums of the two
 settings must agree to the last digit: the walk does not change a column's arithmetic."""
 import os
 import sys
@@ -27,7 +28,7 @@ def stack(n, f, d, dev, gen):
 
 def main():
   dev = torch.device("cuda:0")
-  knob = os.environ.get("BM_SECOND_PASS_REVERSE", "default(1)")
+  knob = os.environ.get("BM_SECOND_PASS_REVERSE", "default(1)") + " BM_PAIR_LOAD_NT=" + os.environ.get("BM_PAIR_LOAD_NT", "default(1)")
   cases = [("krum C3", 51, 12, D, lambda st, f: bm.krum(st, f)),
            ("bulyan C4", 25, 5, D, lambda st, f: bm.bulyan(st, f)),
            ("bulyan C4, shard of 2 ranks", 25, 5, -(-D // 2), lambda st, f: bm.bulyan(st, f)),

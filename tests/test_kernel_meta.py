@@ -15,8 +15,8 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent
 HOT = [
   (r"colwise_burst_kernel<25, 0, 4>", 128),          # C2 median
   (r"colwise_burst_kernel<25, 1, 4>", 128),          # C2 trimmed mean
-  (r"gram3_partial_kernel<7, 2, true>", 168),        # C4 distance pass (n = 25, two planes)
-  (r"gram3_partial_kernel<13, 2, true>", 256),       # C3 distance pass (n = 51)
+  (r"gram3_partial_kernel<7, 2, true, (true|false)>", 168),        # C4 distance pass (n = 25, two planes)
+  (r"gram3_partial_kernel<13, 2, true, (true|false)>", 256),       # C3 distance pass (n = 51)
   (r"bulyan_pass2_kernel<25, 5, 4>", 128),           # C4 pass 2
   (r"selected_mean_burst_kernel", 128),              # C3 average of the selected rows
   (r"momentum_gram_kernel<20, false, false>", 256),  # C5 first pass with the distance pass riding along
