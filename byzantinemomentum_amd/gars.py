@@ -304,18 +304,36 @@ def brute_selection(gradients, f, **kwargs):
   n = len(gradients)
   sel, status = _brute_sel(gradients, f)
   if int(status.item()) != 0:
-    raise RuntimeError("brute: too many non-finite gradients, no subset of n-f rows has a finite diameter")
+    raise RuntimeError(BRUTE_NO_SUBSET)
   return sel[:n - f].tolist()
 
 
-def brute(gradients, f, **kwargs):
+BRUTE_NO_SUBSET = "brute: too many non-finite gradients, no subset of n-f rows has a finite diameter"
+last_brute_status = None   # int32[1] device tensor of the latest brute(): 0, or -1 when no subset was admissible
+
+
+def brute_check(status=None):
+  """Raise when the latest (or the given) Brute search found no admissible subset — the reference's assertion
+  (brute.py:68).  Synchronises (one 4-byte read); not to be called while a stream is being captured."""
+  status = last_brute_status if status is None else status
+  if status is not None and int(status.item()) != 0:
+    raise RuntimeError(BRUTE_NO_SUBSET)
+
+
+def brute(gradients, f, check=False, **kwargs):
   """Brute rule (aggregators/brute.py:70-80): mean of the minimum-diameter subset, index order.  Distances, subset
   search and average all run on the device, on the caller's stream: no host synchronisation (graph-capturable).  When
   no subset of n-f rows has a finite diameter — more than f gradients with non-finite coordinates, where the reference
-  has no selection at all (brute.py:56-57,68) — the result is the average of n-f copies of one such gradient, i.e.
-  non-finite where it is; `brute_selection` raises in that case."""
+  fails its assertion (brute.py:56-57,68) — the search reports status -1: it is kept in `last_brute_status`
+  (device), `brute_check()` / `brute_selection` raise on it, and `check=True` (what the `native-brute` plugin passes)
+  raises here, at the price of one host synchronisation, unless the stream is being captured into a graph.  Unchecked,
+  the result is then the average of n-f copies of one bad gradient, i.e. non-finite where that gradient is."""
+  global last_brute_status
   n, d, device = _validate(gradients)
-  sel, _ = _brute_sel(gradients, f)
+  sel, status = _brute_sel(gradients, f)
+  last_brute_status = status
+  if check and not torch.cuda.is_current_stream_capturing():
+    brute_check(status)
   return selected_mean(gradients, sel, n - f)
 
 

@@ -29,7 +29,18 @@ import torch.distributed as dist
 
 from . import _lib
 
-__all__ = ["shard_bounds", "owned_workers", "ShardedAggregator", "HipBackend", "NativeComm"]
+__all__ = ["shard_bounds", "owned_workers", "Shards", "ShardedAggregator", "HipBackend", "NativeComm"]
+
+
+class Shards(list):
+  """The n gradients restricted to this rank's coordinate slice, which KNOW the length of the whole vectors
+  (`d_total`): what `ShardedAggregator.to_dim_sharded` and `shard_rows` return.  The distance-based rules read the
+  total from it, so that an aggregator serves any sequence of vector lengths (per-layer aggregation, several
+  models) without a collective to find the total out and without guessing."""
+
+  def __init__(self, rows=(), d_total=None):
+    super().__init__(rows)
+    self.d_total = None if d_total is None else int(d_total)
 
 
 def shard_bounds(d, world_size, rank, align=64):
@@ -131,7 +142,8 @@ class HipBackend:
     return self.gars.brute_select_host(dist_host, n, f)
 
   def brute_select_device(self, sq, n, f):
-    return self.gars.brute_select_device(sq, n, f)[0]
+    """(sel, status) on the device; status -1 = no subset of n - f rows has a finite diameter (brute.py:68)."""
+    return self.gars.brute_select_device(sq, n, f)
 
   def sharded_rule(self, name, comm, gradients, f, m, d_total=None):
     """Multi-Krum / Bulyan of the local slice in one C call (bm_sharded_krum / bm_sharded_bulyan);
@@ -231,13 +243,27 @@ class ShardedAggregator:
           raise RuntimeError(f"libbm_gar RCCL communicator unavailable on at least one rank ({failure})")
         warnings.warn(f"libbm_gar RCCL communicator unavailable ({failure}); using torch.distributed collectives")
         self.single_call = False
+    self.brute_status = None
     self._total = None        # (length of the whole vectors, this rank's shard length when it was determined)
+
+  def shard_rows(self, rows, d=None):
+    """This rank's slice (shard_bounds) of n whole gradients held on every rank, as `Shards` carrying the total."""
+    d = int(rows[0].shape[0]) if d is None else int(d)
+    lo, hi = shard_bounds(d, self.world_size, self.rank)
+    return Shards([r[lo:hi] for r in rows], d_total=d)
+
+  def _total_of(self, local, d_total=None):
+    """Total length for a distance pass over `local`: stated, else carried by the shards, else `total_length`."""
+    if d_total is None:
+      d_total = getattr(local, "d_total", None)
+    return self.total_length(local[0].numel(), d_total)
 
   def total_length(self, d_local, d_total=None):
     """Length of the WHOLE vectors (all shards), the number every rank must hand to the distance pass so that a
     short or empty trailing shard plans it exactly like its peers (bm_gar.h, bm_sharded_krum).
 
-    Stated by the caller (`d_total`), or determined ONCE per aggregator: the first call sums the shard lengths over
+    Stated by the caller (`d_total`, or carried by `Shards`: to_dim_sharded / shard_rows), or, for plain lists,
+    determined ONCE per aggregator: the first call sums the shard lengths over
     the ranks (one tiny all-reduce, which every rank enters because every rank makes its first call), later calls
     return that number without any communication.  An aggregator therefore serves ONE vector length; a rank that
     notices another shard length raises instead of guessing — deciding locally whether to repeat the collective could
@@ -337,7 +363,8 @@ class ShardedAggregator:
     """Worker-major -> dimension-major in ONE all-to-all (the step before the
     path when the honest gradients are PRODUCED in parallel, experiments/model.py:333-366 run once per
     worker).  `my_gradients`: the full-length gradients of owned_workers(n, P, rank), in that order.
-    Returns the n gradients restricted to this rank's coordinate slice (shard_bounds), in worker order:
+    Returns the n gradients restricted to this rank's coordinate slice (shard_bounds), in worker order, as `Shards`
+    (they carry d, so the distance-based rules need neither a d_total argument nor a collective to learn it):
     views into one receive buffer, 256-byte aligned, ready for the rules.  Each rank sends (P-1)/P of
     what it produced — n/P * d * 4 bytes spread over the P-1 peers' links at once — never more."""
     world, rank = self.world_size, self.rank
@@ -345,7 +372,7 @@ class ShardedAggregator:
     if len(my_gradients) != len(mine):
       raise ValueError(f"rank {rank} must pass the gradients of workers {mine}")
     if not self.collective:  # (one rank with forced collectives still goes through the exchange: that is how a
-      return list(my_gradients)  #  single-GPU box exercises the RCCL all-to-all)
+      return Shards(my_gradients, d_total=d)  #  single-GPU box exercises the RCCL all-to-all)
     per = -(-(-(-d // world)) // 64) * 64    # padded shard length: ceil(d / P) rounded up to 64 coordinates (256 B)
     n_max = -(-n // world)
     # a rank that owns no worker (n < P) still takes part in the exchange with an all-zero send buffer:
@@ -363,7 +390,7 @@ class ShardedAggregator:
     recv = torch.empty_like(send)
     self._all_to_all(recv.view(-1), send.view(-1))
     lo, hi = shard_bounds(d, world, rank)
-    return [recv[i % world, i // world, :hi - lo] for i in range(n)]
+    return Shards([recv[i % world, i // world, :hi - lo] for i in range(n)], d_total=d)
 
   # -- rules ------------------------------------------------------------------ #
 
@@ -383,7 +410,7 @@ class ShardedAggregator:
     """All-reduced n x n squared-distance matrix (every rank gets the same bits: the sum runs over
     the same P partial matrices in the collective's fixed order)."""
     # the precision plan follows the length of the whole vectors, the same number on every rank (total_length)
-    sq = self.backend.pairwise_sqdist(local, d_total=self.total_length(local[0].numel(), d_total))  # fresh, reduced in place
+    sq = self.backend.pairwise_sqdist(local, d_total=self._total_of(local, d_total))  # fresh, reduced in place
     self._all_reduce(sq)
     return sq
 
@@ -392,7 +419,7 @@ class ShardedAggregator:
     if m is None:
       m = n - f - 2
     if self.single_call:
-      return self.backend.sharded_rule("krum", self.native, local, f, m, self.total_length(local[0].numel(), d_total))
+      return self.backend.sharded_rule("krum", self.native, local, f, m, self._total_of(local, d_total))
     order = self.backend.rank(self.global_sqdist(local, d_total), n, f, m, _lib.RANK_KRUM)
     return self.backend.selected_mean(local, order, m)
 
@@ -401,7 +428,7 @@ class ShardedAggregator:
     if m is None:
       m = n - f - 2
     if self.single_call:
-      return self.backend.sharded_rule("bulyan", self.native, local, f, m, self.total_length(local[0].numel(), d_total))
+      return self.backend.sharded_rule("bulyan", self.native, local, f, m, self._total_of(local, d_total))
     order = self.backend.rank(self.global_sqdist(local, d_total), n, f, m, _lib.RANK_BULYAN)
     return self.backend.bulyan_pass2(local, order, f, m)
 
@@ -426,13 +453,22 @@ class ShardedAggregator:
 
   def brute(self, local, f, d_total=None):
     """Brute rule: all-reduced distances, then the (deterministic) subset search on every rank — on the device with
-    the HIP backend (same bits in, same selection out on every rank, no host round trip)."""
+    the HIP backend (same bits in, same selection out on every rank, no host round trip).  The search's status is
+    kept in `self.brute_status` (device int32[1]); `check_brute()` raises when no subset was admissible, which
+    AggregationStep.floats() does at the step's one synchronisation."""
     n = len(local)
     sq = self.global_sqdist(local, d_total)
     if hasattr(self.backend, "brute_select_device"):
-      return self.backend.selected_mean(local, self.backend.brute_select_device(sq, n, f), n - f)
+      sel, self.brute_status = self.backend.brute_select_device(sq, n, f)
+      return self.backend.selected_mean(local, sel, n - f)
     sel = self.backend.brute_select(sq.sqrt().cpu().contiguous(), n, f)
     return self.backend.selected_mean(local, self.backend.index_tensor(sel, local[0]), n - f)
+
+  def check_brute(self):
+    """Raise (the reference's assertion, brute.py:68) when the latest brute() found no admissible subset; syncs."""
+    status = getattr(self, "brute_status", None)
+    if status is not None and int(status.item()) != 0:
+      raise RuntimeError("brute: too many non-finite gradients, no subset of n-f rows has a finite diameter")
 
   def average(self, local):
     n = len(local)

@@ -242,7 +242,7 @@ class AggregationStep:
         # first pass + the distance pass of the rule in one call (one kernel at h = 20 for long gradients)
         s_avg, h_avg, byz, fused_sq, out6 = ops.momentum_stats_sqdist(
           sampled, self.buffers, self.mu, omd, factors, self.factor, self.attack, self.f_real,
-          d_total=agg.total_length(sampled[0].shape[0]))
+          d_total=agg._total_of(sampled))
       elif self.attack_evals is None:
         s_avg, h_avg, byz, out6 = ops.momentum_stats(sampled, self.buffers, self.mu, omd, factors, self.factor, self.attack)
       else:  # the attack direction alone; the Byzantine vector follows the factor search
@@ -274,7 +274,7 @@ class AggregationStep:
       elif plain_update and self.gar in ("krum", "bulyan") and not (set(self.gar_args) - {"m"}) \
           and hasattr(ops, "stack_stats_sqdist"):
         h_avg, byz, fused_sq, o6 = ops.stack_stats_sqdist(honests, self.factor, self.attack, self.f_real,
-                                                          d_total=agg.total_length(sampled[0].shape[0]))
+                                                          d_total=agg._total_of(sampled))
         h_out3 = o6[3:]
       elif self.attack_evals is None:
         h_avg, h_out3, byz = ops.stack_stats(honests, scale=self.factor, attack=self.attack)
@@ -345,7 +345,7 @@ class AggregationStep:
       self.agg.native, sampled, self.buffers, self.n, self.f_decl, self.f_real, self.gar, self.gar_args.get("m"),
       self.mu, omd, self.clip, self.attack, self.factor, self.nb_past, count,
       self.pasts[0] if count > 0 else None, self._curv, self.pasts[-1] if full else None, params, origin,
-      d_total=self.agg.total_length(sampled[0].shape[0]))
+      d_total=self.agg._total_of(sampled))
     self._update = defense
     self.last_byzantine = byz
     self._pending = dict(packed=stats, prev=self._prev_stats if count > 0 else None, npast=2 if count > 0 else 0,
@@ -414,6 +414,8 @@ class AggregationStep:
       raise RuntimeError("floats() needs a run() first")
     if pend["floats"] is not None:
       return pend["floats"]
+    if self.gar == "brute":
+      self.agg.check_brute()  # the reference's assertion (brute.py:68), at the step's synchronisation point
     if "packed" in pend:
       pend["floats"] = self._floats_from_packed(pend)
       return pend["floats"]

@@ -50,7 +50,8 @@ def _median_aggregate(gradients):
 
 def _brute_aggregate(gradients, f):
   _late_bind()
-  return _gars.brute(gradients, f)
+  # check=True: the reference asserts that a subset with a finite diameter exists (brute.py:68); so does the plugin
+  return _gars.brute(gradients, f, check=True)
 
 
 krum = _Rule("krum", _krum_aggregate, "Multi-Krum, see byzantinemomentum_amd.gars.krum")

@@ -394,58 +394,6 @@ def test_sharded_aggregator_hip_backend_single_rank(bm):
   assert torch.equal(avg, want[0]) and (norm, devi, mx) == want[1:]
 
 
-def test_rccl_path_on_one_gpu(bm):
-  """One-rank NCCL(=RCCL) process group with forced collectives: the exact code path of the
-  multi-GPU runs (all-reduce of the fp64 distance matrix, all-gather of the output)."""
-  import torch.distributed as dist
-  from byzantinemomentum_amd.sharded import ShardedAggregator
-  import os
-  import socket
-  with socket.socket() as s:
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-  dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
-  try:
-    rows, h = O.make_stack("hetero", 25, 5, 40007, seed=18)
-    dev = to_dev(rows)
-    agg = ShardedAggregator(force_collectives=True)
-    assert agg.collective
-    assert agg.native is not None and agg.single_call   # libbm_gar's own RCCL communicator, one C call per rule
-    out = agg.bulyan(dev, 5)
-    assert torch.equal(out, bm.bulyan(dev, 5))
-    assert torch.equal(agg.all_gather_output(out, 40007), out)
-    assert torch.equal(agg.krum(dev, 5), bm.krum(dev, 5))
-    want = bm.compute_avg_dev_max(dev[:h])
-    got = agg.compute_avg_dev_max(dev[:h])
-    assert torch.equal(got[0], want[0]) and got[1:] == want[1:]
-    # the torch.distributed form of the same rules (native_comm=False) must give the same bits
-    plain = ShardedAggregator(force_collectives=True, native_comm=False)
-    assert plain.native is None and not plain.single_call
-    assert torch.equal(plain.bulyan(dev, 5), out) and torch.equal(plain.krum(dev, 5), bm.krum(dev, 5))
-    # worker-major -> dimension-major (SURVEY 8e/f4): the all-to-all really goes through RCCL here (one rank, forced
-    # collectives); with one rank the layout it returns is every gradient restricted to [0, d): the inputs themselves,
-    # as contiguous 256-byte aligned views of ONE receive buffer, accepted as they are by the rules
-    for d_odd in (40007, 64, 1):
-      grads = [g[:d_odd].contiguous() for g in dev[:7]]
-      local = agg.to_dim_sharded(grads, 7, d_odd)
-      assert len(local) == 7 and all(torch.equal(a, b) for a, b in zip(local, grads))
-      assert all(t.is_contiguous() and t.data_ptr() % 256 == 0 for t in local)
-      assert local[0].untyped_storage().data_ptr() == local[6].untyped_storage().data_ptr()
-      assert torch.equal(agg.median(local), bm.median(grads)) and torch.equal(agg.krum(local, 1), bm.krum(grads, 1))
-    # a whole step through forced collectives equals the step without any
-    from byzantinemomentum_amd.step import AggregationStep
-    a = AggregationStep(25, 5, 5, gar="bulyan", nb_past=2, aggregator=agg)
-    b = AggregationStep(25, 5, 5, gar="bulyan", nb_past=2)
-    for it in range(3):
-      sampled = [g * (1.0 + 0.1 * it) for g in dev[:h]]
-      assert torch.equal(a.run(sampled), b.run([g.clone() for g in sampled]))
-      fa, fb = a.floats(), b.floats()
-      assert all(fa[k] == fb[k] or (math.isnan(fa[k]) and math.isnan(fb[k])) for k in fa)
-  finally:
-    dist.destroy_process_group()
-
-
 def test_influence_hooks_match_reference_semantics(bm):
   """`native` influence functions: fraction of the selected gradients that ARE attack tensors
   (aggregators/krum.py:126-150, brute.py:118-140, aksel.py:83-105), from the selected indices."""

@@ -167,3 +167,36 @@ def test_single_process_issues_no_collective():
   assert agg.world_size == 1
   assert torch.equal(agg.krum(rows, F), O.krum(rows, F))
   assert torch.equal(agg.all_gather_output(agg.median(rows), 257), O.median(rows))
+
+
+def test_one_rank_forced_collectives_serves_every_length():
+  """CPU twin of tests/test_gpu_y_rccl_one_rank.py's length loop: ONE aggregator with forced collectives (one-rank
+  gloo group) serves vectors of several lengths, because `to_dim_sharded` / `shard_rows` hand out `Shards` that carry
+  the total length; plain lists of another length need `d_total=` and are otherwise refused with a message."""
+  from byzantinemomentum_amd.sharded import ShardedAggregator, Shards
+  from tests.sharded_backend import OracleBackend
+  os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+  dist.init_process_group("gloo", rank=0, world_size=1)
+  try:
+    rows, h = O.make_stack("hetero", 7, 1, 4100, seed=18)
+    agg = ShardedAggregator(backend=OracleBackend(), force_collectives=True)
+    assert agg.collective
+    assert torch.equal(agg.krum(rows, 1), O.krum(rows, 1))          # a plain list: the total is determined once (4100)
+    for d_odd in (4007, 64, 1):
+      grads = [g[:d_odd].contiguous() for g in rows]
+      local = agg.to_dim_sharded(grads, 7, d_odd)
+      assert isinstance(local, Shards) and local.d_total == d_odd and len(local) == 7
+      assert all(torch.equal(a, b) for a, b in zip(local, grads))
+      assert torch.equal(agg.median(local), O.median(grads))
+      assert torch.equal(agg.krum(local, 1), O.krum(grads, 1))
+      assert torch.allclose(agg.bulyan(local, 1), O.bulyan(grads, 1), rtol=0, atol=2e-6)
+      assert torch.equal(agg.brute(local, 1), O.brute(grads, 1))
+      assert agg.backend.totals_seen[-1] == d_odd
+    short = [g[:100].contiguous() for g in rows]
+    with pytest.raises(ValueError, match="d_total"):
+      agg.krum(short, 1)
+    assert torch.equal(agg.krum(short, 1, d_total=100), O.krum(short, 1))
+    assert torch.equal(agg.krum(agg.shard_rows(short), 1), O.krum(short, 1))
+    assert torch.equal(agg.krum(rows, 1), O.krum(rows, 1))          # the first length is still served
+  finally:
+    dist.destroy_process_group()
