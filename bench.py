@@ -360,7 +360,7 @@ def sharded_extras(bm, agg, dist, device, world, rank, timer, args, rule_name, d
   the unsharded rule on rank 0 alone for the speed-up of this exact workload.  Every figure is the max over the ranks.
   The per_gar entries go into `out` and the top-level `exchange` object into `extra` leg by leg, so that a deadline that
   fires in a later leg keeps what the earlier ones measured; `extra` also receives single_gpu_same_workload."""
-  from byzantinemomentum_amd.sharded import owned_workers, shard_bounds
+  from byzantinemomentum_amd.sharded import Shards, owned_workers, shard_bounds
   n, f = (51, 12) if rule_name == "krum" else (25, 5)
   m = n - f - 2
   # the path's one real exchange, at the top level of the line (a SCALE record then carries it, not only the
@@ -372,7 +372,8 @@ def sharded_extras(bm, agg, dist, device, world, rank, timer, args, rule_name, d
     "layout_exchange_ms": None, "single_gpu_ms": None, "speedup_vs_1gpu": None,
     "collectives": "libbm_gar's own RCCL communicator" if agg.native is not None else "torch.distributed (RCCL)"}
   lo, hi = shard_bounds(d_total, world, rank)
-  stacks = make_stacks(n, f, hi - lo, device, 2, 4321 + rank, args.aliased_byz)
+  # (Shards: the shards state the length of the whole vectors, whatever other lengths this aggregator has served)
+  stacks = [Shards(st, d_total=d_total) for st in make_stacks(n, f, hi - lo, device, 2, 4321 + rank, args.aliased_byz)]
   rule = agg.krum if rule_name == "krum" else agg.bulyan
   rule_bytes = 4 * d_total * n + 4 * d_total * (m + 1)
   tag = f"n={n}, f={f}, total d={d_total} over {world} ranks, max over ranks"
@@ -630,8 +631,9 @@ def main():
     gen = torch.Generator(device=device).manual_seed(77 + rank)
     mu_vec = 0.1 * torch.randn(d, device=device, generator=gen)
     # (one allocation per sampled gradient: for the step that placement measured best)
-    sets = [[mu_vec + s * torch.randn(d, device=device, generator=gen) for s in torch.linspace(0.5, 1.5, h).tolist()]
-            for _ in range(2)]
+    from byzantinemomentum_amd.sharded import Shards
+    sets = [Shards([mu_vec + s * torch.randn(d, device=device, generator=gen) for s in torch.linspace(0.5, 1.5, h).tolist()],
+                   d_total=d_total) for _ in range(2)]
     aggs_per_step = 1
     algo_bytes = {"step": step_algorithmic_bytes(d_total, n, f, args.gar)}
 
@@ -647,7 +649,8 @@ def main():
   else:
     n, f = (51, 12) if workload == "krum" else (25, 5)
     m = n - f - 2
-    stacks = make_stacks(n, f, d, device, 2, 4321 + rank, args.aliased_byz)
+    from byzantinemomentum_amd.sharded import Shards
+    stacks = [Shards(st, d_total=d_total) for st in make_stacks(n, f, d, device, 2, 4321 + rank, args.aliased_byz)]
     aggs_per_step = 1
     algo_bytes = {workload: 4 * d_total * n + 4 * d_total * (m + 1)}
     rule = agg.krum if workload == "krum" else agg.bulyan

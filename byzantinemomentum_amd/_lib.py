@@ -16,7 +16,7 @@ import torch  # noqa: F401  (must be imported before the CDLL, see above)
 _PKG_DIR = pathlib.Path(__file__).resolve().parent
 LIB_PATH = _PKG_DIR / "libbm_gar.so"
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 MAX_ROWS = 64
 EINVAL = -100000
 ENOCOMM, ECOMM = -100001, -100002
@@ -32,6 +32,7 @@ _c_float_pp = ctypes.POINTER(ctypes.c_void_p)
 # name -> (restype, argtypes); mirrors include/bm_gar.h one to one
 SIGNATURES = {
   "bm_abi_version": (ctypes.c_int, []),
+  "bm_tuning_set": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int]),
   "bm_error_string": (ctypes.c_char_p, [ctypes.c_int]),
   "bm_colwise": (ctypes.c_int, [ctypes.c_int, _c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
                                 ctypes.c_void_p, ctypes.c_void_p]),

@@ -1,5 +1,6 @@
 // api.cpp — ABI bookkeeping and host-only entry points of libbm_gar.so.
 #include <stdlib.h>
+#include <string.h>
 #include <math.h>
 #include <algorithm>
 #include <vector>
@@ -16,18 +17,42 @@ static double env_double(const char* name, double dflt) {
   if (v == nullptr || *v == '\0') return dflt;
   return atof(v);
 }
-const Tuning& tuning() {
-  static const Tuning t = {env_int("BM_COL_BURST", 8),  env_int("BM_MEAN_BURST", 8),
+Tuning& tuning_mutable() {
+  static Tuning t = {env_int("BM_COL_BURST", 8),  env_int("BM_MEAN_BURST", 8),
                            env_int("BM_STEP_BURST", 8), env_int("BM_STEP_STREAM", 0), env_int("BM_PAIR_MODE", 0),
                            env_int("BM_PAIR_PLANES", 0), env_int("BM_PAIR_DITHER", 0), env_double("BM_PAIR_TAU", 2e-3),
                            env_int("BM_STUDY_BURST", 8), env_int("BM_STEP_STAGGER_US", 0),
                            env_int("BM_GRAM_STEADY", 1), env_int("BM_BULYAN_SHORT", 1),
-                           env_int("BM_PAIR_LOAD_NT", 1), env_int("BM_SECOND_PASS_REVERSE", 1)};
+                           env_int("BM_PAIR_LOAD_NT", 1), env_int("BM_COL_ROTATE", 0), env_int("BM_COL_PAGE_STRIDE", 0),
+                           env_int("BM_SECOND_PASS_REVERSE", 0)};
   return t;
 }
+const Tuning& tuning() { return tuning_mutable(); }
 }  // namespace bm
 
-extern "C" int bm_abi_version(void) { return 17; }
+extern "C" int bm_abi_version(void) { return 18; }
+
+// Launch-shape knobs of the A/B runs, settable inside one process (the environment is read once, at the first call):
+// alternating two settings on the same data, on the same box, is the only comparison that resolves a 1 % effect.
+extern "C" int bm_tuning_set(const char* name, int value) {
+  using namespace bm;
+  if (name == nullptr) return BM_EINVAL;
+  Tuning& t = tuning_mutable();
+  const struct { const char* key; int* slot; } knobs[] = {
+      {"BM_COL_BURST", &t.col_burst}, {"BM_MEAN_BURST", &t.mean_burst}, {"BM_STEP_BURST", &t.step_burst},
+      {"BM_STEP_STREAM", &t.step_stream}, {"BM_PAIR_MODE", &t.pair_mode}, {"BM_PAIR_PLANES", &t.pair_planes},
+      {"BM_PAIR_DITHER", &t.pair_dither}, {"BM_STUDY_BURST", &t.study_burst},
+      {"BM_STEP_STAGGER_US", &t.step_stagger_us}, {"BM_GRAM_STEADY", &t.gram_steady},
+      {"BM_BULYAN_SHORT", &t.bulyan_short}, {"BM_PAIR_LOAD_NT", &t.pair_load_nt},
+      {"BM_COL_ROTATE", &t.col_rotate}, {"BM_COL_PAGE_STRIDE", &t.col_page_stride},
+      {"BM_SECOND_PASS_REVERSE", &t.second_pass_reverse}};
+  for (const auto& k : knobs)
+    if (strcmp(name, k.key) == 0) {
+      *k.slot = value;
+      return 0;
+    }
+  return BM_EINVAL;
+}
 
 extern "C" const char* bm_error_string(int code) {
   if (code == 0) return "success";

@@ -215,6 +215,9 @@ class AggregationStep:
     Returns the aggregated gradient (slice); statistics stay on the device until floats()."""
     ops, agg, h = self.ops, self.agg, self.h
     sampled = list(grad_sampleds)
+    if getattr(grad_sampleds, "d_total", None) is not None:  # sharded.Shards: keep the stated total length
+      from .sharded import Shards
+      sampled = Shards(sampled, d_total=grad_sampleds.d_total)
     ks = len(sampled)
     if ks < h:
       raise ValueError(f"{ks} sampled gradients for {h} honest workers")

@@ -46,6 +46,10 @@ enum bm_colwise_op {
 
 /* ABI version of this header; bumped on any signature change. */
 int bm_abi_version(void);
+/* Sets one launch-shape knob by the name of its environment variable (BM_COL_BURST, BM_SECOND_PASS_REVERSE, ...:
+ * csrc/bm_common.h, struct Tuning) for the calls that follow — for A/B measurements inside one process; results never
+ * depend on a knob.  BM_EINVAL for an unknown name.  Not thread-safe against running calls. */
+int bm_tuning_set(const char* name, int value);
 
 /* Human-readable text for a code returned by any entry point. */
 const char* bm_error_string(int code);

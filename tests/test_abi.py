@@ -182,4 +182,4 @@ def test_walk_entry_points_validate_arguments_without_gpu(lib):
   assert lib.bm_colwise_eval_walk(_lib.OP_MEDIAN, rows, 20, 5, 1000, 5, *tail, 1, rows, rows, None) == _lib.EINVAL
   assert lib.bm_colwise_eval_walk(_lib.OP_TRMEAN, rows, 19, 5, 1000, 5, *tail, 1, rows, rows, None) == _lib.EINVAL
   assert lib.bm_colwise_eval_walk(_lib.OP_TRMEAN, rows, 20, 5, 1000, 5, None, rows, ctypes.c_float(1.0), 0, rows, rows, None) == _lib.EINVAL
-  assert lib.bm_abi_version() == 17
+  assert lib.bm_abi_version() == 18

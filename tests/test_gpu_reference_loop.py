@@ -97,6 +97,14 @@ CASES = [
   ("krum", 25, 5, "empire", ["factor:-16"], "worker", True),  # the attacks' default: line search through the rule
   ("bulyan", 25, 5, "empire", ["factor:1.1"], "worker", True),
   ("aksel", 25, 5, "little", ["factor:1.5"], "update", True),
+  # the rest of the reference's own GAR set (reproduce.py:109: krum, median, trmean, phocas, meamed, bulyan) at its
+  # n = 25, f = 5 (reproduce.py:165-209), and the two selection-free / norm-based rules of the registry
+  ("phocas", 25, 5, "empire", ["factor:1.1"], "server", True),
+  ("meamed", 25, 5, "little", ["factor:1.5", "negative:True"], "update", True),
+  ("trmean", 25, 5, "little", ["factor:1.5"], "worker", True),
+  ("median", 25, 11, "empire", ["factor:1.1"], "update", True),
+  ("cge", 11, 2, "empire", ["factor:1.1"], "worker", True),
+  ("average", 11, 2, "little", ["factor:1.5"], "server", True),
 ]
 
 
