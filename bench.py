@@ -895,11 +895,23 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
           out["krum_c3_m1"] = entry(ms_1, 4 * d * n + 4 * d * 2, config=f"classic krum (m=1), n={n}, f={f}, d={d}, one GPU")
         except Exception as err:  # noqa: BLE001  (a side entry must not take the line down)
           out["krum_c3_m1"] = {"error": repr(err)}
+      if "BM_BENCH_CHILD" not in os.environ:
+        # the reference's largest worker count (reproduce.py:122-162: all six rules at n = 51) at the ResNet-18 length
+        for key, fn51, rows_out in (("median_n51", lambda st: bm.median(st), 1), ("trmean_n51", lambda st: bm.trmean(st, f), 1),
+                                    ("phocas_n51", lambda st: bm.phocas(st, f), 1), ("meamed_n51", lambda st: bm.meamed(st, f), 1),
+                                    ("bulyan_n51", lambda st: bm.bulyan(st, f), None), ("aksel_n51", lambda st: bm.aksel(st, f), None)):
+          try:
+            ms_51 = timed_loop(lambda i: fn51(stacks[i & 1]), 8, 2, timer, key)
+            nbytes = (4 * d * (n + 1) if rows_out == 1 else
+                      4 * d * n + 4 * d * (m + 1) if key == "bulyan_n51" else 4 * d * n + 4 * d * ((n + 1) // 2 + 1))
+            out[key] = entry(ms_51, nbytes, config=f"{key.split('_')[0]}, n={n}, f={f}, d={d}, one GPU")
+          except Exception as err:  # noqa: BLE001  (a side entry must not take the line down)
+            out[key] = {"error": repr(err)}
       ms_b = timed_loop(lambda i: bm.brute(stacks[i & 1], f), 12, 3, timer, "brute_c3")
       out["brute_c3"] = entry(ms_b, 4 * d * n + 4 * d * (n - f + 1),
                               config=f"brute.py:32-80, n={n}, f={f} (1.6e11 subsets: not enumerable; the subset of smallest "
-                                     f"diameter searched by one wave on the device, bm_brute_select_device: no host round "
-                                     f"trip), d={d}")
+                                     f"diameter searched by one workgroup of 16 waves on the device, bm_brute_select_device: no "
+                                     f"host round trip), d={d}")
     else:
       if cpu_baseline:
         c4_sample = _host_copy(stacks[0])
@@ -923,7 +935,7 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
       ms_b = timed_loop(lambda i: bm.brute(stacks[i & 1], f), 12, 3, timer, "brute_n25")
       out["brute_n25"] = entry(ms_b, 4 * d * n + 4 * d * (n - f + 1),
                                config=f"brute.py:32-80, n={n}, f={f} (the first of the 53 130 subsets of smallest diameter, found "
-                                      f"by one wave on the device without enumerating them, bm_brute_select_device: no host "
+                                      f"by one workgroup on the device without enumerating them, bm_brute_select_device: no host "
                                       f"round trip), d={d}")
       if "BM_BENCH_CHILD" not in os.environ:
         # the headline's column rules on the OTHER row placement, same process (what placement is worth)

@@ -44,11 +44,15 @@ __device__ __forceinline__ int wave_max_i32(int v) {
   return v;
 }
 
+constexpr int kBruteNodeBudgetPerWave = 1 << 18;  // search-tree nodes per wave and launch (~0.1 us each)
+
 struct BruteWave {
   const double* dist;  // LDS, [n][n], symmetric, non-finite where the reference's distance is
   uint64_t* stack;     // LDS, the open alternatives of the search tree (wave-uniform values)
   int n, lane;
   uint64_t adj;        // this lane's row of G(t)
+  int nodes;           // search-tree nodes visited so far by this wave (all has_clique calls of the launch)
+  bool exhausted;      // the budget ran out: the answers of this wave no longer mean anything
 
   __device__ void build(double t) {
     uint64_t a = 0;
@@ -70,6 +74,10 @@ struct BruteWave {
     int top = 0;
     bool have = true;
     for (;;) {
+      if (++nodes > kBruteNodeBudgetPerWave) {
+        exhausted = true;
+        return false;
+      }
       if (!have) {
         if (top == 0) return false;
         cand = stack[--top];
@@ -115,27 +123,72 @@ struct BruteWave {
 
 }  // namespace
 
-// sel_out: BM_MAX_ROWS int32, the n - f selected rows ascending, then zeros.  status[0]: 0, or -1 when every subset
+// sel_out: BM_MAX_ROWS int32, the n - f selected rows ascending, then zeros.  status[0]: 0; -1 when every subset
 // touches a non-finite distance (the reference then has no selection at all, brute.py:56-57,68): sel_out then holds
 // n - f copies of the first row ALL of whose distances are non-finite (a gradient with a non-finite coordinate), so
-// that the average that follows is non-finite where that row is instead of looking like a result.
-__global__ __launch_bounds__(64) void brute_select_kernel(const double* __restrict__ sq, int n, int f,
-                                                          int32_t* __restrict__ sel_out, int32_t* __restrict__ status) {
+// that the average that follows is non-finite where that row is instead of looking like a result; -2 when a wave
+// used up its budget of search-tree nodes (kBruteNodeBudgetPerWave: the tree is exponential in f in the worst case and
+// crafted distance matrices are this library's threat model — a stream must not be held for seconds): sel_out is
+// then all zeros and the caller raises (bm_brute_select, the host search, has no such limit).
+//
+// ONE workgroup of kBruteWaves waves.  The three phases of the search are the host's (api.cpp), but the questions
+// "does G(t) hold n - f mutually adjacent rows" are asked kBruteWaves at a time:
+//   1. wave 0 asks it for the largest finite distance (is there a selection at all?), wave 1 for t = 0;
+//   2. the smallest such t: every round, wave w takes the open candidate (a finite distance strictly between the
+//      bounds) number (2w+1)/(2W) of the way through the row-major enumeration of the open ones — W pivots that are
+//      random in VALUE — and the bounds close in on the tightest answers: the open set shrinks ~W/2-fold per round
+//      (n = 25: 300 pairs, 3 rounds; n = 51: 1 275 pairs, 4 rounds) instead of 2-fold per sequential probe;
+//   3. the lexicographically first set in G(t*): the W lowest rows still in play are tried at once, the lowest one
+//      that extends is taken; as soon as what is left has exactly the size that is needed, it IS the rest.
+// Every wave keeps the (wave-uniform) state of the search itself and recomputes the cheap parts; only the W answers
+// of a round travel through LDS.  The answers are those of the sequential search: G(t) only grows with t, and the
+// extraction takes the same row at every position.
+constexpr int kBruteWaves = 16;
+
+__global__ __launch_bounds__(64 * kBruteWaves) void brute_select_kernel(const double* __restrict__ sq, int n, int f,
+                                                                        int32_t* __restrict__ sel_out,
+                                                                        int32_t* __restrict__ status) {
   __shared__ double dist[BM_MAX_ROWS * BM_MAX_ROWS];
-  __shared__ uint64_t stack[BM_MAX_ROWS + 4];
-  const int lane = threadIdx.x;
+  __shared__ uint64_t stacks[kBruteWaves][BM_MAX_ROWS + 4];
+  __shared__ double piv[kBruteWaves];
+  __shared__ int res[kBruteWaves];   // 1 / 0: the answer of wave w this round; -1: it asked nothing
+  __shared__ int over[kBruteWaves];  // wave w ran out of its node budget
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int k = n - f;
   // distances as the host path forms them: sqrt of the squared ones, only the [x][y], x < y entries are read
-  for (int e = lane; e < n * n; e += 64) {
+  for (int e = tid; e < n * n; e += 64 * kBruteWaves) {
     const int i = e / n, j = e - i * n;
     dist[e] = (i == j) ? 0.0 : __builtin_sqrt(sq[i < j ? i * n + j : j * n + i]);
   }
+  if (lane == 0) over[wave] = 0;
   __syncthreads();
-  BruteWave w{dist, stack, n, lane, 0};
+  BruteWave w{dist, stacks[wave], n, lane, 0, 0, false};
   const uint64_t everyone = n == 64 ? ~(uint64_t)0 : (((uint64_t)1 << n) - 1);
-
-  // candidates: 0 and every finite distance > 0 (pairs i < j: lane i enumerates j > i)
   auto in_range = [&](double v, double lo, double hi) { return __builtin_fabs(v) < __builtin_inf() && v > lo && v < hi; };
+  // one round of answers: wave w publishes (pivot, answer), everybody reads all of them
+  auto publish = [&](double pivot, int answer) {
+    if (lane == 0) {
+      piv[wave] = pivot;
+      res[wave] = answer;
+      if (w.exhausted) over[wave] = 1;
+    }
+    __syncthreads();
+  };
+  auto any_over = [&]() {
+    int o = 0;
+#pragma unroll
+    for (int v = 0; v < kBruteWaves; ++v) o |= over[v];
+    return o != 0;
+  };
+  auto give_up = [&](int code, int fill) {
+    if (wave == 0) {
+      if (lane < BM_MAX_ROWS) sel_out[lane] = (lane < k) ? fill : 0;
+      if (lane == 0) status[0] = code;
+    }
+  };
+
+  // ---- 1. the largest finite distance (wave 0) and zero (wave 1) ----
   double vmax = 0.0;
   if (lane < n)
     for (int j = lane + 1; j < n; ++j) {
@@ -147,8 +200,17 @@ __global__ __launch_bounds__(64) void brute_select_kernel(const double* __restri
     const double o = __shfl_xor(vmax, off, 64);
     vmax = o > vmax ? o : vmax;
   }
-  w.build(vmax);
-  if (!w.has_clique(everyone, k)) {
+  int answer = -1;
+  if (wave < 2) {
+    w.build(wave == 0 ? vmax : 0.0);
+    answer = w.has_clique(everyone, k) ? 1 : 0;
+  }
+  publish(0.0, answer);
+  const bool feasible = res[0] == 1, at_zero = res[1] == 1;
+  const bool over1 = any_over();
+  __syncthreads();  // (everybody has read the answers before the next round overwrites them)
+  if (over1) return give_up(-2, 0);
+  if (!feasible) {
     // a row whose distances are ALL non-finite (a gradient with a non-finite coordinate); else one that has any
     int all_bad = 64, any_bad = 64;
     if (lane < n && n > 1) {
@@ -161,31 +223,33 @@ __global__ __launch_bounds__(64) void brute_select_kernel(const double* __restri
     all_bad = -wave_max_i32(-all_bad);
     any_bad = -wave_max_i32(-any_bad);
     const int bad = all_bad < 64 ? all_bad : any_bad;
-    if (lane < BM_MAX_ROWS) sel_out[lane] = (lane < k && bad < 64) ? bad : 0;
-    if (lane == 0) status[0] = -1;
-    return;
+    return give_up(-1, bad < 64 ? bad : 0);
   }
-  // invariant: G(hi) holds k mutually adjacent rows, G(lo) does not (lo = -1: nothing is known below 0)
-  double lo = -1.0, hi = vmax;
-  w.build(0.0);
-  if (w.has_clique(everyone, k)) {
-    hi = 0.0;
-  } else {
-    lo = 0.0;
-    for (;;) {
-      // the open candidates, counted per row; the pivot: the middle one of the middle row that has any (ballots and
-      // v_readlane only: no cross-lane scan)
-      int mine = 0;
-      if (lane < n)
-        for (int j = lane + 1; j < n; ++j) mine += in_range(dist[lane * n + j], lo, hi) ? 1 : 0;
-      const uint64_t holders = __builtin_amdgcn_ballot_w64(mine > 0);
-      if (holders == 0) break;  // nothing between lo and hi: hi is the smallest diameter
-      const int my_rank = __builtin_popcountll(holders & (((uint64_t)1 << lane) - 1));
-      const uint64_t owner_mask = __builtin_amdgcn_ballot_w64(mine > 0 && my_rank == __builtin_popcountll(holders) / 2);
+
+  // ---- 2. the smallest diameter.  Invariant: G(hi) holds k mutually adjacent rows, G(lo) does not ----
+  double lo = 0.0, hi = at_zero ? 0.0 : vmax;
+  while (!at_zero) {
+    // the open candidates, counted per row (pairs i < j: lane i enumerates j > i), and their row-major prefix
+    int mine = 0;
+    if (lane < n)
+      for (int j = lane + 1; j < n; ++j) mine += in_range(dist[lane * n + j], lo, hi) ? 1 : 0;
+    int incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    if (total == 0) break;  // nothing between lo and hi: hi is the smallest diameter
+    const int askers = total < kBruteWaves ? total : kBruteWaves;
+    answer = -1;
+    double pivot = 0.0;
+    if (wave < askers) {
+      const int idx = (int)(((int64_t)(2 * wave + 1) * total) / (2 * askers));  // distinct for distinct waves
+      const uint64_t owner_mask = __builtin_amdgcn_ballot_w64(incl > idx && incl - mine <= idx);
       const int src = __builtin_ctzll(owner_mask);
-      double pivot = 0.0;
       if (lane == src) {
-        int skip = mine / 2;
+        int skip = idx - (incl - mine);
         for (int j = lane + 1; j < n; ++j) {
           const double v = dist[lane * n + j];
           if (in_range(v, lo, hi)) {
@@ -199,30 +263,88 @@ __global__ __launch_bounds__(64) void brute_select_kernel(const double* __restri
       }
       pivot = readlane_f64(pivot, src);
       w.build(pivot);
-      if (w.has_clique(everyone, k))
-        hi = pivot;
-      else
-        lo = pivot;
+      answer = w.has_clique(everyone, k) ? 1 : 0;
     }
+    publish(pivot, answer);
+#pragma unroll
+    for (int v = 0; v < kBruteWaves; ++v) {
+      const int r = res[v];
+      const double p = piv[v];
+      if (r == 1 && p < hi) hi = p;
+      if (r == 0 && p > lo) lo = p;
+    }
+    const bool over2 = any_over();
+    __syncthreads();
+    if (over2) return give_up(-2, 0);
   }
+
+  // ---- 3. the first subset in lexicographic order in G(hi): the smallest row that still leaves a completion among
+  //         the rows above it, position by position ----
   w.build(hi);
-  // the first subset in lexicographic order: the smallest row that still leaves a completion among the rows above it
-  uint64_t cand = everyone;
+  uint64_t cand = everyone;  // rows still in play: adjacent to every chosen row, above the last chosen one
+  uint64_t skipped = 0;      // rows of `cand` that were tried at this position and do not extend
   int chosen = 0;
   int32_t mine_sel = 0;
-  for (int c = 0; c < n && chosen < k; ++c) {
-    const uint64_t bit = (uint64_t)1 << c;
-    if ((cand & bit) == 0) continue;
-    const uint64_t above = c == 63 ? 0 : ~(((uint64_t)1 << (c + 1)) - 1);
-    const uint64_t next = cand & readlane64(w.adj, c) & above;
-    if (w.has_clique(next, k - chosen - 1)) {
-      if (lane == chosen) mine_sel = c;
-      ++chosen;
-      cand = next;
+  while (chosen < k) {
+    const uint64_t open = cand & ~skipped;
+    if (__builtin_popcountll(cand) == k - chosen && skipped == 0) {
+      // what is left has exactly the size that is needed, and it holds a completion: it is the completion
+      const int my = lane - chosen;
+      if (my >= 0 && my < k - chosen) {
+        uint64_t rest = cand;
+        for (int t = 0; t < my; ++t) rest &= rest - 1;
+        mine_sel = __builtin_ctzll(rest);
+      }
+      chosen = k;
+      break;
     }
+    if (open == 0) break;  // (cannot happen while the invariant holds: status -1 below)
+    // wave v tries the v-th lowest open row
+    uint64_t rest = open;
+    for (int t = 0; t < wave && rest != 0; ++t) rest &= rest - 1;
+    answer = -1;
+    uint64_t next = 0;
+    int c = 64;
+    if (rest != 0) {
+      c = __builtin_ctzll(rest);
+      const uint64_t above = c == 63 ? 0 : ~(((uint64_t)1 << (c + 1)) - 1);
+      next = cand & readlane64(w.adj, c) & above;
+      answer = w.has_clique(next, k - chosen - 1) ? 1 : 0;
+    }
+    publish((double)c, answer);
+    int winner = -1;
+#pragma unroll
+    for (int v = kBruteWaves - 1; v >= 0; --v)
+      if (res[v] == 1) winner = v;
+    const bool over3 = any_over();
+    __syncthreads();
+    if (over3) return give_up(-2, 0);
+    // the rows tried this round, lowest first (every wave walks the same `open`)
+    uint64_t tried = 0, walk = open;
+    int win_row = 64;
+    for (int v = 0; v < kBruteWaves && walk != 0; ++v) {
+      const int row = __builtin_ctzll(walk);
+      if (v == winner) {
+        win_row = row;
+        break;
+      }
+      tried |= (uint64_t)1 << row;
+      walk &= walk - 1;
+    }
+    if (winner < 0) {
+      skipped |= tried;
+      continue;
+    }
+    if (lane == chosen) mine_sel = win_row;
+    ++chosen;
+    const uint64_t above = win_row == 63 ? 0 : ~(((uint64_t)1 << (win_row + 1)) - 1);
+    cand = cand & readlane64(w.adj, win_row) & above;
+    skipped = 0;
   }
-  if (lane < BM_MAX_ROWS) sel_out[lane] = lane < chosen ? mine_sel : 0;
-  if (lane == 0) status[0] = chosen == k ? 0 : -1;
+  if (wave == 0) {
+    if (lane < BM_MAX_ROWS) sel_out[lane] = (chosen == k && lane < k) ? mine_sel : 0;
+    if (lane == 0) status[0] = chosen == k ? 0 : -1;
+  }
 }
 
 }  // namespace bm
@@ -232,7 +354,7 @@ extern "C" int bm_brute_select_device(const double* sq_nxn, int n, int f, int32_
   using namespace bm;
   if (sq_nxn == nullptr || sel_out == nullptr || status == nullptr || n < 1 || n > BM_MAX_ROWS || f < 0 || n - f < 1)
     return BM_EINVAL;
-  hipLaunchKernelGGL(brute_select_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), sq_nxn, n, f, sel_out,
+  hipLaunchKernelGGL(brute_select_kernel, dim3(1), dim3(64 * kBruteWaves), 0, static_cast<hipStream_t>(stream), sq_nxn, n, f, sel_out,
                      status);
   BM_LAUNCH_CHECK();
   return 0;

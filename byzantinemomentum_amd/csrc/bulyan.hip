@@ -27,7 +27,7 @@ constexpr int kBulBlock = 256;
 template <int N, int F, int VEC>
 __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(
     RowTable rows, const int32_t* __restrict__ order, int64_t nvec, int nt_result, float* __restrict__ out,
-    int short_window, int reverse) {
+    int short_window, int reverse, int tail) {
   constexpr int MMAX = N - F - 2;
   constexpr int THETA = N - 2 * F - 2;
   constexpr int BETA = THETA - 2 * F;
@@ -68,9 +68,11 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(
       for (int c = 0; c < VEC; ++c) x[c][t] = tmp[c];
     }
   };
-  auto rule = [&](float (&x)[VEC][MMAX], float (&r)[VEC]) {
+  // (generic over the number of columns a lane holds: VEC in the body, 1 for the d % VEC trailing columns)
+  auto rule = [&](auto& x, auto& r) {
+    constexpr int W = (int)(sizeof(r) / sizeof(float));
 #pragma unroll
-    for (int c = 0; c < VEC; ++c) {
+    for (int c = 0; c < W; ++c) {
       // selected[i]: forward sequential sum from rank i to m_max-1, exact division by the count
       float sel[THETA];
       bool has_nan = false;
@@ -125,13 +127,23 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(
       r[c] = has_nan ? kNaN : res;
     }
   };
+  // the d % VEC trailing columns: one lane each, in the last workgroup (no second launch: 4.3 us of a C4 aggregation),
+  // before the body so that nothing of it stays live across the main loop
+  if (VEC > 1 && blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < tail) {
+    const int64_t j = nvec * VEC + threadIdx.x;
+    float x[1][MMAX], r[1];
+#pragma unroll
+    for (int t = 0; t < MMAX; ++t) x[0][t] = ranked[t][j];
+    rule(x, r);
+    out[j] = r[0];
+  }
   {
-    // Blocks of kBulBlock column groups, walked from the LAST one when `reverse` is set (BM_SECOND_PASS_REVERSE, the
-    // default): the distance pass that ranked the rows read them from the first coordinate to the last, so what the
-    // 256 MB Infinity Cache still holds when this kernel starts is the TAIL of every row (256 MB / 25 rows = 2.5 M
-    // coordinates at n = 25: 184 MB of this kernel's 804 MB of reads) — walking forward would evict it before
-    // reaching it.  Workgroups are dispatched in index order, so workgroup 0 takes the last block.  The arithmetic of
-    // a column does not depend on where the walk starts: same bits.
+    // Blocks of kBulBlock column groups, walked from the last one when `reverse` is set (BM_SECOND_PASS_REVERSE=1 or
+    // bm_bulyan_pass2_walk): the distance pass that ranked the rows read them from the first coordinate to the last, so
+    // what the 256 MB Infinity Cache could still hold when this kernel starts is the TAIL of every row.  Measured
+    // (same box, alternating, profiles/r05_a_second_pass_walk_ab.txt): it does not — the reversed walk is 0-1 % slower
+    // at C3 / C4 / CGE — so the default is the forward walk.  The arithmetic of a column does not depend on where the
+    // walk starts: same bits.
     const uint32_t nblk = (nv + kBulBlock - 1) / kBulBlock;
     for (uint32_t b = blockIdx.x; b < nblk; b += gridDim.x) {
       const uint32_t v = (reverse != 0 ? nblk - 1 - b : b) * kBulBlock + threadIdx.x;
@@ -209,34 +221,25 @@ static int launch_bulyan_fast(const float* const* rows_host, const int32_t* orde
     RowTable tab{};
     for (int i = 0; i < N; ++i) tab.p[i] = rows_host[i] + lo;
     float* out = out_all + lo;
-    int64_t body = 0;
     if (vec == 4 && kMaxVec >= 4 && d / 4 > 0) {
       const int64_t nvec = d / 4;
       hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 4 ? 4 : 1)>),
                          dim3(stream_grid(nvec, kBulBlock, kColMaxBlocks)), dim3(kBulBlock), 0,
                          s, tab, order, nvec, 1, out, tuning().bulyan_short,
-                         reverse);
-      BM_LAUNCH_CHECK();
-      body = nvec * 4;
-    } else if (vec == 2 && kMaxVec >= 2 && d / 2 > 0) {
+                         reverse, (int)(d - nvec * 4));
+    } else if (vec >= 2 && kMaxVec >= 2 && d / 2 > 0) {
       const int64_t nvec = d / 2;
       hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 2 ? 2 : 1)>),
                          dim3(stream_grid(nvec, kBulBlock, kColMaxBlocks)), dim3(kBulBlock), 0,
                          s, tab, order, nvec, 1, out, tuning().bulyan_short,
-                         reverse);
-      BM_LAUNCH_CHECK();
-      body = nvec * 2;
-    }
-    if (body < d) {
-      RowTable tail{};
-      for (int i = 0; i < N; ++i) tail.p[i] = tab.p[i] + body;
-      const int64_t rest = d - body;
+                         reverse, (int)(d - nvec * 2));
+    } else {
       hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, 1>),
-                         dim3(stream_grid(rest, kBulBlock, kColMaxBlocks)), dim3(kBulBlock), 0,
-                         s, tail, order, rest, 1, out + body, tuning().bulyan_short,
-                         reverse);
-      BM_LAUNCH_CHECK();
+                         dim3(stream_grid(d, kBulBlock, kColMaxBlocks)), dim3(kBulBlock), 0,
+                         s, tab, order, d, 1, out, tuning().bulyan_short,
+                         reverse, 0);
     }
+    BM_LAUNCH_CHECK();
   }
   return 0;
 }

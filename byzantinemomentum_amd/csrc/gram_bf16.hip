@@ -44,6 +44,7 @@
 //   * fp32 chains cover 32 coordinates, per-wave fp32 sums ~100 chunks, everything wider is fp64
 //     (workgroup, grid, GPUs) in a fixed order: deterministic, no atomics.
 #include "gram_split.h"
+#include "rank_body.h"
 
 namespace bm {
 
@@ -449,10 +450,16 @@ __device__ __forceinline__ void gram_to_sqdist(const double* __restrict__ gram, 
 // last does not matter for the result: every entry of G is summed by one workgroup in a fixed order.
 constexpr int kGramRedWaves = 16;  // 16 waves x 16 loads in flight: the sum is a latency chain over L2/HBM
 static_assert(64 * kGramRedWaves == kSqThreads, "the last workgroup of the reduction runs gram_to_sqdist");
+// rk.on (bm_pairwise_rank): that last workgroup also RANKS the rows when the gate listed nothing — 16 waves, one row
+// each, right where the distances were formed; when rows were listed the gated direct kernel, next on the stream,
+// ranks after it has corrected them (pairwise.hip).
 __global__ __launch_bounds__(64 * kGramRedWaves) void gram_reduce_sqdist_kernel(
     const double* __restrict__ partial, int nblocks, int n, double* __restrict__ gram, double tau,
-    double* __restrict__ sq, int* __restrict__ sub, int n_full) {
-  __shared__ double wsum[kGramRedWaves][64];
+    double* __restrict__ sq, int* __restrict__ sub, int n_full, RankArgs rk) {
+  // (the ranking's arrays start where the wave sums of the reduction are: the two uses never overlap in time)
+  __shared__ double lds[kRankLdsBytes / sizeof(double)];
+  static_assert(kRankLdsBytes >= kGramRedWaves * 64 * (int)sizeof(double), "the wave sums live in the ranking's arrays");
+  double(*wsum)[64] = reinterpret_cast<double(*)[64]>(lds);
   __shared__ int listed[BM_MAX_ROWS];
   __shared__ int last;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -478,15 +485,26 @@ __global__ __launch_bounds__(64 * kGramRedWaves) void gram_reduce_sqdist_kernel(
     sub[kArrivalSlot] = 0;
     sub[kArrivalSlot + 1] = 0;  // arrival counter of the gated direct kernel (pairwise.hip), next on the stream
   }
+  if (rk.on) {
+    if (threadIdx.x == 0) last = sub[0];  // (the count this very lane has just stored)
+    __threadfence();
+    __syncthreads();  // the distances this workgroup has just stored are visible to all its lanes
+    if (last == 0) krum_rank_body(sq, n_full, rk.f, rk.m, rk.mode, rk.order, rk.scores, lds);
+  }
 }
 
 // Fixed-order sum of the per-workgroup partial Gram matrices (n rows), then the squared distances of the n_full >= n
 // rows of the stack (rows n-1 .. n_full-1 alias the last row of G) + accuracy flag.
 int gram_finish(const double* partial, int blocks, int n, int n_full, double* gram, double* sq_nxn, int* sub, double tau,
-                hipStream_t s) {
+                hipStream_t s, const RankArgs* rank) {
   const int64_t per_block = (int64_t)n * (n + 1) / 2;
+  RankArgs rk{};
+  if (rank != nullptr) {
+    rk = *rank;
+    rk.on = 1;
+  }
   hipLaunchKernelGGL(gram_reduce_sqdist_kernel, dim3((int)((per_block + 63) / 64)), dim3(64 * kGramRedWaves), 0, s,
-                     partial, blocks, n, gram, tau, sq_nxn, sub, n_full);
+                     partial, blocks, n, gram, tau, sq_nxn, sub, n_full, rk);
   BM_LAUNCH_CHECK();
   return 0;
 }

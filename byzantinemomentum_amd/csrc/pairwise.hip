@@ -139,13 +139,6 @@ __device__ __forceinline__ int row_offset_bytes(const PairGeom& g, int I, int a)
   return blk * kDmaPitch + (a % g.rb) * g.row_bytes;
 }
 
-// what a gated launch does on top of its own work when it belongs to bm_pairwise_rank (by value in the kernarg segment)
-struct RankArgs {
-  int on, f, m, mode;
-  int32_t* order;
-  double* scores;
-};
-
 constexpr int kRedWaves = 8;
 constexpr int kDirectArrivalSlot = 97;  // int slot of the gate's 512-byte row-list area: arrival counter of the gated call
 
@@ -190,16 +183,12 @@ __global__ __launch_bounds__(kPairMaxThreads) void pairwise_partial_kernel(
   // sub (device, may be NULL): the rows the accuracy gate of the Gram path asks to recompute
   // (gram_to_sqdist_kernel): sub[0] = how many (0: this launch has nothing to do), sub[1..] = their
   // indices.  The kernel then works on that sub-stack with the geometry of ITS row count.
-  // rk.on (gated launches of bm_pairwise_rank): the launch also RANKS the rows from the final distances, so a
-  // single-GPU Krum / Bulyan has no rank launch of its own — workgroup 0 right here when nothing was listed (the
-  // common case: this launch did nothing at all before), else the workgroup that arrives last, after it has
-  // written the corrected distances.
+  // rk.on (gated launches of bm_pairwise_rank): when rows WERE listed, the workgroup that arrives last ranks the rows
+  // after it has written the corrected distances; when nothing was listed (the common case) the last workgroup of the
+  // Gram reduction has ranked them already (gram_reduce_sqdist_kernel: 16 waves, one row each, where this launch has
+  // 2-3) and this launch is empty.
   if (sub != nullptr) {
-    if (sub[0] == 0) {
-      if (rk.on && blockIdx.x == 0)
-        krum_rank_body(sq, n_full, rk.f, rk.m, rk.mode, rk.order, rk.scores, reinterpret_cast<double*>(smem));
-      return;
-    }
+    if (sub[0] == 0) return;
     g = pair_geometry(sub[0], 0);
   }
   const float** row_ptr = reinterpret_cast<const float**>(smem);  // 512 B pointer table
@@ -457,7 +446,7 @@ __global__ __launch_bounds__(kRankThreads) void krum_rank_kernel(const double* _
 
 namespace bm {
 int gram_finish(const double* partial, int blocks, int n, int n_full, double* gram, double* sq_nxn, int* sub, double tau,
-                hipStream_t s);
+                hipStream_t s, const RankArgs* rank = nullptr);
 int gram_arrival_slot();
 int gram3_partials(const float* const* rows, int n, int64_t d, int64_t d_total, double* partial, int* sub,
                    int* blocks_out, hipStream_t s);
@@ -531,10 +520,8 @@ static int pairwise_gram_path(const float* const* rows, int n, int64_t d, int64_
   int rc = gram3_partials(rows, n, d, d_total, gram_partial, flag, &blocks, s);
   if (rc != 0) return rc;
   double* gram = gram_partial + gram3_partial_doubles(n);
-  rc = gram_finish(gram_partial, blocks, n, n, gram, sq_nxn, flag, tau, s);
-  if (rc != 0) return rc;
-  if (tau <= 0.0)  // no gate, no third launch: the ranking, if any, is a launch of its own
-    return rank == nullptr ? 0 : bm_krum_rank(sq_nxn, n, rank->f, rank->m, rank->mode, rank->order, rank->scores, s);
+  rc = gram_finish(gram_partial, blocks, n, n, gram, sq_nxn, flag, tau, s, rank);  // (ranks when nothing is listed)
+  if (rc != 0 || tau <= 0.0) return rc;  // (no gate: nothing is ever listed, no third launch)
   return pairwise_direct(rows, n, d, sq_nxn, direct_partial, flag, s, rank);
 }
 }  // namespace bm
@@ -604,13 +591,10 @@ extern "C" int bm_pairwise_rank(const float* const* rows, int n, int64_t d, int6
     const int rc = bm_pairwise_sqdist_shard(rows, n, d, d_total, sq_nxn, ws, stream);
     return rc != 0 ? rc : bm_krum_rank(sq_nxn, n, f, m, mode, order_out, scores_out, stream);
   }
-  // The gated launch has 8 waves where the rank kernel has 16, and the ranking is one wave per row: up to 32 rows
-  // it costs about what it costs alone (n = 25: 4 rounds instead of 2) and saves a launch; beyond (n = 51: 7 rounds
-  // instead of 4, measured +40 us on a C3 aggregation) the rank kernel stays a launch of its own.
-  if (n > 32) {
-    const int rc = pairwise_gram_path(rows, n, d, d_total, sq_nxn, ws, nullptr, s);
-    return rc != 0 ? rc : bm_krum_rank(sq_nxn, n, f, m, mode, order_out, scores_out, stream);
-  }
+  // The rows are ranked inside the launches of the distance pass: by the last workgroup of the Gram reduction when the
+  // accuracy gate lists nothing, by the last workgroup of the gated direct kernel when it does (round 4 ranked in the
+  // gated launch in both cases — 2-3 waves, one row at a time: 16.5 us of a 21 us launch at n = 25 — and kept a rank
+  // launch of its own beyond 32 rows: 13.4 us at n = 51; profiles/r05_b_full_kernel_trace.csv).
   const RankArgs req{1, f, m, mode, order_out, scores_out};
   return pairwise_gram_path(rows, n, d, d_total, sq_nxn, ws, &req, s);
 }

@@ -1,6 +1,7 @@
 // rank_body.h — score + stable rank of the rows from the n x n squared distances, by ONE workgroup (any multiple of 64
-// lanes): the body of krum_rank_kernel (pairwise.hip), also run by the last workgroup of the Gram kernel when the
-// accuracy gate lists nothing (gram_bf16.hip), so that a single-GPU Krum / Bulyan needs no rank launch of its own.
+// lanes): the body of krum_rank_kernel (pairwise.hip), also run by the last workgroup of the GATED direct kernel
+// (pairwise.hip, the third launch of bm_pairwise_rank, n <= 32), so that a single-GPU Krum / Bulyan needs no rank
+// launch of its own.
 //
 // Replaces the Python score / sort loops of aggregators/krum.py:50-62 and bulyan.py:56-69.  The distances of a row
 // are sorted across the lanes of one wave (bitonic network), then lane i adds the `take` smallest of row i in
@@ -10,6 +11,15 @@
 #include "bm_common.h"
 
 namespace bm {
+
+// What a launch of the distance pass does on top of its own work when it belongs to bm_pairwise_rank (by value in the
+// kernarg segment): rank the rows from the final distances.  `on` = 1: the last workgroup of the Gram reduction ranks
+// when the accuracy gate listed nothing (the common case), the gated direct kernel when it did.
+struct RankArgs {
+  int on, f, m, mode;
+  int32_t* order;
+  double* scores;
+};
 
 constexpr int kRankSrtDoubles = BM_MAX_ROWS * (BM_MAX_ROWS + 1);  // srt[i][r] = r-th smallest distance of row i
 constexpr int kRankLdsBytes = (kRankSrtDoubles + BM_MAX_ROWS) * (int)sizeof(double);

@@ -22,7 +22,7 @@ template <int VEC>
 __global__ __launch_bounds__(kRedBlock) void selected_mean_kernel(RowTable rows,
                                                                   const int32_t* __restrict__ idx,
                                                                   int m, int64_t nvec, float fm, int nt_result,
-                                                                  float* __restrict__ out, int reverse) {
+                                                                  float* __restrict__ out, int reverse, int tail) {
   __shared__ const float* sel[BM_MAX_ROWS];
   if (threadIdx.x < m) sel[threadIdx.x] = rows.p[idx[threadIdx.x]];
   __syncthreads();
@@ -46,6 +46,13 @@ __global__ __launch_bounds__(kRedBlock) void selected_mean_kernel(RowTable rows,
     for (int c = 0; c < VEC; ++c) acc[c] = acc[c] / fm;
     store_result_policy<VEC>(out + v * VEC, acc, nt_result);
   }
+  // the d % VEC trailing columns: one lane each, in the last workgroup (no second launch)
+  if (VEC > 1 && blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < tail) {
+    const int64_t j = nvec * VEC + threadIdx.x;
+    float acc = 0.0f;
+    for (int k = 0; k < m; ++k) acc += sel[k][j];
+    out[j] = acc / fm;
+  }
 }
 
 // Burst form of the same kernel for long gradients (16-byte columns): one workgroup of 1024 lanes per CU,
@@ -57,7 +64,8 @@ constexpr int kMeanBurstSlots = 9;  // 9 x 1024 x 16 B = 144 KB of results next 
 __global__ __launch_bounds__(kMeanBurstThreads) void selected_mean_burst_kernel(RowTable rows,
                                                                                 const int32_t* __restrict__ idx, int m,
                                                                                 int64_t nvec, float fm,
-                                                                                float* __restrict__ out, int reverse) {
+                                                                                float* __restrict__ out, int reverse,
+                                                                                int tail) {
   using V = typename VecLoad<4>::T;
   __shared__ V stage[kMeanBurstSlots * kMeanBurstThreads];
   __shared__ const float* sel[BM_MAX_ROWS];
@@ -94,11 +102,18 @@ __global__ __launch_bounds__(kMeanBurstThreads) void selected_mean_burst_kernel(
       if (v < nv) __builtin_nontemporal_store(stage[(it - p0) * kMeanBurstThreads + tid], reinterpret_cast<V*>(out) + v);
     }
   }
+  // the d % 4 trailing columns: one lane each, in the last workgroup (no second launch: 4.4 us of a C3 aggregation)
+  if (blockIdx.x == gridDim.x - 1 && (int)tid < tail) {
+    const int64_t j = nvec * 4 + tid;
+    float acc = 0.0f;
+    for (int k = 0; k < m; ++k) acc += sel[k][j];
+    out[j] = acc / fm;
+  }
 }
 
 template <int VEC>
 static int launch_selected_mean(const RowTable& tab, const int32_t* idx, int m, int64_t nvec,
-                                float* out, hipStream_t s) {
+                                float* out, hipStream_t s, int tail = 0) {
   if (nvec <= 0) return 0;
   if constexpr (VEC == 4) {
     const int cus = compute_units();
@@ -107,14 +122,14 @@ static int launch_selected_mean(const RowTable& tab, const int32_t* idx, int m, 
     if (tuning().mean_burst > 0 && m >= 12 && nvec < ((int64_t)1 << 30) &&
         nvec / ((int64_t)cus * kMeanBurstThreads) >= tuning().mean_burst) {
       hipLaunchKernelGGL(selected_mean_burst_kernel, dim3(cus), dim3(kMeanBurstThreads), 0, s, tab, idx, m, nvec,
-                         (float)m, out, tuning().second_pass_reverse);
+                         (float)m, out, tuning().second_pass_reverse, tail);
       BM_LAUNCH_CHECK();
       return 0;
     }
   }
   const int grid = stream_grid(nvec, kRedBlock, 256 * 32);
   hipLaunchKernelGGL(selected_mean_kernel<VEC>, dim3(grid), dim3(kRedBlock), 0, s, tab, idx, m, nvec,
-                     (float)m, 1, out, tuning().second_pass_reverse);
+                     (float)m, 1, out, tuning().second_pass_reverse, tail);
   BM_LAUNCH_CHECK();
   return 0;
 }
@@ -458,12 +473,14 @@ extern "C" int bm_selected_mean(const float* const* rows, int n, const int32_t* 
   const int vec = common_vec_width(reinterpret_cast<const void* const*>(rows), n, out);
   int64_t body = 0;
   int rc = 0;
-  if (vec == 4) {
-    body = (d / 4) * 4;
-    rc = launch_selected_mean<4>(tab, idx, m, d / 4, out, s);
-  } else if (vec == 2) {
-    body = (d / 2) * 2;
-    rc = launch_selected_mean<2>(tab, idx, m, d / 2, out, s);
+  // (the d % VEC trailing columns ride in the last workgroup of the body's launch; a launch of their own only when
+  //  there is no body)
+  if (vec == 4 && d >= 4) {
+    body = d;
+    rc = launch_selected_mean<4>(tab, idx, m, d / 4, out, s, (int)(d % 4));
+  } else if (vec >= 2 && d >= 2) {
+    body = d;
+    rc = launch_selected_mean<2>(tab, idx, m, d / 2, out, s, (int)(d % 2));
   }
   if (rc != 0) return rc;
   if (body < d) {

@@ -274,8 +274,8 @@ def brute_select_host(dist_host, n, f):
 
 def brute_select_device(sq, n, f):
   """Subset search of the Brute rule on a DEVICE fp64 n x n matrix of SQUARED distances (bm_brute_select_device: one
-  wave, no host round trip).  Returns (sel int32[MAX_ROWS]: the n - f rows ascending, status int32[1]: 0, or -1 when
-  every subset touches a non-finite distance), both on the device."""
+  workgroup, no host round trip).  Returns (sel int32[MAX_ROWS]: the n - f rows ascending, status int32[1]: 0, -1 when
+  every subset touches a non-finite distance, -2 when the search gave up on its node budget), both on the device."""
   lib = _lib.load()
   device = sq.device
   sel = torch.empty(_lib.MAX_ROWS, dtype=torch.int32, device=device)
@@ -303,12 +303,13 @@ def brute_selection(gradients, f, **kwargs):
   synchronises; raises when no subset of n-f rows has a finite diameter (the reference then has no selection)."""
   n = len(gradients)
   sel, status = _brute_sel(gradients, f)
-  if int(status.item()) != 0:
-    raise RuntimeError(BRUTE_NO_SUBSET)
+  brute_check(status)
   return sel[:n - f].tolist()
 
 
 BRUTE_NO_SUBSET = "brute: too many non-finite gradients, no subset of n-f rows has a finite diameter"
+BRUTE_BUDGET = ("brute: the device search gave up after its budget of search-tree nodes (csrc/brute.hip; a distance matrix "
+                "built against the search?) — gars.brute_select_host on the host has no such limit")
 last_brute_status = None   # int32[1] device tensor of the latest brute(): 0, or -1 when no subset was admissible
 
 
@@ -316,7 +317,10 @@ def brute_check(status=None):
   """Raise when the latest (or the given) Brute search found no admissible subset — the reference's assertion
   (brute.py:68).  Synchronises (one 4-byte read); not to be called while a stream is being captured."""
   status = last_brute_status if status is None else status
-  if status is not None and int(status.item()) != 0:
+  code = 0 if status is None else int(status.item())
+  if code == -2:
+    raise RuntimeError(BRUTE_BUDGET)
+  if code != 0:
     raise RuntimeError(BRUTE_NO_SUBSET)
 
 

@@ -18,8 +18,10 @@ are those of the recording.  Contents may change freely; a stack at other addres
 
 `fn` must not synchronise with the host while it is recorded.  Calls that do, and therefore cannot be graphed: the
 factor search of the attacks (`AggregationStep(attack_evals=...)`: `.item()` per evaluation), `floats()`, sharded
-rules over torch.distributed collectives that stage through the host, `ShardedAggregator.brute` (host search of the
-all-reduced matrix).  A failed recording raises GraphCaptureError and leaves nothing behind.
+rules over torch.distributed collectives that stage through the host, and `ShardedAggregator.brute` with a backend
+that has no device search (the HIP backend has one, bm_brute_select_device: its brute IS capturable; the status of
+the search stays on the device until `check_brute()` / `floats()`).  A failed recording raises GraphCaptureError and
+leaves nothing behind.
 """
 
 import torch

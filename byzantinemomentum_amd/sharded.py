@@ -467,8 +467,9 @@ class ShardedAggregator:
   def check_brute(self):
     """Raise (the reference's assertion, brute.py:68) when the latest brute() found no admissible subset; syncs."""
     status = getattr(self, "brute_status", None)
-    if status is not None and int(status.item()) != 0:
-      raise RuntimeError("brute: too many non-finite gradients, no subset of n-f rows has a finite diameter")
+    if status is not None:
+      from . import gars
+      gars.brute_check(status)
 
   def average(self, local):
     n = len(local)

@@ -116,11 +116,11 @@ int bm_selected_mean(const float* const* rows, int n, const int32_t* idx, int m,
  * order is the DEVICE output of bm_krum_rank(mode BULYAN). */
 int bm_bulyan_pass2(const float* const* rows, int n, const int32_t* order, int f, int m,
                     int64_t d, float* out, void* stream);
-/* The same with the walk stated: 0 = from the first column, 1 = from the last one, < 0 = the library's default
- * (bm_bulyan_pass2: from the last one, where the distance pass that produced `order` finished and whose neighbourhood
- * the 256 MB Infinity Cache still holds).  The output does not depend on it; a caller that runs pass 2 repeatedly
- * over the same rows (the factor search of attacks/identical.py:67-77 against Bulyan) alternates it, so that every
- * pass starts where the previous one ended. */
+/* bm_bulyan_pass2 with the walk over the columns stated: 0 = from the first column, 1 = from the last one, < 0 = the
+ * library's default (what bm_bulyan_pass2 does: from the first one — starting at the end, where the distance pass
+ * that produced `order` finished, measured 0-1 % SLOWER on the MI355X, profiles/r05_a_second_pass_walk_ab.txt).  The
+ * output does not depend on the walk; a caller that runs pass 2 repeatedly over the same rows (the factor search of
+ * attacks/identical.py:67-77 against Bulyan) may alternate it. */
 int bm_bulyan_pass2_walk(const float* const* rows, int n, const int32_t* order, int f, int m,
                          int64_t d, float* out, int walk, void* stream);
 
@@ -272,13 +272,16 @@ int bm_multi_scale(float* const* y, int k, int64_t d, const float* factors, void
  * The subsets are not enumerated (bisection over the distances, a search tree of
  * depth <= f per probe): n = 51, f = 12 — 1.6e11 subsets — takes 0.1 ms. */
 int bm_brute_select(const double* dist_nxn, int n, int f, int32_t* sel_out);
-/* The same search by one wave ON THE DEVICE, from the SQUARED distances where bm_pairwise_sqdist left them: no copy
- * out, no host search, no copy in — distances -> search -> bm_selected_mean are three launches on one stream, and a
- * HIP graph can record them.  sel_out (DEVICE, BM_MAX_ROWS int32): the n-f rows ascending, then zeros — the index
- * table bm_selected_mean reads.  status (DEVICE, one int32): 0, or -1 when every subset touches a non-finite distance
- * (brute.py:56-57: the reference then selects nothing); sel_out then holds n-f copies of the first row all of whose
- * distances are non-finite, so that the average that follows is non-finite where that row is.  Same selections as
- * bm_brute_select (tests/test_gpu_parity_r4.py). */
+/* The subset search of bm_brute_select ON THE DEVICE (one workgroup of 16 waves that probe 16 thresholds / 16 rows at
+ * a time, csrc/brute.hip), from the SQUARED distances where bm_pairwise_sqdist left them: no copy out, no host search,
+ * no copy in — distances -> search -> bm_selected_mean are three launches on one stream, and a HIP graph can record
+ * them.  sel_out (DEVICE, BM_MAX_ROWS int32): the n-f rows ascending, then zeros — the index table bm_selected_mean
+ * reads.  status (DEVICE, one int32): 0; -1 when every subset touches a non-finite distance (brute.py:56-57,68: the
+ * reference then fails its assertion) — sel_out then holds n-f copies of the first row all of whose distances are
+ * non-finite, so that the average that follows is non-finite where that row is; -2 when the search gave up on its
+ * budget of 2^18 search-tree nodes per wave (the tree is exponential in f in the worst case; a crafted matrix must
+ * not hold the stream for seconds) — sel_out is then all zeros, and bm_brute_select on the host has no such limit.
+ * Same selections as bm_brute_select (tests/test_gpu_parity_r4.py). */
 int bm_brute_select_device(const double* sq_nxn, int n, int f, int32_t* sel_out, int32_t* status, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -373,7 +376,7 @@ int bm_colwise_eval_supported(int op, int n);
 int64_t bm_colwise_eval_workspace_bytes(void);
 int bm_colwise_eval(int op, const float* const* honests, int h, int copies, int64_t d, int f, const float* avg,
                     const float* dir, float t, double* out, void* ws, void* stream);
-/* The same with the walk stated (0 = from the first column, as bm_colwise_eval; 1 = from the last one): the
+/* bm_colwise_eval with the walk over the columns stated (0 = from the first column, as bm_colwise_eval; 1 = from the last one): the
  * evaluations of one search read the same honest rows again and again, alternating the walk lets each start in what
  * the previous one left in the Infinity Cache.  A lane adds its columns in the order of the walk: the two walks agree
  * to the rounding of the objective's sum (fp32 over <= 64 elements per lane, fp64 beyond), not bit for bit. */
