@@ -62,7 +62,9 @@ def parse():
                  help="N > 1: weak = every rank holds --d coordinates (default for colwise, which has no exchange step), "
                       "strong = --d coordinates in total, split by shard_bounds (default for krum / bulyan / step)")
   p.add_argument("--gar", default="krum", help="aggregation rule of --workload step")
-  p.add_argument("--d", type=int, default=None, help="TOTAL number of coordinates (split across the ranks)")
+  # (--dim: the spelling that survives `python -m torch.distributed.run ... bench.py --dim N`, whose own parser takes a
+  #  bare --d for an abbreviation of its --duplicate-* options)
+  p.add_argument("--d", "--dim", dest="d", type=int, default=None, help="TOTAL number of coordinates (split across the ranks)")
   p.add_argument("--weak", action="store_true", help="same as --scaling weak")
   p.add_argument("--no-cpu-baseline", action="store_true")
   p.add_argument("--no-extras", action="store_true", help="N = 1: skip the per_gar measurements of C3/C4/C5")
@@ -554,7 +556,8 @@ def main():
       port = s.getsockname()[1]
     os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
                               f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1", "--master-port",
-                              str(port), str(ROOT / "bench.py"), *sys.argv[1:]])
+                              str(port), str(ROOT / "bench.py"),
+                              *("--dim" + a[3:] if a == "--d" or a.startswith("--d=") else a for a in sys.argv[1:])])
   world = int(os.environ.get("WORLD_SIZE", "1"))
   rank = int(os.environ.get("RANK", "0"))
   local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -406,8 +406,10 @@ constexpr int kArrivalSlot = 96;  // int slot of the 512-byte row-list area that
 // n rows in G (compact), n_full >= n rows in sq: rows n-1 .. n_full-1 of the full stack are ONE row of G (the aliased
 // Byzantine copies of a step: the Gram kernel contracted the row once); they are at distance exactly 0 of each other
 // and share every other distance, and if the gate lists one of them it lists them all.
+// dist (LDS, may be NULL): also receives the n_full x n_full DISTANCES as the ranking reads them (rank_body.h).
 __device__ __forceinline__ void gram_to_sqdist(const double* __restrict__ gram, int n, double tau,
-                                               double* __restrict__ sq, int* __restrict__ sub, int* listed, int n_full) {
+                                               double* __restrict__ sq, int* __restrict__ sub, int* listed, int n_full,
+                                               double* dist = nullptr) {
   if (threadIdx.x < BM_MAX_ROWS) listed[threadIdx.x] = 0;
   __syncthreads();
   for (int e = threadIdx.x; e < n_full * n_full; e += kSqThreads) {
@@ -418,7 +420,9 @@ __device__ __forceinline__ void gram_to_sqdist(const double* __restrict__ gram, 
       // non-finite coordinate is at non-finite distance of everything, its own copies included (x - x = nan in
       // krum.py:44-47, which the rules turn into +inf; bm_pairwise_sqdist on the expanded stack says NaN too)
       const double gdd = gram[b3_tri_index(ci, ci, n)];
-      sq[e] = (i != j && !(fabs(gdd) < __builtin_inf())) ? __builtin_nan("") : 0.0;
+      const double same_row = (i != j && !(fabs(gdd) < __builtin_inf())) ? __builtin_nan("") : 0.0;
+      sq[e] = same_row;
+      if (dist != nullptr) dist[e] = rank_distance(same_row);
       continue;
     }
     const int lo = ci < cj ? ci : cj, hi = ci < cj ? cj : ci;
@@ -432,6 +436,7 @@ __device__ __forceinline__ void gram_to_sqdist(const double* __restrict__ gram, 
     }
     if (v < 0.0) v = 0.0;  // rounding of nearly identical rows; NaN stays NaN
     sq[e] = v;
+    if (dist != nullptr) dist[e] = rank_distance(v);
   }
   __syncthreads();
   if (threadIdx.x == 0 && sub != nullptr) {
@@ -456,10 +461,10 @@ static_assert(64 * kGramRedWaves == kSqThreads, "the last workgroup of the reduc
 __global__ __launch_bounds__(64 * kGramRedWaves) void gram_reduce_sqdist_kernel(
     const double* __restrict__ partial, int nblocks, int n, double* __restrict__ gram, double tau,
     double* __restrict__ sq, int* __restrict__ sub, int n_full, RankArgs rk) {
-  // (the ranking's arrays start where the wave sums of the reduction are: the two uses never overlap in time)
-  __shared__ double lds[kRankLdsBytes / sizeof(double)];
-  static_assert(kRankLdsBytes >= kGramRedWaves * 64 * (int)sizeof(double), "the wave sums live in the ranking's arrays");
-  double(*wsum)[64] = reinterpret_cast<double(*)[64]>(lds);
+  // dynamic LDS: the wave sums of the reduction, then (last workgroup, rk.on) the ranking's arrays in the same place
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double* lds = reinterpret_cast<double*>(smem);
+  double(*wsum)[64] = reinterpret_cast<double(*)[64]>(smem);
   __shared__ int listed[BM_MAX_ROWS];
   __shared__ int last;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -480,16 +485,15 @@ __global__ __launch_bounds__(64 * kGramRedWaves) void gram_reduce_sqdist_kernel(
   }
   // arrival: release this workgroup's entries of G, take a ticket; the last ticket acquires everybody's
   if (!arrive_last(sub + kArrivalSlot, (int)gridDim.x, &last)) return;
-  gram_to_sqdist(gram, n, tau, sq, sub, listed, n_full);
+  gram_to_sqdist(gram, n, tau, sq, sub, listed, n_full, rk.on ? lds : nullptr);  // (the wave sums are done with)
   if (threadIdx.x == 0) {
     sub[kArrivalSlot] = 0;
     sub[kArrivalSlot + 1] = 0;  // arrival counter of the gated direct kernel (pairwise.hip), next on the stream
+    last = sub[0];              // (the count this very lane has just stored)
   }
   if (rk.on) {
-    if (threadIdx.x == 0) last = sub[0];  // (the count this very lane has just stored)
-    __threadfence();
-    __syncthreads();  // the distances this workgroup has just stored are visible to all its lanes
-    if (last == 0) krum_rank_body(sq, n_full, rk.f, rk.m, rk.mode, rk.order, rk.scores, lds);
+    __syncthreads();  // the distances in LDS and the count
+    if (last == 0) krum_rank_from_distances(lds, n_full, rk.f, rk.m, rk.mode, rk.order, rk.scores);
   }
 }
 
@@ -503,7 +507,14 @@ int gram_finish(const double* partial, int blocks, int n, int n_full, double* gr
     rk = *rank;
     rk.on = 1;
   }
-  hipLaunchKernelGGL(gram_reduce_sqdist_kernel, dim3((int)((per_block + 63) / 64)), dim3(64 * kGramRedWaves), 0, s,
+  int lds_bytes = kGramRedWaves * 64 * (int)sizeof(double);
+  if (rk.on && rank_lds_bytes(n_full) > lds_bytes) lds_bytes = rank_lds_bytes(n_full);
+  if (lds_bytes > 48 * 1024) {  // (n >= 56 with a ranking)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gram_reduce_sqdist_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kRankLdsBytes);
+    if (e != hipSuccess) return hip_code(e);
+  }
+  hipLaunchKernelGGL(gram_reduce_sqdist_kernel, dim3((int)((per_block + 63) / 64)), dim3(64 * kGramRedWaves), lds_bytes, s,
                      partial, blocks, n, gram, tau, sq_nxn, sub, n_full, rk);
   BM_LAUNCH_CHECK();
   return 0;

@@ -438,8 +438,8 @@ __global__ __launch_bounds__(kRankThreads) void krum_rank_kernel(const double* _
                                                                  int f, int m, int mode,
                                                                  int32_t* __restrict__ order,
                                                                  double* __restrict__ scores_out) {
-  __shared__ double lds[kRankLdsBytes / sizeof(double)];
-  krum_rank_body(sq, n, f, m, mode, order, scores_out, lds);
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // rank_lds_bytes(n)
+  krum_rank_body(sq, n, f, m, mode, order, scores_out, reinterpret_cast<double*>(smem));
 }
 
 }  // namespace bm
@@ -482,7 +482,7 @@ static int pairwise_direct(const float* const* rows, int n, int64_t d, double* s
   if (rank != nullptr && sub != nullptr) {
     rk = *rank;
     rk.on = 1;
-    if (lds_bytes < (size_t)kRankLdsBytes) lds_bytes = kRankLdsBytes;  // (the ranking's arrays alias the tiles)
+    if (lds_bytes < (size_t)rank_lds_bytes(n)) lds_bytes = rank_lds_bytes(n);  // (the ranking's arrays alias the tiles)
   }
   PairGeom gw = g;
   gw.width = (int)min_width;
@@ -574,7 +574,12 @@ extern "C" int bm_krum_rank(const double* sq_nxn, int n, int f, int m, int mode,
   if (sq_nxn == nullptr || order_out == nullptr || n < 1 || n > BM_MAX_ROWS || f < 0 ||
       (mode != BM_RANK_KRUM && mode != BM_RANK_BULYAN))
     return BM_EINVAL;
-  hipLaunchKernelGGL(krum_rank_kernel, dim3(1), dim3(kRankThreads), 0, static_cast<hipStream_t>(stream),
+  if (rank_lds_bytes(n) > 48 * 1024) {  // (n >= 56; the call is a table look-up after the first time)
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(krum_rank_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, kRankLdsBytes);
+    if (e != hipSuccess) return hip_code(e);
+  }
+  hipLaunchKernelGGL(krum_rank_kernel, dim3(1), dim3(kRankThreads), rank_lds_bytes(n), static_cast<hipStream_t>(stream),
                      sq_nxn, n, f, m, mode, order_out, scores_out);
   BM_LAUNCH_CHECK();
   return 0;

@@ -3,10 +3,7 @@
 // (pairwise.hip, the third launch of bm_pairwise_rank, n <= 32), so that a single-GPU Krum / Bulyan needs no rank
 // launch of its own.
 //
-// Replaces the Python score / sort loops of aggregators/krum.py:50-62 and bulyan.py:56-69.  The distances of a row
-// are sorted across the lanes of one wave (bitonic network), then lane i adds the `take` smallest of row i in
-// ascending order in fp64 — the same sequence of additions as the reference's `sum(sorted(...)[:take])` — and the
-// rows are ranked by score, ties to the lower index (Python's stable sort).
+// Replaces the Python score / sort loops of aggregators/krum.py:50-62 and bulyan.py:56-69.
 #pragma once
 #include "bm_common.h"
 
@@ -21,40 +18,45 @@ struct RankArgs {
   double* scores;
 };
 
-constexpr int kRankSrtDoubles = BM_MAX_ROWS * (BM_MAX_ROWS + 1);  // srt[i][r] = r-th smallest distance of row i
-constexpr int kRankLdsBytes = (kRankSrtDoubles + BM_MAX_ROWS) * (int)sizeof(double);
+// LDS of the ranking: the distances D[n][n], the rows in ascending order S[n][n-1], the scores [n] — 2 n^2 doubles.
+__host__ __device__ constexpr int rank_lds_bytes(int n) { return 2 * n * n * (int)sizeof(double); }
+constexpr int kRankLdsBytes = rank_lds_bytes(BM_MAX_ROWS);  // 64 KB at n = 64
 
-// lds: kRankLdsBytes, 8-byte aligned.  Every lane of the workgroup must call (barriers inside).
-__device__ __forceinline__ void krum_rank_body(const double* __restrict__ sq, int n, int f, int m, int mode,
-                                               int32_t* __restrict__ order, double* __restrict__ scores_out,
-                                               double* lds) {
-  double(*srt)[BM_MAX_ROWS + 1] = reinterpret_cast<double(*)[BM_MAX_ROWS + 1]>(lds);
-  double* score = lds + kRankSrtDoubles;
-  const double kInf = __builtin_inf();
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int waves = (int)blockDim.x >> 6;
-  // One wave per row (n <= 64): lane j holds dist(i, j) = sqrt in fp64, non-finite -> +inf (krum.py:46-47), the
-  // row's own lane and the lanes past n hold +inf too; the 64 values are sorted ascending across the lanes by a
-  // bitonic network (21 compare-exchange steps of one cross-lane exchange each, whatever n — counting every value's
-  // rank against n broadcasts, as before, was n^3 / 64 fp64 compares per stack: 2.4 x the instructions at n = 51).
-  // Lanes 0 .. n-2 then hold the row's n - 1 distances in ascending order (equal values in either order: the sums
-  // below do not depend on it).
-  for (int i = wave; i < n; i += waves) {
-    double v = kInf;
-    if (lane < n && lane != i) {
-      v = sqrt(sq[i * n + lane]);
-      if (!(v == v) || v == kInf || v == -kInf) v = kInf;
+// distance as the rules see it: sqrt in fp64, non-finite -> +inf (krum.py:46-47)
+__device__ __forceinline__ double rank_distance(double sq) {
+  const double v = sqrt(sq);
+  return (__builtin_fabs(v) < __builtin_inf()) ? v : __builtin_inf();
+}
+
+// From the distances in LDS: D[i * n + j] = rank_distance(sq[i][j]) (the diagonal is never read).  lds: rank_lds_bytes(n)
+// bytes, 8-byte aligned, D first.  Every lane of the workgroup must call (barriers inside), after a barrier that made D
+// visible.
+//
+// Every distance finds its place in its row by COUNTING — pair (i, j) counts the k with d_ik < d_ij, ties to the lower
+// index — all n (n - 1) pairs at once across the workgroup (n reads of LDS each, the lanes of a wave share i and read
+// the same address: broadcasts), and is scattered to S[i][place]; then lane i adds the `take` smallest of row i in
+// ascending order in fp64 — the same sequence of additions as the reference's `sum(sorted(...)[:take])` — and the rows
+// are ranked by score, ties to the lower index (Python's stable sort).  (Round 4 sorted each row across the 64 lanes of
+// one wave with a bitonic network of 21 dependent cross-lane exchanges: 8.5 us at n = 25 and 13 us at n = 51 with 16
+// waves, profiles/r05_c_full_kernel_trace.csv; counting is ~1 us at both.)
+__device__ __forceinline__ void krum_rank_from_distances(double* lds, int n, int f, int m, int mode,
+                                                         int32_t* __restrict__ order, double* __restrict__ scores_out) {
+  const double* D = lds;
+  double* S = lds + n * n;
+  double* score = S + n * (n - 1);
+  const int tid = threadIdx.x, threads = (int)blockDim.x;
+  for (int e = tid; e < n * n; e += threads) {
+    const int i = e / n, j = e - i * n;
+    if (i == j) continue;
+    const double v = D[e];
+    const double* row = D + i * n;
+    int place = 0;
+#pragma unroll 8
+    for (int k = 0; k < n; ++k) {
+      const double dk = row[k];
+      place += (k != i && (dk < v || (dk == v && k < j))) ? 1 : 0;
     }
-#pragma unroll
-    for (int k = 2; k <= 64; k <<= 1) {
-#pragma unroll
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        const double o = __shfl_xor(v, j, 64);
-        const bool keep_min = ((lane & k) == 0) == ((lane & j) == 0);
-        v = keep_min ? __builtin_fmin(v, o) : __builtin_fmax(v, o);
-      }
-    }
-    if (lane < n - 1) srt[i][lane] = v;
+    S[i * (n - 1) + place] = v;
   }
   __syncthreads();
   if (tid < n) {
@@ -64,7 +66,7 @@ __device__ __forceinline__ void krum_rank_body(const double* __restrict__ sq, in
     if (take < 0) take = 0;
     double s = 0.0;
 #pragma unroll 8
-    for (int t = 0; t < take; ++t) s += srt[tid][t];  // additions stay in ascending order
+    for (int t = 0; t < take; ++t) s += S[tid * (n - 1) + t];  // additions stay in ascending order
     score[tid] = s;
     if (scores_out != nullptr) scores_out[tid] = s;
   }
@@ -80,6 +82,15 @@ __device__ __forceinline__ void krum_rank_body(const double* __restrict__ sq, in
     }
     order[rank] = tid;
   }
+}
+
+// The same from the n x n squared distances in device memory.
+__device__ __forceinline__ void krum_rank_body(const double* __restrict__ sq, int n, int f, int m, int mode,
+                                               int32_t* __restrict__ order, double* __restrict__ scores_out,
+                                               double* lds) {
+  for (int e = threadIdx.x; e < n * n; e += (int)blockDim.x) lds[e] = rank_distance(sq[e]);
+  __syncthreads();
+  krum_rank_from_distances(lds, n, f, m, mode, order, scores_out);
 }
 
 }  // namespace bm

@@ -118,3 +118,26 @@ def test_cpu_baseline_legs_on_a_small_stack():
     assert rec["host"]["hardware_threads"] == os.cpu_count() and rec["host"]["torch"] == torch.__version__
   from oracle import reference_loader
   assert col["kind"] == ("reference" if reference_loader.available() else "port")
+
+
+def test_self_spawn_spells_the_length_flag_so_that_the_launcher_leaves_it_alone(monkeypatch):
+  """`--d N` must reach the ranks as `--dim N`: torch.distributed.run's own parser takes a bare --d for an abbreviation
+  of its --duplicate-* options and refuses the command line."""
+  bench = load_bench()
+  calls = []
+
+  def fake_execv(exe, argv):
+    calls.append(argv)
+    raise SystemExit(0)
+  monkeypatch.setattr(os, "execv", fake_execv)
+  monkeypatch.delenv("WORLD_SIZE", raising=False)
+  for spelled in (["--d", "1000"], ["--d=1000"], ["--dim", "1000"]):
+    calls.clear()
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", *spelled])
+    with pytest.raises(SystemExit):
+      bench.main()
+    tail = calls[0][calls[0].index(str(ROOT / "bench.py")) + 1:]
+    assert "--d" not in tail and not any(a.startswith("--d=") for a in tail), tail
+    assert bench.parse.__call__ is not None
+    monkeypatch.setattr(sys, "argv", ["bench.py", *tail])
+    assert bench.parse().d == 1000 and bench.parse().gpus == 2

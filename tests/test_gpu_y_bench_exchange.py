@@ -30,7 +30,7 @@ def _launch(*flags, timeout=420):
 
 
 def test_one_rank_launcher_run_fills_the_exchange_object():
-  done, lines = _launch("--workload", "bulyan", "--d", "2000003", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+  done, lines = _launch("--workload", "bulyan", "--dim", "2000003", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
                         "--no-traffic")
   assert done.returncode == 0, done.stderr[-3000:]
   assert len(lines) == 1, done.stdout[-2000:]
@@ -48,7 +48,7 @@ def test_one_rank_launcher_run_fills_the_exchange_object():
 
 
 def test_a_deadline_that_fires_costs_the_exchange_legs_not_the_line():
-  done, lines = _launch("--workload", "bulyan", "--d", "2000003", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
+  done, lines = _launch("--workload", "bulyan", "--dim", "2000003", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
                         "--no-traffic", "--extras-timeout", "0.05")
   assert done.returncode == 0, done.stderr[-3000:]
   assert len(lines) == 1, done.stdout[-2000:]
