@@ -367,12 +367,13 @@ def sharded_extras(bm, agg, dist, device, world, rank, timer, args, rule_name, d
   m = n - f - 2
   # the path's one real exchange, at the top level of the line (a SCALE record then carries it, not only the
   # embarrassingly parallel headline): BASELINE.json configs[3] for Bulyan — strong scaling of a fixed d
-  exchange = extra["exchange"] = {
+  exchange = extra.setdefault("exchange", {})  # (the same object all along: a deadline may be writing its `error` into it)
+  exchange.update({
     "workload": f"{rule_name} n={n} f={f}, total d={d_total} dim-sharded over {world} ranks (strong scaling), one all-reduce "
                 f"of the {n}x{n} fp64 squared-distance partials inside the call",
     "ms": None, "agg_per_s": None, "allreduce_us": None, "allreduce_bytes": 8 * n * n, "allgather_output_ms": None,
     "layout_exchange_ms": None, "single_gpu_ms": None, "speedup_vs_1gpu": None,
-    "collectives": "libbm_gar's own RCCL communicator" if agg.native is not None else "torch.distributed (RCCL)"}
+    "collectives": "libbm_gar's own RCCL communicator" if agg.native is not None else "torch.distributed (RCCL)"})
   lo, hi = shard_bounds(d_total, world, rank)
   # (Shards: the shards state the length of the whole vectors, whatever other lengths this aggregator has served)
   stacks = [Shards(st, d_total=d_total) for st in make_stacks(n, f, hi - lo, device, 2, 4321 + rank, args.aliased_byz)]
@@ -754,6 +755,9 @@ def main():
         print(json.dumps(make_line()), flush=True)
     deadline = Deadline(args.extras_timeout, give_up)
     try:
+      # (tests: BM_BENCH_STALL_S makes this rank hang here, as a rank stuck in a collective would — the deadline must
+      #  then print the line; tests/test_gpu_y_bench_exchange.py)
+      time.sleep(float(os.environ.get("BM_BENCH_STALL_S", "0") or 0))
       if agg is None:
         agg = make_aggregator(bm, dist, device, world, rank, distributed)
       sharded_extras(bm, agg, dist, device, world, rank, timer, args, exchange_rule,

@@ -6,7 +6,7 @@
 
 namespace bm {
 
-constexpr int kPlacedRows = 25;    // the one row count with a PLACED instance of the burst kernel (experiments)
+constexpr int kPlacedRows = 25;    // the one row count with a PLAIN-load instance of the burst kernel (experiment)
 constexpr int kBurstMaxRows = 25;  // 4 waves per SIMD (1024 lanes per CU) leave 128 VGPRs: trmean at n = 25 just fits, n = 26 spills
 
 template <int N, int OP, int VEC>
@@ -26,18 +26,16 @@ static int launch_colwise_vec(const RowTable& rows_all, int64_t d_all, int f, fl
       const int cus = compute_units();
       const int64_t burst_iters = nvec / ((int64_t)cus * kBurstThreads);
       if (tuning().col_burst > 0 && burst_iters >= tuning().col_burst) {
-        if constexpr (N == kPlacedRows) {  // the placement experiments (BM_COL_ROTATE, BM_COL_PAGE_STRIDE), one shape
-          const int rotate = tuning().col_rotate, s = tuning().col_page_stride;
-          const bool stride_ok = s > 0 && s <= 12 && ((cus * (kBurstThreads / 64)) % (4 << s)) == 0;
-          if (rotate > 0 || stride_ok) {
+        if constexpr (N == kPlacedRows) {  // the load-policy experiment (BM_COL_LOAD_PLAIN), one shape
+          if (tuning().col_load_plain != 0) {
             hipLaunchKernelGGL((colwise_burst_kernel<N, OP, VEC, true>), dim3(cus), dim3(kBurstThreads), 0, stream, rows,
-                               nvec, tail, f, inv_keep, out_all + lo, rotate > 0 ? rotate : 0, stride_ok ? s : 0);
+                               nvec, tail, f, inv_keep, out_all + lo);
             BM_LAUNCH_CHECK();
             continue;
           }
         }
         hipLaunchKernelGGL((colwise_burst_kernel<N, OP, VEC>), dim3(cus), dim3(kBurstThreads), 0, stream, rows, nvec,
-                           tail, f, inv_keep, out_all + lo, 0, 0);
+                           tail, f, inv_keep, out_all + lo);
         BM_LAUNCH_CHECK();
         continue;
       }

@@ -169,17 +169,13 @@ __global__ __launch_bounds__(kColBlock) void colwise_kernel(RowTable rows, int64
 constexpr int kBurstThreads = 1024;
 constexpr int kBurstLdsBytes = 160 * 1024;
 
-// PLACED (experiments on rows whose start addresses are congruent modulo the channel interleave — one allocation per
-// row, what a caller of the rules has): the same kernel with two run-time choices about WHERE a wave's loads fall.
-//   rotate k:  wave w of the grid loads the rows in the order (i + k w) mod N instead of 0 .. N-1 (pointers fetched
-//              from the kernarg segment with a scalar offset; the rule sorts, so the result does not depend on it);
-//   stride s:  the four 256-byte quarters of a wave's 1 KB load lie 2^s * 256 bytes apart instead of side by side
-//              (a bijection of the column groups of one iteration of the grid, computed once per lane).
-// rotate = stride = 0 is the plain kernel.
-template <int N, int OP, int VEC, bool PLACED = false>
+// PLAIN (experiment on rows whose start addresses are congruent modulo 2 MB — one allocation per row, what a caller
+// of the rules has): the row loads without the non-temporal hint.  (Two other placements of a wave's loads were measured
+// on such rows and changed nothing or cost 1-4 %: rotating the row order per wave, and spreading the four 256-byte
+// quarters of a wave's 1 KB load 1 KB .. 256 KB apart — profiles/r05_b_col_placement_probe.txt; removed.)
+template <int N, int OP, int VEC, bool PLAIN = false>
 __global__ __launch_bounds__(kBurstThreads) void colwise_burst_kernel(RowTable rows, int64_t nvec, int tail, int f,
-                                                                      float inv_keep, float* __restrict__ out,
-                                                                      int rotate = 0, int stride_log2 = 0) {
+                                                                      float inv_keep, float* __restrict__ out) {
   static_assert(OP == BM_OP_MEDIAN || OP == BM_OP_TRMEAN, "the closest-to-centre rules need the LDS for themselves");
   using V = typename VecLoad<VEC>::T;
   constexpr int kSlots = kBurstLdsBytes / (kBurstThreads * VEC * (int)sizeof(float));
@@ -187,25 +183,7 @@ __global__ __launch_bounds__(kBurstThreads) void colwise_burst_kernel(RowTable r
   const uint32_t nv = (uint32_t)nvec, tid = threadIdx.x;
   const uint32_t span = gridDim.x * kBurstThreads;  // column groups per iteration of the whole grid
   const uint32_t iters = (nv + span - 1) / span;
-  uint32_t first = blockIdx.x * kBurstThreads + tid;
-  if constexpr (PLACED) {
-    if (stride_log2 > 0) {  // (the host checks that 4 * 2^s waves divide the grid's waves)
-      const uint32_t x = first & 15u, u = first >> 4, q = u & 3u, w = u >> 2;
-      const uint32_t wi = w & ((1u << stride_log2) - 1u), wb = w >> stride_log2;
-      first = ((((wb << 2) + q) << stride_log2) + wi) * 16u + x;
-    }
-    if (rotate > 0) {
-      typedef const float* __attribute__((address_space(4))) const* KargTable;
-      const KargTable karg = (KargTable)__builtin_amdgcn_kernarg_segment_ptr();  // the row table is the first argument
-      const uint32_t wave = __builtin_amdgcn_readfirstlane((blockIdx.x * kBurstThreads + tid) >> 6);
-      const uint32_t rot = (wave * (uint32_t)rotate) % (uint32_t)N;
-#pragma unroll
-      for (int i = 0; i < N; ++i) {
-        const uint32_t j = (uint32_t)i + rot;
-        rows.p[i] = (const float*)karg[j >= (uint32_t)N ? j - N : j];
-      }
-    }
-  }
+  const uint32_t first = blockIdx.x * kBurstThreads + tid;
   for (uint32_t p0 = 0; p0 < iters; p0 += kSlots) {
     const uint32_t p1 = (p0 + kSlots < iters) ? p0 + kSlots : iters;
     for (uint32_t it = p0; it < p1; ++it) {
@@ -216,7 +194,17 @@ __global__ __launch_bounds__(kBurstThreads) void colwise_burst_kernel(RowTable r
 #pragma unroll
         for (int i = 0; i < N; ++i) {
           float t[VEC];
-          load_stream_off<VEC>(rows.p[i], off, t);
+          if constexpr (PLAIN) {
+            const V raw = *reinterpret_cast<const V*>(reinterpret_cast<const char*>(rows.p[i]) + off);
+            if constexpr (VEC == 1) {
+              t[0] = raw;
+            } else {
+#pragma unroll
+              for (int c = 0; c < VEC; ++c) t[c] = raw[c];
+            }
+          } else {
+            load_stream_off<VEC>(rows.p[i], off, t);
+          }
 #pragma unroll
           for (int c = 0; c < VEC; ++c) x[c][i] = t[c];
         }

@@ -493,7 +493,7 @@ __global__ __launch_bounds__(64 * kGramRedWaves) void gram_reduce_sqdist_kernel(
   }
   if (rk.on) {
     __syncthreads();  // the distances in LDS and the count
-    if (last == 0) krum_rank_from_distances(lds, n_full, rk.f, rk.m, rk.mode, rk.order, rk.scores);
+    if (last == 0) krum_rank_from_distances(lds, n_full, rk.f, rk.m, rk.mode, rk.order, rk.scores, rk.bitonic != 0);
   }
 }
 

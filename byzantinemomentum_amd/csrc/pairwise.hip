@@ -392,7 +392,7 @@ __global__ __launch_bounds__(kPairMaxThreads) void pairwise_partial_kernel(
   if (rk.on) {
     __threadfence();
     __syncthreads();  // the corrected distances of this workgroup's own stores are visible to all its lanes
-    krum_rank_body(sq, n_full, rk.f, rk.m, rk.mode, rk.order, rk.scores, reinterpret_cast<double*>(smem));
+    krum_rank_body(sq, n_full, rk.f, rk.m, rk.mode, rk.order, rk.scores, reinterpret_cast<double*>(smem), rk.bitonic != 0);
   }
 }
 
@@ -437,9 +437,9 @@ constexpr int kRankThreads = 1024;
 __global__ __launch_bounds__(kRankThreads) void krum_rank_kernel(const double* __restrict__ sq, int n,
                                                                  int f, int m, int mode,
                                                                  int32_t* __restrict__ order,
-                                                                 double* __restrict__ scores_out) {
+                                                                 double* __restrict__ scores_out, int bitonic) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // rank_lds_bytes(n)
-  krum_rank_body(sq, n, f, m, mode, order, scores_out, reinterpret_cast<double*>(smem));
+  krum_rank_body(sq, n, f, m, mode, order, scores_out, reinterpret_cast<double*>(smem), bitonic != 0);
 }
 
 }  // namespace bm
@@ -580,7 +580,7 @@ extern "C" int bm_krum_rank(const double* sq_nxn, int n, int f, int m, int mode,
     if (e != hipSuccess) return hip_code(e);
   }
   hipLaunchKernelGGL(krum_rank_kernel, dim3(1), dim3(kRankThreads), rank_lds_bytes(n), static_cast<hipStream_t>(stream),
-                     sq_nxn, n, f, m, mode, order_out, scores_out);
+                     sq_nxn, n, f, m, mode, order_out, scores_out, rank_bitonic(n) ? 1 : 0);
   BM_LAUNCH_CHECK();
   return 0;
 }
@@ -600,7 +600,7 @@ extern "C" int bm_pairwise_rank(const float* const* rows, int n, int64_t d, int6
   // accuracy gate lists nothing, by the last workgroup of the gated direct kernel when it does (round 4 ranked in the
   // gated launch in both cases — 2-3 waves, one row at a time: 16.5 us of a 21 us launch at n = 25 — and kept a rank
   // launch of its own beyond 32 rows: 13.4 us at n = 51; profiles/r05_b_full_kernel_trace.csv).
-  const RankArgs req{1, f, m, mode, order_out, scores_out};
+  const RankArgs req{1, f, m, mode, rank_bitonic(n) ? 1 : 0, order_out, scores_out};
   return pairwise_gram_path(rows, n, d, d_total, sq_nxn, ws, &req, s);
 }
 

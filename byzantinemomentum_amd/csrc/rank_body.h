@@ -13,7 +13,7 @@ namespace bm {
 // kernarg segment): rank the rows from the final distances.  `on` = 1: the last workgroup of the Gram reduction ranks
 // when the accuracy gate listed nothing (the common case), the gated direct kernel when it did.
 struct RankArgs {
-  int on, f, m, mode;
+  int on, f, m, mode, bitonic;
   int32_t* order;
   double* scores;
 };
@@ -32,31 +32,53 @@ __device__ __forceinline__ double rank_distance(double sq) {
 // bytes, 8-byte aligned, D first.  Every lane of the workgroup must call (barriers inside), after a barrier that made D
 // visible.
 //
-// Every distance finds its place in its row by COUNTING — pair (i, j) counts the k with d_ik < d_ij, ties to the lower
-// index — all n (n - 1) pairs at once across the workgroup (n reads of LDS each, the lanes of a wave share i and read
-// the same address: broadcasts), and is scattered to S[i][place]; then lane i adds the `take` smallest of row i in
-// ascending order in fp64 — the same sequence of additions as the reference's `sum(sorted(...)[:take])` — and the rows
-// are ranked by score, ties to the lower index (Python's stable sort).  (Round 4 sorted each row across the 64 lanes of
-// one wave with a bitonic network of 21 dependent cross-lane exchanges: 8.5 us at n = 25 and 13 us at n = 51 with 16
-// waves, profiles/r05_c_full_kernel_trace.csv; counting is ~1 us at both.)
+// Two ways to put a row's distances in ascending order into S (`bitonic`, wave-uniform):
+//   counting (n <= 32): pair (i, j) counts the k with d_ik < d_ij, ties to the lower index — all n (n - 1) pairs at once
+//     across the workgroup, n broadcast reads of LDS each — and scatters d_ij to S[i][place]: n^3 compare steps in all,
+//     nothing dependent but the count itself;
+//   bitonic (n > 32): one wave per row, the row's n - 1 distances (+inf in the other lanes) sorted across the 64 lanes
+//     by a bitonic network (21 compare-exchange steps of one cross-lane exchange each): 21 n steps in all, a third of
+//     the instructions of counting at n = 51, but 21 dependent exchanges per row.
+// Then lane i adds the `take` smallest of row i in ascending order in fp64 — the same sequence of additions as the
+// reference's `sum(sorted(...)[:take])` (equal values in either order: the sums do not depend on it) — and the rows are
+// ranked by score, ties to the lower index (Python's stable sort).
 __device__ __forceinline__ void krum_rank_from_distances(double* lds, int n, int f, int m, int mode,
-                                                         int32_t* __restrict__ order, double* __restrict__ scores_out) {
+                                                         int32_t* __restrict__ order, double* __restrict__ scores_out,
+                                                         bool bitonic) {
   const double* D = lds;
   double* S = lds + n * n;
   double* score = S + n * (n - 1);
   const int tid = threadIdx.x, threads = (int)blockDim.x;
-  for (int e = tid; e < n * n; e += threads) {
-    const int i = e / n, j = e - i * n;
-    if (i == j) continue;
-    const double v = D[e];
-    const double* row = D + i * n;
-    int place = 0;
-#pragma unroll 8
-    for (int k = 0; k < n; ++k) {
-      const double dk = row[k];
-      place += (k != i && (dk < v || (dk == v && k < j))) ? 1 : 0;
+  if (bitonic) {
+    const double kInf = __builtin_inf();
+    const int wave = tid >> 6, lane = tid & 63, waves = threads >> 6;
+    for (int i = wave; i < n; i += waves) {
+      double v = (lane < n && lane != i) ? D[i * n + lane] : kInf;
+#pragma unroll
+      for (int k = 2; k <= 64; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+          const double o = __shfl_xor(v, j, 64);
+          const bool keep_min = ((lane & k) == 0) == ((lane & j) == 0);
+          v = keep_min ? __builtin_fmin(v, o) : __builtin_fmax(v, o);
+        }
+      }
+      if (lane < n - 1) S[i * (n - 1) + lane] = v;
     }
-    S[i * (n - 1) + place] = v;
+  } else {
+    for (int e = tid; e < n * n; e += threads) {
+      const int i = e / n, j = e - i * n;
+      if (i == j) continue;
+      const double v = D[e];
+      const double* row = D + i * n;
+      int place = 0;
+#pragma unroll 8
+      for (int k = 0; k < n; ++k) {
+        const double dk = row[k];
+        place += (k != i && (dk < v || (dk == v && k < j))) ? 1 : 0;
+      }
+      S[i * (n - 1) + place] = v;
+    }
   }
   __syncthreads();
   if (tid < n) {
@@ -87,10 +109,16 @@ __device__ __forceinline__ void krum_rank_from_distances(double* lds, int n, int
 // The same from the n x n squared distances in device memory.
 __device__ __forceinline__ void krum_rank_body(const double* __restrict__ sq, int n, int f, int m, int mode,
                                                int32_t* __restrict__ order, double* __restrict__ scores_out,
-                                               double* lds) {
+                                               double* lds, bool bitonic) {
   for (int e = threadIdx.x; e < n * n; e += (int)blockDim.x) lds[e] = rank_distance(sq[e]);
   __syncthreads();
-  krum_rank_from_distances(lds, n, f, m, mode, order, scores_out);
+  krum_rank_from_distances(lds, n, f, m, mode, order, scores_out, bitonic);
+}
+
+// BM_RANK_ALGO: 0 (default) = by row count, 1 = bitonic, 2 = counting (A/B)
+inline bool rank_bitonic(int n) {
+  const int algo = tuning().rank_algo;
+  return algo == 1 || (algo != 2 && n > 32);
 }
 
 }  // namespace bm

@@ -17,11 +17,12 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _launch(*flags, timeout=420):
+def _launch(*flags, timeout=420, **environ):
   with socket.socket() as s:
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
   env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+  env.update(environ)
   cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
          "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", *flags]
   done = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=timeout)
@@ -48,8 +49,10 @@ def test_one_rank_launcher_run_fills_the_exchange_object():
 
 
 def test_a_deadline_that_fires_costs_the_exchange_legs_not_the_line():
+  # (the rank hangs for 60 s where the exchange legs start — what a peer lost in a collective looks like — with a
+  #  deadline of 2 s: the line must come from the deadline, with the headline and the reason)
   done, lines = _launch("--workload", "bulyan", "--dim", "2000003", "--steps", "3", "--warmup", "1", "--no-cpu-baseline",
-                        "--no-traffic", "--extras-timeout", "0.05")
+                        "--no-traffic", "--extras-timeout", "2", BM_BENCH_STALL_S="60")
   assert done.returncode == 0, done.stderr[-3000:]
   assert len(lines) == 1, done.stdout[-2000:]
   line = json.loads(lines[0])
