@@ -13,8 +13,12 @@ import pathlib
 
 import torch  # noqa: F401  (must be imported before the CDLL, see above)
 
+import os
+
 _PKG_DIR = pathlib.Path(__file__).resolve().parent
-LIB_PATH = _PKG_DIR / "libbm_gar.so"
+# BM_GAR_LIB: another build of the SAME library (A/B runs of a kernel against an older version of itself,
+# scripts/gram_variant_probe.py); the default, and the only thing the tests and the bench load, is the in-tree build.
+LIB_PATH = pathlib.Path(os.environ["BM_GAR_LIB"]).resolve() if os.environ.get("BM_GAR_LIB") else _PKG_DIR / "libbm_gar.so"
 
 ABI_VERSION = 18
 MAX_ROWS = 64

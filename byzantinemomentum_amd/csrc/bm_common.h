@@ -284,7 +284,6 @@ struct Tuning {
   int gram_steady;     // BM_GRAM_STEADY: 1 (default) = the condition-free steady-state loop of the Gram kernel, 0 = the generic loop only (A/B)
   int bulyan_short;    // BM_BULYAN_SHORT: 1 (default) = Bulyan pass 2 searches its window among the positions that straddle the median only (same bits), 0 = all positions (A/B)
   int pair_load_nt;    // BM_PAIR_LOAD_NT: 1 (default) = the Gram kernel's row loads carry the non-temporal hint, 0 = default cache policy (aligned rows; A/B with BM_SECOND_PASS_REVERSE: does the tail of the rows stay in the Infinity Cache for the second pass?)
-  int col_load_plain;  // BM_COL_LOAD_PLAIN (burst form of median / trmean at n = 25): 1 = row loads without the non-temporal hint (experiment); 0 (default) = non-temporal
   int rank_algo;       // BM_RANK_ALGO: how the rows' distances are put in order for the scores (rank_body.h): 0 (default) = counting up to 32 rows, a bitonic network per row beyond; 1 = bitonic, 2 = counting (A/B; same scores)
   int second_pass_reverse;  // BM_SECOND_PASS_REVERSE: 1 = the second pass of a two-pass rule (selected mean, Bulyan pass 2) walks the columns from the END (the distance pass before it finished there; same bits); 0 (default) = from the start — measured on one box, alternating: the reversed walk is 0-1 % SLOWER at C3 / C4 / CGE and a wash for Aksel (profiles/r05_a_second_pass_walk_ab.txt)
 };

@@ -138,8 +138,9 @@ struct BruteWave {
 //      bounds) number (2w+1)/(2W) of the way through the row-major enumeration of the open ones — W pivots that are
 //      random in VALUE — and the bounds close in on the tightest answers: the open set shrinks ~W/2-fold per round
 //      (n = 25: 300 pairs, 3 rounds; n = 51: 1 275 pairs, 4 rounds) instead of 2-fold per sequential probe;
-//   3. the lexicographically first set in G(t*): the W lowest rows still in play are tried at once, the lowest one
-//      that extends is taken; as soon as what is left has exactly the size that is needed, it IS the rest.
+//   3. the lexicographically first set in G(t*): first the rows that lie in some such set at all (n independent
+//      questions; when exactly n - f rows pass, they are the answer: the usual case), then position by position with W
+//      prefixes of the lowest open rows per round, the longest prefix that extends taken whole.
 // Every wave keeps the (wave-uniform) state of the search itself and recomputes the cheap parts; only the W answers
 // of a round travel through LDS.  The answers are those of the sequential search: G(t) only grows with t, and the
 // extraction takes the same row at every position.
@@ -153,6 +154,7 @@ __global__ __launch_bounds__(64 * kBruteWaves) void brute_select_kernel(const do
   __shared__ double piv[kBruteWaves];
   __shared__ int res[kBruteWaves];   // 1 / 0: the answer of wave w this round; -1: it asked nothing
   __shared__ int over[kBruteWaves];  // wave w ran out of its node budget
+  __shared__ uint64_t cores[kBruteWaves];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int k = n - f;
@@ -278,15 +280,32 @@ __global__ __launch_bounds__(64 * kBruteWaves) void brute_select_kernel(const do
     if (over2) return give_up(-2, 0);
   }
 
-  // ---- 3. the first subset in lexicographic order in G(hi): the smallest row that still leaves a completion among
-  //         the rows above it, position by position ----
+  // ---- 3. the first subset in lexicographic order in G(hi) ----
   w.build(hi);
-  uint64_t cand = everyone;  // rows still in play: adjacent to every chosen row, above the last chosen one
-  uint64_t skipped = 0;      // rows of `cand` that were tried at this position and do not extend
+  // 3a. the CORE: the rows that lie in some set of k mutually adjacent rows — n independent questions, wave v asks
+  //     them for rows v, v + W, ...  No other row can be chosen at any position (the sequential search asks the same
+  //     question with fewer rows in play), and when exactly k rows are left they ARE the answer: the usual case (the
+  //     set of smallest diameter is unique), one barrier.
+  uint64_t mine_core = 0;
+  for (int c = wave; c < n; c += kBruteWaves)
+    if (w.has_clique(readlane64(w.adj, c), k - 1)) mine_core |= (uint64_t)1 << c;
+  if (lane == 0) {
+    cores[wave] = mine_core;
+    if (w.exhausted) over[wave] = 1;
+  }
+  __syncthreads();
+  uint64_t cand = 0;  // rows still in play: in the core, adjacent to every chosen row, above the last chosen one
+#pragma unroll
+  for (int v = 0; v < kBruteWaves; ++v) cand |= cores[v];
+  if (any_over()) return give_up(-2, 0);
+  // 3b. position by position: a round tries the prefixes c_0, c_0 c_1, ... of the W lowest open rows — wave v takes
+  //     c_0 .. c_{v-1} for chosen and asks whether c_v still extends — and the longest prefix of "yes" is taken whole;
+  //     the row behind it has then failed exactly the question the sequential search would have asked at that position.
+  uint64_t skipped = 0;  // rows of `cand` that were tried at this position and do not extend
   int chosen = 0;
   int32_t mine_sel = 0;
   while (chosen < k) {
-    const uint64_t open = cand & ~skipped;
+    skipped &= cand;
     if (__builtin_popcountll(cand) == k - chosen && skipped == 0) {
       // what is left has exactly the size that is needed, and it holds a completion: it is the completion
       const int my = lane - chosen;
@@ -298,48 +317,44 @@ __global__ __launch_bounds__(64 * kBruteWaves) void brute_select_kernel(const do
       chosen = k;
       break;
     }
+    const uint64_t open = cand & ~skipped;
     if (open == 0) break;  // (cannot happen while the invariant holds: status -1 below)
-    // wave v tries the v-th lowest open row
-    uint64_t rest = open;
-    for (int t = 0; t < wave && rest != 0; ++t) rest &= rest - 1;
-    answer = -1;
-    uint64_t next = 0;
+    // wave v: the state after c_0 .. c_{v-1}, then c_v
+    uint64_t state = cand, rest = open;
+    bool in_play = true;
     int c = 64;
-    if (rest != 0) {
+    for (int t = 0; t <= wave && in_play; ++t) {
+      if (rest == 0) {
+        in_play = false;
+        break;
+      }
       c = __builtin_ctzll(rest);
+      rest &= rest - 1;
       const uint64_t above = c == 63 ? 0 : ~(((uint64_t)1 << (c + 1)) - 1);
-      next = cand & readlane64(w.adj, c) & above;
-      answer = w.has_clique(next, k - chosen - 1) ? 1 : 0;
+      if ((state & ((uint64_t)1 << c)) == 0) in_play = false;  // (not adjacent to an earlier row of the prefix)
+      state = state & readlane64(w.adj, c) & above;
     }
-    publish((double)c, answer);
-    int winner = -1;
+    answer = -1;
+    if (in_play && chosen + wave + 1 <= k) answer = w.has_clique(state, k - chosen - wave - 1) ? 1 : 0;
+    publish(0.0, answer);
+    int accepted = 0;  // the longest run of "yes" from wave 0 (the answers are monotone: a prefix of a prefix extends)
 #pragma unroll
-    for (int v = kBruteWaves - 1; v >= 0; --v)
-      if (res[v] == 1) winner = v;
+    for (int v = 0; v < kBruteWaves; ++v) accepted += (accepted == v && res[v] == 1) ? 1 : 0;
     const bool over3 = any_over();
     __syncthreads();
     if (over3) return give_up(-2, 0);
-    // the rows tried this round, lowest first (every wave walks the same `open`)
-    uint64_t tried = 0, walk = open;
-    int win_row = 64;
-    for (int v = 0; v < kBruteWaves && walk != 0; ++v) {
+    // every wave replays the accepted prefix on its own copy of the state
+    uint64_t walk = open;
+    for (int v = 0; v < accepted; ++v) {
       const int row = __builtin_ctzll(walk);
-      if (v == winner) {
-        win_row = row;
-        break;
-      }
-      tried |= (uint64_t)1 << row;
       walk &= walk - 1;
+      if (lane == chosen + v) mine_sel = row;
+      const uint64_t above = row == 63 ? 0 : ~(((uint64_t)1 << (row + 1)) - 1);
+      cand = cand & readlane64(w.adj, row) & above;
     }
-    if (winner < 0) {
-      skipped |= tried;
-      continue;
-    }
-    if (lane == chosen) mine_sel = win_row;
-    ++chosen;
-    const uint64_t above = win_row == 63 ? 0 : ~(((uint64_t)1 << (win_row + 1)) - 1);
-    cand = cand & readlane64(w.adj, win_row) & above;
-    skipped = 0;
+    chosen += accepted;
+    if (accepted > 0) skipped = 0;
+    if (walk != 0 && accepted < kBruteWaves && chosen < k) skipped |= (uint64_t)1 << __builtin_ctzll(walk);
   }
   if (wave == 0) {
     if (lane < BM_MAX_ROWS) sel_out[lane] = (chosen == k && lane < k) ? mine_sel : 0;

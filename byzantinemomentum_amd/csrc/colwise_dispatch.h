@@ -6,7 +6,6 @@
 
 namespace bm {
 
-constexpr int kPlacedRows = 25;    // the one row count with a PLAIN-load instance of the burst kernel (experiment)
 constexpr int kBurstMaxRows = 25;  // 4 waves per SIMD (1024 lanes per CU) leave 128 VGPRs: trmean at n = 25 just fits, n = 26 spills
 
 template <int N, int OP, int VEC>
@@ -26,14 +25,6 @@ static int launch_colwise_vec(const RowTable& rows_all, int64_t d_all, int f, fl
       const int cus = compute_units();
       const int64_t burst_iters = nvec / ((int64_t)cus * kBurstThreads);
       if (tuning().col_burst > 0 && burst_iters >= tuning().col_burst) {
-        if constexpr (N == kPlacedRows) {  // the load-policy experiment (BM_COL_LOAD_PLAIN), one shape
-          if (tuning().col_load_plain != 0) {
-            hipLaunchKernelGGL((colwise_burst_kernel<N, OP, VEC, true>), dim3(cus), dim3(kBurstThreads), 0, stream, rows,
-                               nvec, tail, f, inv_keep, out_all + lo);
-            BM_LAUNCH_CHECK();
-            continue;
-          }
-        }
         hipLaunchKernelGGL((colwise_burst_kernel<N, OP, VEC>), dim3(cus), dim3(kBurstThreads), 0, stream, rows, nvec,
                            tail, f, inv_keep, out_all + lo);
         BM_LAUNCH_CHECK();

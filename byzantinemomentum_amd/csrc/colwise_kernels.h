@@ -169,11 +169,14 @@ __global__ __launch_bounds__(kColBlock) void colwise_kernel(RowTable rows, int64
 constexpr int kBurstThreads = 1024;
 constexpr int kBurstLdsBytes = 160 * 1024;
 
-// PLAIN (experiment on rows whose start addresses are congruent modulo 2 MB — one allocation per row, what a caller
-// of the rules has): the row loads without the non-temporal hint.  (Two other placements of a wave's loads were measured
-// on such rows and changed nothing or cost 1-4 %: rotating the row order per wave, and spreading the four 256-byte
-// quarters of a wave's 1 KB load 1 KB .. 256 KB apart — profiles/r05_b_col_placement_probe.txt; removed.)
-template <int N, int OP, int VEC, bool PLAIN = false>
+// Rows whose start addresses are congruent modulo 2 MB (one allocation per row: what a caller of the rules has) run
+// this kernel 0-10 % slower than rows cut out of one allocation at a skewed stride, depending on the box (0 % on one,
+// 5-6 % on two, 10 % on the round-4 driver box).  Three kernel-side remedies were measured on such rows, each in one
+// process alternating with this kernel on the same data, and removed: the row order rotated per wave (no change), the
+// four 256-byte quarters of a wave's 1 KB load spread 1 KB .. 256 KB apart (0-4 % slower), the row loads without the
+// non-temporal hint (11 % slower, on the slab as well) — profiles/r05_b_col_placement_probe.txt,
+// profiles/r05_e_col_load_policy_probe.txt.
+template <int N, int OP, int VEC>
 __global__ __launch_bounds__(kBurstThreads) void colwise_burst_kernel(RowTable rows, int64_t nvec, int tail, int f,
                                                                       float inv_keep, float* __restrict__ out) {
   static_assert(OP == BM_OP_MEDIAN || OP == BM_OP_TRMEAN, "the closest-to-centre rules need the LDS for themselves");
@@ -194,17 +197,7 @@ __global__ __launch_bounds__(kBurstThreads) void colwise_burst_kernel(RowTable r
 #pragma unroll
         for (int i = 0; i < N; ++i) {
           float t[VEC];
-          if constexpr (PLAIN) {
-            const V raw = *reinterpret_cast<const V*>(reinterpret_cast<const char*>(rows.p[i]) + off);
-            if constexpr (VEC == 1) {
-              t[0] = raw;
-            } else {
-#pragma unroll
-              for (int c = 0; c < VEC; ++c) t[c] = raw[c];
-            }
-          } else {
-            load_stream_off<VEC>(rows.p[i], off, t);
-          }
+          load_stream_off<VEC>(rows.p[i], off, t);
 #pragma unroll
           for (int c = 0; c < VEC; ++c) x[c][i] = t[c];
         }

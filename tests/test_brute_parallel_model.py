@@ -91,30 +91,40 @@ def parallel_search(dist, n, f, waves=W):
         if not yes and pivot > lo:
           lo = pivot
   adj = _graph(dist, n, hi)
-  cand, skipped, chosen, sel, rounds3 = everyone, 0, 0, [], 0
+  # 3a. the rows that lie in SOME set of k mutually adjacent rows (n independent questions, `waves` at a time): no other
+  #     row can be chosen at any position, and when exactly k rows are left they are the answer
+  core = sum(1 << c for c in range(n) if _has_clique(adj, adj[c], k - 1))
+  rounds3 = -(-n // waves)
+  if bin(core).count("1") == k:
+    return 0, [i for i in range(n) if core >> i & 1], rounds, rounds3
+  # 3b. position by position among the rows of the core; a round tries the prefixes c_0, c_0 c_1, ... of the lowest
+  #     open rows (wave v assumes c_0 .. c_{v-1} chosen): the longest prefix that extends is taken whole, and the row
+  #     behind it has then failed exactly the question the sequential search would have asked
+  cand, skipped, chosen, sel = core, 0, 0, []
   while chosen < k:
+    open_rows = [i for i in range(n) if (cand & ~skipped) >> i & 1]
     if bin(cand).count("1") == k - chosen and skipped == 0:
       sel += [i for i in range(n) if cand >> i & 1]
       chosen = k
       break
-    open_rows = [i for i in range(n) if (cand & ~skipped) >> i & 1]
     if not open_rows:
       return -1, None, rounds, rounds3
     rounds3 += 1
     tried = open_rows[:waves]
-    winner = None
-    for c in tried:
-      nxt = cand & adj[c] & ~((1 << (c + 1)) - 1)
-      if _has_clique(adj, nxt, k - chosen - 1):
-        winner = c
-        break  # (the kernel evaluates all of them at once and keeps the lowest that extends)
-    if winner is None:
-      skipped |= sum(1 << c for c in tried)
-      continue
-    sel.append(winner)
-    chosen += 1
-    cand = cand & adj[winner] & ~((1 << (winner + 1)) - 1)
-    skipped = 0
+    accepted, state = 0, cand
+    for v, c in enumerate(tried):
+      if chosen + v + 1 > k:
+        break
+      nxt = state & adj[c] & ~((1 << (c + 1)) - 1)
+      if not (state >> c & 1) or not _has_clique(adj, nxt, k - chosen - v - 1):  # (c must still be in play)
+        break  # (answers are monotone in v: the kernel takes the longest run of "yes" from v = 0)
+      state, accepted = nxt, v + 1
+    sel += tried[:accepted]
+    chosen += accepted
+    if accepted > 0:
+      cand, skipped = state, 0
+    if accepted < len(tried) and chosen < k:
+      skipped |= 1 << tried[accepted]   # it failed with exactly the prefix the sequential search would have had
   return 0, sel, rounds, rounds3
 
 
@@ -158,7 +168,7 @@ def test_parallel_search_at_the_reference_shapes(n, f):
     status, got, r2, r3 = parallel_search(dist, n, f)
     assert rc == 0 and status == 0 and got == want, (n, f, trial)
     worst2, worst3 = max(worst2, r2), max(worst3, r3)
-  assert worst2 <= 6 and worst3 <= n, (worst2, worst3)
+  assert worst2 <= 6 and worst3 <= 4 + 2 * f + 3, (worst2, worst3)
 
 
 def test_parallel_search_with_fewer_open_candidates_than_waves():

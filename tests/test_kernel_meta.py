@@ -13,8 +13,8 @@ ROOT = pathlib.Path(__file__).resolve().parent.parent
 # (regex on the demangled name, VGPR ceiling): the ceiling is what the launch bounds of the kernel aim at
 # (168 = three workgroups of 256 lanes per CU, 128 = one workgroup of 1024 lanes per CU ... DESIGN 4)
 HOT = [
-  (r"colwise_burst_kernel<25, 0, 4, (true|false)>", 128),          # C2 median (true: the placement experiments)
-  (r"colwise_burst_kernel<25, 1, 4, (true|false)>", 128),          # C2 trimmed mean
+  (r"colwise_burst_kernel<25, 0, 4>", 128),          # C2 median
+  (r"colwise_burst_kernel<25, 1, 4>", 128),          # C2 trimmed mean
   (r"gram3_partial_kernel<7, 2, true, (true|false)>", 168),        # C4 distance pass (n = 25, two planes)
   (r"gram3_partial_kernel<13, 2, true, (true|false)>", 256),       # C3 distance pass (n = 51)
   (r"bulyan_pass2_kernel<25, 5, 4>", 128),           # C4 pass 2
