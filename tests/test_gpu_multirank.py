@@ -88,6 +88,40 @@ def _bulyan_mismatch_report(bm, agg, local, full, got, want, bad, lo, hi, kind):
           f"unsharded pass 2 from its ranking alone {int(((pass2_single[lo:hi] - host).abs() > tol).sum())}")
 
 
+def _step_mismatch_report(bm, single, got_def, want_def, off, lo, hi, gar, it):
+  """A step whose sharded defense vector differs from the single-rank step's: where, by how much, and whether the
+  single-rank side agrees with the rule applied to ITS OWN momentum buffers and Byzantine vector (no collective here:
+  the peers may have passed and moved on)."""
+  idx = off.nonzero().flatten()
+  blocks = torch.unique(idx // 1024)
+  rows = list(single.buffers) + [single.last_byzantine] * F
+  rule = bm.krum if gar == "krum" else bm.bulyan
+  again = rule(rows, F)
+  order = (bm.gars.krum_selection(rows, F) if gar == "krum" else bm.gars.bulyan_ranking(rows, F))
+  host = (O.krum if gar == "krum" else O.bulyan)([r.cpu() for r in rows], F).to(DEV)
+  tol = 2e-6 * max(float(want_def.abs().max()), 1e-30)
+  return (f"step {it}, rule {gar}: {int(off.sum())} coordinates of [{lo}, {hi}) differ (max "
+          f"{float((got_def - want_def[lo:hi]).abs().max()):.3e}, scale {float(want_def.abs().max()):.3e}); first "
+          f"{int(idx[0])}, last {int(idx[-1])}, in {blocks.numel()} blocks of 1024 ({blocks[:8].tolist()}...); the rule "
+          f"on the single-rank step's own buffers: {int(((again - want_def).abs() > tol).sum())} coordinates off its "
+          f"defense vector over the whole length, {int(((again[lo:hi] - got_def).abs() > tol).sum())} off the sharded "
+          f"one on this slice; the oracle on the host on the same buffers: {int(((host - want_def).abs() > tol).sum())} "
+          f"off the single-rank defense, {int(((host[lo:hi] - got_def).abs() > tol).sum())} off the sharded one; ranking "
+          f"of the buffers {order[:20]}")
+
+
+def _poison_allocator():
+  """Fill what torch's caching allocator will hand out next with NaN bit patterns (0x7fc00000: NaN as a float, a
+  huge count as an integer): a kernel that reads memory nobody wrote — an arrival counter assumed zero, a slot past
+  the rows, an output block never stored — then fails every time instead of only when the memory happens to hold
+  something else than a previous run's identical result."""
+  big = torch.full((1 << 28,), math.nan, dtype=torch.float32, device=DEV)
+  mid = [torch.full((1 << 14,), math.nan, dtype=torch.float32, device=DEV) for _ in range(512)]
+  tiny = [torch.full((128,), math.nan, dtype=torch.float32, device=DEV) for _ in range(4096)]
+  torch.cuda.synchronize()
+  del big, mid, tiny
+
+
 def _close(a, b, tol, what):
   scale = max(float(b.abs().max()) if b.numel() else 0.0, 1e-30)
   err = float((a - b).abs().max()) if b.numel() else 0.0
@@ -123,6 +157,7 @@ def _rank_body(rank, world, rendezvous, d, queue):
                           timeout=datetime.timedelta(seconds=180))
   try:
     torch.cuda.set_device(0)
+    _poison_allocator()
     import byzantinemomentum_amd as bm
     from byzantinemomentum_amd.sharded import HipBackend, ShardedAggregator, owned_workers, shard_bounds
     from byzantinemomentum_amd.step import AggregationStep
@@ -199,7 +234,10 @@ def _rank_body(rank, world, rendezvous, d, queue):
         if gar == "median":
           assert torch.equal(got_def, want_def[lo:hi]), (gar, it)
         else:
-          _close(got_def, want_def[lo:hi], 2e-6, (gar, it))
+          scale = max(float(want_def.abs().max()), 1e-30)
+          off = (got_def - want_def[lo:hi]).abs() > 2e-6 * scale
+          if bool(off.any()):
+            raise AssertionError(_step_mismatch_report(bm, single, got_def, want_def, off, lo, hi, gar, it))
         for key, val in want.items():
           g = got[key]
           assert (math.isnan(g) and math.isnan(val)) or abs(g - val) <= 1e-6 * max(abs(val), 1e-6), (gar, it, key, g, val)
