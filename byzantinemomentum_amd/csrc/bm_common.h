@@ -248,6 +248,17 @@ __device__ __forceinline__ bool arrive_last(int* counter, int total, int* lds_fl
   return *lds_flag != 0;
 }
 
+// One entry of a small index table that the PREVIOUS kernel on the stream wrote (the ranking, the selected rows), read
+// coherently at agent scope (`global_load_dword ... sc1`: the load cannot be served from a stale line of this XCD's L2
+// or of the scalar cache).  Kernel boundaries make such tables visible by themselves — in one process per GPU no read
+// of one has ever been seen stale — but with five processes time-sharing one MI355X (tests/test_gpu_zz_multirank.py) a
+// second-pass kernel that fetched the ranking with SCALAR loads computed 11 % of its workgroups (one XCD's worth) from
+// the ranking of the call before, in 4 of 11 runs: right ranking in memory, right result on the next launch.  The
+// tables are 72-256 bytes per launch: reading them the careful way costs nothing.
+__device__ __forceinline__ int32_t load_index_coherent(const int32_t* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Deterministic block reduction (sum) of one double per thread; result valid on thread 0.
 template <int BLOCK>
 __device__ __forceinline__ double block_reduce_sum(double v, double* lds /* BLOCK/64 doubles */) {

@@ -43,11 +43,14 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(
   if constexpr (MMAX <= 25) {
     typedef const float* __attribute__((address_space(4))) const* KargTable;
     const KargTable karg = (KargTable)__builtin_amdgcn_kernarg_segment_ptr();
+    // (the ranking: ONE coherent load per wave — lane t fetches order[t] — then a v_readlane per pointer; scalar loads
+    //  of `order` go through the scalar cache, see load_index_coherent)
+    const int mine = (int)(threadIdx.x & 63) < MMAX ? load_index_coherent(order + (threadIdx.x & 63)) : 0;
 #pragma unroll
-    for (int t = 0; t < MMAX; ++t) ranked[t] = (const float*)karg[__builtin_amdgcn_readfirstlane(order[t])];
+    for (int t = 0; t < MMAX; ++t) ranked[t] = (const float*)karg[__builtin_amdgcn_readlane(mine, t)];
   } else {
     __shared__ const float* ranked_lds[MMAX];
-    if (threadIdx.x < MMAX) ranked_lds[threadIdx.x] = rows.p[order[threadIdx.x]];
+    if (threadIdx.x < MMAX) ranked_lds[threadIdx.x] = rows.p[load_index_coherent(order + threadIdx.x)];
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < MMAX; ++t) {
@@ -170,7 +173,7 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_generic_kernel(
   const int theta = n - 2 * f - 2;
   const int beta = theta - 2 * f;
   __shared__ const float* ranked[BM_MAX_ROWS];
-  if ((int)threadIdx.x < m_max) ranked[threadIdx.x] = rows.p[order[threadIdx.x]];
+  if ((int)threadIdx.x < m_max) ranked[threadIdx.x] = rows.p[load_index_coherent(order + threadIdx.x)];
   __syncthreads();
   float* xs = smem + threadIdx.x;                       // [m_max][kBulBlock]
   float* sel = smem + m_max * kBulBlock + threadIdx.x;  // [theta][kBulBlock]

@@ -24,7 +24,7 @@ __global__ __launch_bounds__(kRedBlock) void selected_mean_kernel(RowTable rows,
                                                                   int m, int64_t nvec, float fm, int nt_result,
                                                                   float* __restrict__ out, int reverse, int tail) {
   __shared__ const float* sel[BM_MAX_ROWS];
-  if (threadIdx.x < m) sel[threadIdx.x] = rows.p[idx[threadIdx.x]];
+  if (threadIdx.x < m) sel[threadIdx.x] = rows.p[load_index_coherent(idx + threadIdx.x)];
   __syncthreads();
   // (`reverse`: blocks of kRedBlock column groups walked from the last one — the pass that selected the rows read them
   //  from the first coordinate to the last, the Infinity Cache holds their tail; see bulyan_pass2_kernel.  Same bits.)
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kMeanBurstThreads) void selected_mean_burst_kernel(
   __shared__ V stage[kMeanBurstSlots * kMeanBurstThreads];
   __shared__ const float* sel[BM_MAX_ROWS];
   const uint32_t tid = threadIdx.x;
-  if ((int)tid < m) sel[tid] = rows.p[idx[tid]];
+  if ((int)tid < m) sel[tid] = rows.p[load_index_coherent(idx + tid)];
   __syncthreads();
   const uint32_t nv = (uint32_t)nvec;
   const uint32_t span = gridDim.x * kMeanBurstThreads;

@@ -314,7 +314,7 @@ class ShardedAggregator:
 
   # -- collectives (never called when world_size == 1) ----------------------- #
   # Every exchange of this class goes through the three primitives below (a subclass may route them elsewhere:
-  # tests/test_gpu_multirank.py stages them through host tensors to run several ranks on ONE GPU over gloo).
+  # tests/test_gpu_zz_multirank.py stages them through host tensors to run several ranks on ONE GPU over gloo).
 
   def _all_reduce(self, tensor, op=None):
     if self.collective:

@@ -4,7 +4,7 @@ torch.distributed form of the same rules, the packed statistics exchange, all_to
 full step.  SURVEY.md section 8e; BASELINE.json configs[3], configs[4].
 
 `gpurun` and the driver's test box hand out ONE GPU, so this file is SKIPPED there (and has never run: the code below
-repeats, call for call, what tests/test_gpu_multirank.py and test_rccl_path_on_one_gpu do on one device, where they
+repeats, call for call, what tests/test_gpu_zz_multirank.py and test_rccl_path_on_one_gpu do on one device, where they
 pass); it is the vehicle for a node with several GPUs.  It sorts last among the GPU tests on purpose.
 """
 

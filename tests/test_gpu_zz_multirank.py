@@ -1,5 +1,8 @@
 """Several ranks of the dim-sharded path with the HIP kernels underneath — on ONE MI355X.
 
+(Collected LAST among the GPU tests on purpose: four or five processes share the one GPU here, its 4-rank case fails
+intermittently — DESIGN 8 — and a `-x` run must not lose the parity tests behind it.)
+
 `gpurun` hands out one GPU, so no RCCL job of more than one rank can run there; the gloo tests cover the
 partitioning logic with an oracle backend on CPU.  What neither covers is the REAL kernels on ragged and empty
 shards inside a multi-rank job.  Here 2-4 processes share `cuda:0`, each holds its coordinate slice as GPU tensors
@@ -200,7 +203,8 @@ def _rank_body(rank, world, rendezvous, d, queue):
         got, want = sharded(), single()
         assert got.shape[0] == hi - lo
         if name == "bulyan":  # pass 2 may keep either of two exactly tied deviations: allow isolated columns only if tied
-          bad = (got - want[lo:hi]).abs() > 2e-6 * float(want.abs().max())
+          # (`~(<=)`: a NaN — an output nobody stored, on poisoned memory — counts as a difference)
+          bad = ~((got - want[lo:hi]).abs() <= 2e-6 * float(want.abs().max()))
           if int(bad.sum()) > max(1, (hi - lo) // 10000):
             raise AssertionError(_bulyan_mismatch_report(bm, agg, local, full, got, want, bad, lo, hi, kind, kept["order"]))
         else:
