@@ -506,3 +506,15 @@ def test_device_rank_algorithm_equals_the_oracle():
           continue
         assert got_scores == list(want_scores), (n, f, variant, krum_mode)
         assert got_order == O._stable_order(list(want_scores)), (n, f, variant, krum_mode)
+
+
+def test_brute_status_codes_raise_what_they_mean():
+  """The device search's status: 0 passes, -1 is the reference's failed assertion (brute.py:68), -2 the node budget."""
+  import torch
+  from byzantinemomentum_amd import gars
+  gars.brute_check(torch.tensor([0], dtype=torch.int32))
+  gars.brute_check(None if gars.last_brute_status is None else torch.tensor([0], dtype=torch.int32))
+  with pytest.raises(RuntimeError, match="no subset of n-f rows has a finite diameter"):
+    gars.brute_check(torch.tensor([-1], dtype=torch.int32))
+  with pytest.raises(RuntimeError, match="budget"):
+    gars.brute_check(torch.tensor([-2], dtype=torch.int32))
