@@ -11,7 +11,7 @@ find $out/prof_full -name "*kernel_stats.csv" -exec cp {} $out/full_kernel_stats
 find $out/prof_full -name "*kernel_trace.csv" -exec cp {} $out/full_kernel_trace.csv \;
 rm -rf $out/prof_colwise $out/prof_full
 for i in 1 2 3 4 5; do
-  timeout 300 python -m pytest tests/test_gpu_multirank.py -m gpu -q -x -W always 2>&1 | tail -120 > $out/multirank_$i.log
+  timeout 300 python -m pytest tests/test_gpu_zz_multirank.py -m gpu -q -x -W always 2>&1 | tail -120 > $out/multirank_$i.log
   grep -q "passed" $out/multirank_$i.log && ! grep -q "failed\|repeating" $out/multirank_$i.log && echo "run $i clean" >> $out/multirank_summary.txt || echo "run $i NOT clean" >> $out/multirank_summary.txt
 done
 ls -la $out

@@ -4,7 +4,7 @@ set -u
 out=gpurun_out/r05_k; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp; cd /root/repo
 for i in 1 2; do
-  BM_TEST_POISON=0 timeout 500 python -m pytest tests/test_gpu_full_size_o1.py tests/test_gpu_multirank.py -m gpu -q > $out/multirank_after_full_size_$i.log 2>&1
+  BM_TEST_POISON=0 timeout 500 python -m pytest tests/test_gpu_full_size_o1.py tests/test_gpu_zz_multirank.py -m gpu -q > $out/multirank_after_full_size_$i.log 2>&1
   tail -3 $out/multirank_after_full_size_$i.log
 done
 ls -la $out
