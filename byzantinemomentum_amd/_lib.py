@@ -20,7 +20,7 @@ _PKG_DIR = pathlib.Path(__file__).resolve().parent
 # scripts/gram_variant_probe.py); the default, and the only thing the tests and the bench load, is the in-tree build.
 LIB_PATH = pathlib.Path(os.environ["BM_GAR_LIB"]).resolve() if os.environ.get("BM_GAR_LIB") else _PKG_DIR / "libbm_gar.so"
 
-ABI_VERSION = 18
+ABI_VERSION = 19
 MAX_ROWS = 64
 EINVAL = -100000
 ENOCOMM, ECOMM = -100001, -100002
@@ -51,8 +51,6 @@ SIGNATURES = {
                                       ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
   "bm_bulyan_pass2": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                      ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
-  "bm_bulyan_pass2_walk": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
-                                          ctypes.c_int64, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]),
   "bm_aksel_pass1": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
   "bm_stack_stats": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
@@ -115,9 +113,6 @@ SIGNATURES = {
   "bm_colwise_eval": (ctypes.c_int, [ctypes.c_int, _c_float_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p,
                                      ctypes.c_void_p]),
-  "bm_colwise_eval_walk": (ctypes.c_int, [ctypes.c_int, _c_float_pp, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
-                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_int, ctypes.c_void_p,
-                                          ctypes.c_void_p, ctypes.c_void_p]),
   "bm_pairwise_rank": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
                                       ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                       ctypes.c_void_p]),

@@ -19,8 +19,21 @@ LIB_PATH = PKG_DIR / "libbm_gar.so"
 INCLUDE_DIR = PKG_DIR.parent / "include"
 
 ARCH = "gfx950"
+# NO packed-fp32 VALU instructions (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32) in this library.  The SLP vectoriser
+# pairs independent fp32 chains into them — in Bulyan's second pass the suffix sums of neighbouring ranks: 497 packed
+# instructions, 398 of them with op_sel / op_sel_hi — and that kernel returned wrong coordinates in ~1.5 % of its
+# launches whenever several processes time-shared the GPU (always lanes 48-63 of one register of a wave, on inputs
+# nobody had written; several experiments per GPU is the reference's own deployment mode, reproduce.py:62-73,118).
+# The same source without the packed forms: 0 of 3 200 launch sets against 44 of 3 200 (profiles/r06_pass2_variants.txt,
+# DESIGN 8).  -fno-slp-vectorize stops the pairing; turning the `packed-fp32-ops` target feature off makes the code
+# generator unable to select the instructions at all, whatever the source or a later compiler does (the flag reaches
+# the host compilation too, which says it does not know the feature: filtered from the build's messages).
+# tests/test_kernel_meta.py disassembles the library and fails if one comes back.
+NO_PACKED_FP32 = ["-fno-slp-vectorize", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wall", "-Wno-unused-function",
             "-fno-gpu-rdc", "-ffp-contract=off"]
+if os.environ.get("BM_BUILD_PACKED_FP32", "0") in ("", "0"):  # (1: the A side of an A/B build, never shipped)
+  CXXFLAGS += NO_PACKED_FP32
 
 
 def _hipcc():
@@ -47,7 +60,7 @@ def _compile(src, obj):
   proc = subprocess.run(cmd, capture_output=True, text=True)
   if proc.returncode != 0:
     raise RuntimeError(f"hipcc failed on {src.name}:\n{proc.stderr}")
-  return proc.stderr
+  return "\n".join(line for line in proc.stderr.splitlines() if "packed-fp32-ops" not in line)
 
 
 def build(force=False, verbose=False):

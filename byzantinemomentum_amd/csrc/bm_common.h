@@ -205,6 +205,15 @@ static inline int common_vec_width(const void* const* ptrs, int n, const void* e
   return 1;
 }
 
+// Dynamic LDS beyond what a launch gets without asking: ONE rule for every kernel of the library.  A launch whose
+// dynamic + static LDS exceeds 48 KB opts in through hipFuncAttributeMaxDynamicSharedMemorySize (gfx950 has 160 KB per
+// workgroup; 48 KB is the most conservative default of the parts HIP runs on, so nothing here depends on a roomier
+// one).  `static_bytes`: the __shared__ arrays the kernel declares besides its dynamic segment.
+static inline int lds_opt_in(const void* kernel, size_t dynamic_bytes, size_t static_bytes) {
+  if (dynamic_bytes + static_bytes <= 48u * 1024u) return 0;
+  return hip_code(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)dynamic_bytes));
+}
+
 // Grid size for a streaming kernel: enough workgroups to fill 256 CUs several times over,
 // capped so that the grid-stride loop amortises launch/tail effects.
 static inline int stream_grid(int64_t work_items, int block, int max_blocks) {
@@ -294,9 +303,9 @@ struct Tuning {
   int step_stagger_us; // BM_STEP_STAGGER_US: start every other workgroup of an XCD this many microseconds late in the fused first pass of a Krum / Bulyan step (0 = off)
   int gram_steady;     // BM_GRAM_STEADY: 1 (default) = the condition-free steady-state loop of the Gram kernel, 0 = the generic loop only (A/B)
   int bulyan_short;    // BM_BULYAN_SHORT: 1 (default) = Bulyan pass 2 searches its window among the positions that straddle the median only (same bits), 0 = all positions (A/B)
-  int pair_load_nt;    // BM_PAIR_LOAD_NT: 1 (default) = the Gram kernel's row loads carry the non-temporal hint, 0 = default cache policy (aligned rows; A/B with BM_SECOND_PASS_REVERSE: does the tail of the rows stay in the Infinity Cache for the second pass?)
+  int pair_load_nt;    // BM_PAIR_LOAD_NT: 1 (default) = the Gram kernel's row loads carry the non-temporal hint, 0 = default cache policy (aligned rows; A/B)
   int rank_algo;       // BM_RANK_ALGO: how the rows' distances are put in order for the scores (rank_body.h): 0 (default) = counting up to 32 rows, a bitonic network per row beyond; 1 = bitonic, 2 = counting (A/B; same scores)
-  int second_pass_reverse;  // BM_SECOND_PASS_REVERSE: 1 = the second pass of a two-pass rule (selected mean, Bulyan pass 2) walks the columns from the END (the distance pass before it finished there; same bits); 0 (default) = from the start — measured on one box, alternating: the reversed walk is 0-1 % SLOWER at C3 / C4 / CGE and a wash for Aksel (profiles/r05_a_second_pass_walk_ab.txt)
+  int brute_budget;    // BM_BRUTE_BUDGET: search-tree nodes per wave of the device Brute search before it gives up with status -2 (default 0 = 2^18; tests set a tiny one)
 };
 const Tuning& tuning();
 Tuning& tuning_mutable();  // bm_tuning_set (A/B runs inside one process)

@@ -44,7 +44,7 @@ __device__ __forceinline__ int wave_max_i32(int v) {
   return v;
 }
 
-constexpr int kBruteNodeBudgetPerWave = 1 << 18;  // search-tree nodes per wave and launch (~0.1 us each)
+constexpr int kBruteNodeBudgetPerWave = 1 << 18;  // search-tree nodes per wave and launch (~0.1 us each); BM_BRUTE_BUDGET overrides (tests)
 
 struct BruteWave {
   const double* dist;  // LDS, [n][n], symmetric, non-finite where the reference's distance is
@@ -53,6 +53,7 @@ struct BruteWave {
   uint64_t adj;        // this lane's row of G(t)
   int nodes;           // search-tree nodes visited so far by this wave (all has_clique calls of the launch)
   bool exhausted;      // the budget ran out: the answers of this wave no longer mean anything
+  int budget;          // search-tree nodes this wave may visit
 
   __device__ void build(double t) {
     uint64_t a = 0;
@@ -74,7 +75,7 @@ struct BruteWave {
     int top = 0;
     bool have = true;
     for (;;) {
-      if (++nodes > kBruteNodeBudgetPerWave) {
+      if (++nodes > budget) {
         exhausted = true;
         return false;
       }
@@ -128,8 +129,9 @@ struct BruteWave {
 // n - f copies of the first row ALL of whose distances are non-finite (a gradient with a non-finite coordinate), so
 // that the average that follows is non-finite where that row is instead of looking like a result; -2 when a wave
 // used up its budget of search-tree nodes (kBruteNodeBudgetPerWave: the tree is exponential in f in the worst case and
-// crafted distance matrices are this library's threat model — a stream must not be held for seconds): sel_out is
-// then all zeros and the caller raises (bm_brute_select, the host search, has no such limit).
+// crafted distance matrices are this library's threat model — a stream must not be held for seconds): sel_out then
+// holds n - f times the index -1, which the averaging kernels (reduce.hip) answer with an all-NaN vector — never a
+// usable selection — and the Python host falls back to bm_brute_select, the host search, which has no such limit.
 //
 // ONE workgroup of kBruteWaves waves.  The three phases of the search are the host's (api.cpp), but the questions
 // "does G(t) hold n - f mutually adjacent rows" are asked kBruteWaves at a time:
@@ -148,7 +150,7 @@ constexpr int kBruteWaves = 16;
 
 __global__ __launch_bounds__(64 * kBruteWaves) void brute_select_kernel(const double* __restrict__ sq, int n, int f,
                                                                         int32_t* __restrict__ sel_out,
-                                                                        int32_t* __restrict__ status) {
+                                                                        int32_t* __restrict__ status, int budget) {
   __shared__ double dist[BM_MAX_ROWS * BM_MAX_ROWS];
   __shared__ uint64_t stacks[kBruteWaves][BM_MAX_ROWS + 4];
   __shared__ double piv[kBruteWaves];
@@ -165,7 +167,7 @@ __global__ __launch_bounds__(64 * kBruteWaves) void brute_select_kernel(const do
   }
   if (lane == 0) over[wave] = 0;
   __syncthreads();
-  BruteWave w{dist, stacks[wave], n, lane, 0, 0, false};
+  BruteWave w{dist, stacks[wave], n, lane, 0, 0, false, budget};
   const uint64_t everyone = n == 64 ? ~(uint64_t)0 : (((uint64_t)1 << n) - 1);
   auto in_range = [&](double v, double lo, double hi) { return __builtin_fabs(v) < __builtin_inf() && v > lo && v < hi; };
   // one round of answers: wave w publishes (pivot, answer), everybody reads all of them
@@ -211,7 +213,7 @@ __global__ __launch_bounds__(64 * kBruteWaves) void brute_select_kernel(const do
   const bool feasible = res[0] == 1, at_zero = res[1] == 1;
   const bool over1 = any_over();
   __syncthreads();  // (everybody has read the answers before the next round overwrites them)
-  if (over1) return give_up(-2, 0);
+  if (over1) return give_up(-2, -1);
   if (!feasible) {
     // a row whose distances are ALL non-finite (a gradient with a non-finite coordinate); else one that has any
     int all_bad = 64, any_bad = 64;
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(64 * kBruteWaves) void brute_select_kernel(const do
     }
     const bool over2 = any_over();
     __syncthreads();
-    if (over2) return give_up(-2, 0);
+    if (over2) return give_up(-2, -1);
   }
 
   // ---- 3. the first subset in lexicographic order in G(hi) ----
@@ -297,7 +299,7 @@ __global__ __launch_bounds__(64 * kBruteWaves) void brute_select_kernel(const do
   uint64_t cand = 0;  // rows still in play: in the core, adjacent to every chosen row, above the last chosen one
 #pragma unroll
   for (int v = 0; v < kBruteWaves; ++v) cand |= cores[v];
-  if (any_over()) return give_up(-2, 0);
+  if (any_over()) return give_up(-2, -1);
   // 3b. position by position: a round tries the prefixes c_0, c_0 c_1, ... of the W lowest open rows — wave v takes
   //     c_0 .. c_{v-1} for chosen and asks whether c_v still extends — and the longest prefix of "yes" is taken whole;
   //     the row behind it has then failed exactly the question the sequential search would have asked at that position.
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(64 * kBruteWaves) void brute_select_kernel(const do
     for (int v = 0; v < kBruteWaves; ++v) accepted += (accepted == v && res[v] == 1) ? 1 : 0;
     const bool over3 = any_over();
     __syncthreads();
-    if (over3) return give_up(-2, 0);
+    if (over3) return give_up(-2, -1);
     // every wave replays the accepted prefix on its own copy of the state
     uint64_t walk = open;
     for (int v = 0; v < accepted; ++v) {
@@ -369,8 +371,9 @@ extern "C" int bm_brute_select_device(const double* sq_nxn, int n, int f, int32_
   using namespace bm;
   if (sq_nxn == nullptr || sel_out == nullptr || status == nullptr || n < 1 || n > BM_MAX_ROWS || f < 0 || n - f < 1)
     return BM_EINVAL;
+  const int budget = tuning().brute_budget > 0 ? tuning().brute_budget : kBruteNodeBudgetPerWave;
   hipLaunchKernelGGL(brute_select_kernel, dim3(1), dim3(64 * kBruteWaves), 0, static_cast<hipStream_t>(stream), sq_nxn, n, f, sel_out,
-                     status);
+                     status, budget);
   BM_LAUNCH_CHECK();
   return 0;
 }

@@ -27,7 +27,7 @@ constexpr int kBulBlock = 256;
 template <int N, int F, int VEC>
 __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(
     RowTable rows, const int32_t* __restrict__ order, int64_t nvec, int nt_result, float* __restrict__ out,
-    int short_window, int reverse, int tail) {
+    int short_window, int tail) {
   constexpr int MMAX = N - F - 2;
   constexpr int THETA = N - 2 * F - 2;
   constexpr int BETA = THETA - 2 * F;
@@ -141,15 +141,9 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(
     out[j] = r[0];
   }
   {
-    // Blocks of kBulBlock column groups, walked from the last one when `reverse` is set (BM_SECOND_PASS_REVERSE=1 or
-    // bm_bulyan_pass2_walk): the distance pass that ranked the rows read them from the first coordinate to the last, so
-    // what the 256 MB Infinity Cache could still hold when this kernel starts is the TAIL of every row.  Measured
-    // (same box, alternating, profiles/r05_a_second_pass_walk_ab.txt): it does not — the reversed walk is 0-1 % slower
-    // at C3 / C4 / CGE — so the default is the forward walk.  The arithmetic of a column does not depend on where the
-    // walk starts: same bits.
     const uint32_t nblk = (nv + kBulBlock - 1) / kBulBlock;
     for (uint32_t b = blockIdx.x; b < nblk; b += gridDim.x) {
-      const uint32_t v = (reverse != 0 ? nblk - 1 - b : b) * kBulBlock + threadIdx.x;
+      const uint32_t v = b * kBulBlock + threadIdx.x;
       if (v < nv) {
         const uint32_t off = v * (uint32_t)(VEC * sizeof(float));
         float x[VEC][MMAX], r[VEC];
@@ -213,7 +207,7 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_generic_kernel(
 
 template <int N, int F>
 static int launch_bulyan_fast(const float* const* rows_host, const int32_t* order, int64_t d_all,
-                              float* out_all, int reverse, hipStream_t s) {
+                              float* out_all, hipStream_t s) {
   constexpr int MMAX = N - F - 2;
   constexpr int kMaxVec = (MMAX <= 20) ? 4 : (MMAX <= 44 ? 2 : 1);
   int vec = common_vec_width(reinterpret_cast<const void* const*>(rows_host), N, out_all);
@@ -228,19 +222,16 @@ static int launch_bulyan_fast(const float* const* rows_host, const int32_t* orde
       const int64_t nvec = d / 4;
       hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 4 ? 4 : 1)>),
                          dim3(stream_grid(nvec, kBulBlock, kColMaxBlocks)), dim3(kBulBlock), 0,
-                         s, tab, order, nvec, 1, out, tuning().bulyan_short,
-                         reverse, (int)(d - nvec * 4));
+                         s, tab, order, nvec, 1, out, tuning().bulyan_short, (int)(d - nvec * 4));
     } else if (vec >= 2 && kMaxVec >= 2 && d / 2 > 0) {
       const int64_t nvec = d / 2;
       hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, (kMaxVec >= 2 ? 2 : 1)>),
                          dim3(stream_grid(nvec, kBulBlock, kColMaxBlocks)), dim3(kBulBlock), 0,
-                         s, tab, order, nvec, 1, out, tuning().bulyan_short,
-                         reverse, (int)(d - nvec * 2));
+                         s, tab, order, nvec, 1, out, tuning().bulyan_short, (int)(d - nvec * 2));
     } else {
       hipLaunchKernelGGL((bulyan_pass2_kernel<N, F, 1>),
                          dim3(stream_grid(d, kBulBlock, kColMaxBlocks)), dim3(kBulBlock), 0,
-                         s, tab, order, d, 1, out, tuning().bulyan_short,
-                         reverse, 0);
+                         s, tab, order, d, 1, out, tuning().bulyan_short, 0);
     }
     BM_LAUNCH_CHECK();
   }
@@ -363,12 +354,9 @@ int64_t pairwise_workspace_bytes(int n, int64_t d);  // pairwise.hip
 
 }  // namespace bm
 
-// walk: 0 = from the first column, 1 = from the last one, < 0 = the library's default (BM_SECOND_PASS_REVERSE).  The
-// register-resident instances honour it; the generic kernel walks forward.  The output does not depend on it.
-extern "C" int bm_bulyan_pass2_walk(const float* const* rows, int n, const int32_t* order, int f, int m,
-                                    int64_t d, float* out, int walk, void* stream) {
+extern "C" int bm_bulyan_pass2(const float* const* rows, int n, const int32_t* order, int f, int m,
+                               int64_t d, float* out, void* stream) {
   using namespace bm;
-  const int reverse = walk < 0 ? tuning().second_pass_reverse : (walk != 0 ? 1 : 0);
   if (rows == nullptr || order == nullptr || (out == nullptr && d > 0) || n < 1 || n > BM_MAX_ROWS || f < 1 ||
       n < 4 * f + 3 || m < 1 || m > n - f - 2 || d < 0)
     return BM_EINVAL;
@@ -379,7 +367,7 @@ extern "C" int bm_bulyan_pass2_walk(const float* const* rows, int n, const int32
     // register-resident instances for the (n, f) grid the reference exercises
     // (reproduce.py:139,182; reproduce-appendix.py:121-158) and their neighbours
 #define BM_BULYAN_CASE(NN, FF) \
-  if (n == NN && f == FF) return launch_bulyan_fast<NN, FF>(rows, order, d, out, reverse, s);
+  if (n == NN && f == FF) return launch_bulyan_fast<NN, FF>(rows, order, d, out, s);
     BM_BULYAN_CASE(11, 2)
     BM_BULYAN_CASE(15, 3)
     BM_BULYAN_CASE(19, 4)
@@ -401,20 +389,12 @@ extern "C" int bm_bulyan_pass2_walk(const float* const* rows, int n, const int32
   const int theta = n - 2 * f - 2;
   const size_t lds = (size_t)(m_max + theta) * kBulBlock * sizeof(float);
   const int grid = stream_grid(d, kBulBlock, kColMaxBlocks);
-  if (lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(bulyan_pass2_generic_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return hip_code(e);
-  }
+  if (const int rc = lds_opt_in(reinterpret_cast<const void*>(bulyan_pass2_generic_kernel), lds, BM_MAX_ROWS * sizeof(float*)))
+    return rc;
   hipLaunchKernelGGL(bulyan_pass2_generic_kernel, dim3(grid), dim3(kBulBlock), lds, s, tab, order, n,
                      f, m, d, out);
   BM_LAUNCH_CHECK();
   return 0;
-}
-
-extern "C" int bm_bulyan_pass2(const float* const* rows, int n, const int32_t* order, int f, int m,
-                               int64_t d, float* out, void* stream) {
-  return bm_bulyan_pass2_walk(rows, n, order, f, m, d, out, -1, stream);
 }
 
 extern "C" int bm_aksel_pass1(const float* const* rows, int n, int64_t d, float* median_out,

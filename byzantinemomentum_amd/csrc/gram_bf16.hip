@@ -430,7 +430,9 @@ __device__ __forceinline__ void gram_to_sqdist(const double* __restrict__ gram, 
     const double gij = gram[b3_tri_index(lo, hi, n)];
     double v = (gii + gjj) - 2.0 * gij;
     const bool same = (gii == gjj) && (gij == gii);
-    if (!same && v < tau * (gii + gjj)) {  // NaN compares false: non-finite rows are never listed
+    // (tau <= 0 disables the gate: nothing may be listed then — rounding can leave v slightly negative — because the
+    //  caller launches no exact pass and this launch must rank, pairwise.hip)
+    if (tau > 0.0 && !same && v < tau * (gii + gjj)) {  // NaN compares false: non-finite rows are never listed
       listed[i] = 1;                       // benign race: every writer stores 1
       listed[j] = 1;
     }
@@ -509,11 +511,10 @@ int gram_finish(const double* partial, int blocks, int n, int n_full, double* gr
   }
   int lds_bytes = kGramRedWaves * 64 * (int)sizeof(double);
   if (rk.on && rank_lds_bytes(n_full) > lds_bytes) lds_bytes = rank_lds_bytes(n_full);
-  if (lds_bytes > 48 * 1024) {  // (n >= 56 with a ranking)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gram_reduce_sqdist_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kRankLdsBytes);
-    if (e != hipSuccess) return hip_code(e);
-  }
+  // (static: listed[] + last; beyond 48 KB from n = 55 with a ranking)
+  if (const int rc = lds_opt_in(reinterpret_cast<const void*>(gram_reduce_sqdist_kernel), (size_t)lds_bytes,
+                                (BM_MAX_ROWS + 1) * sizeof(int)))
+    return rc;
   hipLaunchKernelGGL(gram_reduce_sqdist_kernel, dim3((int)((per_block + 63) / 64)), dim3(64 * kGramRedWaves), lds_bytes, s,
                      partial, blocks, n, gram, tau, sq_nxn, sub, n_full, rk);
   BM_LAUNCH_CHECK();
@@ -529,11 +530,7 @@ static int launch_gram3_planes(const RowTable& tab, int n, int64_t d, bool align
   auto kern = aligned ? (tuning().pair_load_nt != 0 ? gram3_partial_kernel<K, NPL, true, true>
                                                     : gram3_partial_kernel<K, NPL, true, false>)
                       : gram3_partial_kernel<K, NPL, false, true>;
-  if (S::kLds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, S::kLds);
-    if (e != hipSuccess) return hip_code(e);
-  }
+  if (const int rc = lds_opt_in(reinterpret_cast<const void*>(kern), (size_t)S::kLds, 0)) return rc;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * kB3Waves), S::kLds, s, tab, n, d, 1.0f / (float)n, centre,
                      (unsigned)tuning().pair_dither, partial, arrival, tuning().gram_steady);
   BM_LAUNCH_CHECK();

@@ -490,11 +490,8 @@ static int pairwise_direct(const float* const* rows, int n, int64_t d, double* s
   const bool aligned =
       common_vec_width(reinterpret_cast<const void* const*>(rows), n, nullptr) == 4;
   auto kern = aligned ? pairwise_partial_kernel<true> : pairwise_partial_kernel<false>;
-  if (lds_bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-    if (e != hipSuccess) return hip_code(e);
-  }
+  // (static: the wave sums of the in-kernel reduction, 4 KB)
+  if (const int rc = lds_opt_in(reinterpret_cast<const void*>(kern), lds_bytes, kRedWaves * 64 * sizeof(double))) return rc;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(threads), lds_bytes, s, tab, g, d, partial, sub, n, sq_nxn, rk);
   BM_LAUNCH_CHECK();
   if (sub == nullptr) {
@@ -574,11 +571,7 @@ extern "C" int bm_krum_rank(const double* sq_nxn, int n, int f, int m, int mode,
   if (sq_nxn == nullptr || order_out == nullptr || n < 1 || n > BM_MAX_ROWS || f < 0 ||
       (mode != BM_RANK_KRUM && mode != BM_RANK_BULYAN))
     return BM_EINVAL;
-  if (rank_lds_bytes(n) > 48 * 1024) {  // (n >= 56; the call is a table look-up after the first time)
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(krum_rank_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, kRankLdsBytes);
-    if (e != hipSuccess) return hip_code(e);
-  }
+  if (const int rc = lds_opt_in(reinterpret_cast<const void*>(krum_rank_kernel), (size_t)rank_lds_bytes(n), 0)) return rc;
   hipLaunchKernelGGL(krum_rank_kernel, dim3(1), dim3(kRankThreads), rank_lds_bytes(n), static_cast<hipStream_t>(stream),
                      sq_nxn, n, f, m, mode, order_out, scores_out, rank_bitonic(n) ? 1 : 0);
   BM_LAUNCH_CHECK();

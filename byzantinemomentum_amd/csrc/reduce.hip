@@ -22,15 +22,23 @@ template <int VEC>
 __global__ __launch_bounds__(kRedBlock) void selected_mean_kernel(RowTable rows,
                                                                   const int32_t* __restrict__ idx,
                                                                   int m, int64_t nvec, float fm, int nt_result,
-                                                                  float* __restrict__ out, int reverse, int tail) {
+                                                                  float* __restrict__ out, int tail) {
   __shared__ const float* sel[BM_MAX_ROWS];
-  if (threadIdx.x < m) sel[threadIdx.x] = rows.p[load_index_coherent(idx + threadIdx.x)];
+  __shared__ int poisoned;
+  if (threadIdx.x == 0) poisoned = 0;
   __syncthreads();
-  // (`reverse`: blocks of kRedBlock column groups walked from the last one — the pass that selected the rows read them
-  //  from the first coordinate to the last, the Infinity Cache holds their tail; see bulyan_pass2_kernel.  Same bits.)
+  if (threadIdx.x < m) {
+    // (a NEGATIVE index is the Brute search saying "no selection, do not use this", brute.hip: the mean is then NaN
+    //  everywhere instead of the average of some rows)
+    const int i = load_index_coherent(idx + threadIdx.x);
+    if (i < 0) poisoned = 1;
+    sel[threadIdx.x] = rows.p[i < 0 ? 0 : i];
+  }
+  __syncthreads();
+  if (poisoned) fm = __builtin_nanf("");
   const int64_t nblk = (nvec + kRedBlock - 1) / kRedBlock;
   for (int64_t b = blockIdx.x; b < nblk; b += gridDim.x) {
-    const int64_t v = (reverse != 0 ? nblk - 1 - b : b) * kRedBlock + threadIdx.x;
+    const int64_t v = b * kRedBlock + threadIdx.x;
     if (v >= nvec) continue;
     float acc[VEC];
 #pragma unroll
@@ -64,14 +72,21 @@ constexpr int kMeanBurstSlots = 9;  // 9 x 1024 x 16 B = 144 KB of results next 
 __global__ __launch_bounds__(kMeanBurstThreads) void selected_mean_burst_kernel(RowTable rows,
                                                                                 const int32_t* __restrict__ idx, int m,
                                                                                 int64_t nvec, float fm,
-                                                                                float* __restrict__ out, int reverse,
-                                                                                int tail) {
+                                                                                float* __restrict__ out, int tail) {
   using V = typename VecLoad<4>::T;
   __shared__ V stage[kMeanBurstSlots * kMeanBurstThreads];
   __shared__ const float* sel[BM_MAX_ROWS];
+  __shared__ int poisoned;
   const uint32_t tid = threadIdx.x;
-  if ((int)tid < m) sel[tid] = rows.p[load_index_coherent(idx + tid)];
+  if (tid == 0) poisoned = 0;
   __syncthreads();
+  if ((int)tid < m) {
+    const int i = load_index_coherent(idx + tid);  // (negative: no selection — the mean is NaN, see selected_mean_kernel)
+    if (i < 0) poisoned = 1;
+    sel[tid] = rows.p[i < 0 ? 0 : i];
+  }
+  __syncthreads();
+  if (poisoned) fm = __builtin_nanf("");
   const uint32_t nv = (uint32_t)nvec;
   const uint32_t span = gridDim.x * kMeanBurstThreads;
   const uint32_t iters = (nv + span - 1) / span;
@@ -79,8 +94,7 @@ __global__ __launch_bounds__(kMeanBurstThreads) void selected_mean_burst_kernel(
   for (uint32_t p0 = 0; p0 < iters; p0 += kMeanBurstSlots) {
     const uint32_t p1 = (p0 + kMeanBurstSlots < iters) ? p0 + kMeanBurstSlots : iters;
     for (uint32_t it = p0; it < p1; ++it) {
-      // (`reverse`: the iterations walk the columns from the end, see selected_mean_kernel; the staging slot keeps `it`)
-      const uint32_t v = (reverse != 0 ? iters - 1 - it : it) * span + first;
+      const uint32_t v = it * span + first;
       if (v < nv) {
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll 8
@@ -98,7 +112,7 @@ __global__ __launch_bounds__(kMeanBurstThreads) void selected_mean_burst_kernel(
     }
     __syncthreads();  // what makes the stores below a burst
     for (uint32_t it = p0; it < p1; ++it) {
-      const uint32_t v = (reverse != 0 ? iters - 1 - it : it) * span + first;
+      const uint32_t v = it * span + first;
       if (v < nv) __builtin_nontemporal_store(stage[(it - p0) * kMeanBurstThreads + tid], reinterpret_cast<V*>(out) + v);
     }
   }
@@ -122,14 +136,14 @@ static int launch_selected_mean(const RowTable& tab, const int32_t* idx, int m, 
     if (tuning().mean_burst > 0 && m >= 12 && nvec < ((int64_t)1 << 30) &&
         nvec / ((int64_t)cus * kMeanBurstThreads) >= tuning().mean_burst) {
       hipLaunchKernelGGL(selected_mean_burst_kernel, dim3(cus), dim3(kMeanBurstThreads), 0, s, tab, idx, m, nvec,
-                         (float)m, out, tuning().second_pass_reverse, tail);
+                         (float)m, out, tail);
       BM_LAUNCH_CHECK();
       return 0;
     }
   }
   const int grid = stream_grid(nvec, kRedBlock, 256 * 32);
   hipLaunchKernelGGL(selected_mean_kernel<VEC>, dim3(grid), dim3(kRedBlock), 0, s, tab, idx, m, nvec,
-                     (float)m, 1, out, tuning().second_pass_reverse, tail);
+                     (float)m, 1, out, tail);
   BM_LAUNCH_CHECK();
   return 0;
 }

@@ -23,7 +23,7 @@ namespace bm {
 
 constexpr int kEvalMaxBlocks = 2048;
 
-template <int N, int OP, int VEC, bool REV = false>
+template <int N, int OP, int VEC>
 __global__ __launch_bounds__(kColBlock) void colwise_eval_kernel(RowTable rows, int h, const float* __restrict__ avg,
                                                                  const float* __restrict__ dir, float t, int64_t nvec,
                                                                  int f, float inv_keep, double* __restrict__ partial) {
@@ -34,19 +34,8 @@ __global__ __launch_bounds__(kColBlock) void colwise_eval_kernel(RowTable rows, 
   float acc = 0.0f;
   double wide = 0.0;
   int since = 0;
-  // REV (bm_colwise_eval_walk with walk = 1, its own instances: the forward kernel is the code it always was): the
-  // blocks of kColBlock column groups are walked from the last one.  The evaluations of a search read the same rows
-  // again and again, and a pass that starts where the previous one ended finds its first 256 MB in the Infinity
-  // Cache.  A lane then adds its columns in the opposite order: the objective agrees with the forward walk to the
-  // rounding of that sum (fp32 over <= 64 elements, fp64 beyond), not bit for bit.
   const int64_t stride = (int64_t)gridDim.x * kColBlock;
-  const int64_t top = ((nvec + kColBlock - 1) / kColBlock) * kColBlock;
-  for (int64_t v0 = (int64_t)blockIdx.x * kColBlock + threadIdx.x; v0 < (REV ? top : nvec); v0 += stride) {
-    int64_t v = v0;
-    if constexpr (REV) {
-      v = top - kColBlock - v0 + 2 * (int64_t)threadIdx.x;  // block nblk - 1 - b, same lane
-      if (v >= nvec) continue;
-    }
+  for (int64_t v = (int64_t)blockIdx.x * kColBlock + threadIdx.x; v < nvec; v += stride) {
     const int64_t j = v * VEC;
     float x[VEC][N];
     float a[VEC], dr[VEC];
@@ -96,7 +85,7 @@ __global__ __launch_bounds__(kEvalFinishThreads) void eval_finish_kernel(const d
 
 template <int N, int OP>
 static int launch_eval(const float* const* rows, int h, int64_t d, int f, const float* avg, const float* dir, float t,
-                       double* out, double* partial, int reverse, hipStream_t s) {
+                       double* out, double* partial, hipStream_t s) {
   constexpr int kMaxVec = (N <= 28) ? 4 : 2;
   const int keep = (OP == BM_OP_TRMEAN) ? (N - 2 * f) : (N - f);
   const float inv_keep = 1.0f / (float)(keep > 0 ? keep : 1);
@@ -112,9 +101,7 @@ static int launch_eval(const float* const* rows, int h, int64_t d, int f, const 
   if (vec >= 2 && d / vec > 0) {
     const int64_t nvec = d / vec;
     const int grid = stream_grid(nvec, kColBlock, kEvalMaxBlocks);
-    auto kern = vec == 4 ? (reverse ? colwise_eval_kernel<N, OP, (kMaxVec >= 4 ? 4 : 2), true>
-                                    : colwise_eval_kernel<N, OP, (kMaxVec >= 4 ? 4 : 2), false>)
-                         : (reverse ? colwise_eval_kernel<N, OP, 2, true> : colwise_eval_kernel<N, OP, 2, false>);
+    auto kern = vec == 4 ? colwise_eval_kernel<N, OP, (kMaxVec >= 4 ? 4 : 2)> : colwise_eval_kernel<N, OP, 2>;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kColBlock), 0, s, tab, h, avg, dir, t, nvec, f, inv_keep, partial);
     BM_LAUNCH_CHECK();
     nparts = grid;
@@ -125,7 +112,6 @@ static int launch_eval(const float* const* rows, int h, int64_t d, int f, const 
     for (int i = 0; i < h; ++i) tail.p[i] = rows[i] + body;
     const int64_t rest = d - body;
     const int grid = (body == 0) ? stream_grid(rest, kColBlock, kEvalMaxBlocks) : 1;
-    // (the ragged tail — at most three columns behind a vector body — walks forward whatever the walk)
     hipLaunchKernelGGL((colwise_eval_kernel<N, OP, 1>), dim3(grid), dim3(kColBlock), 0, s, tail, h, avg + body, dir + body,
                        t, rest, f, inv_keep, partial + nparts);
     BM_LAUNCH_CHECK();
@@ -139,11 +125,11 @@ static int launch_eval(const float* const* rows, int h, int64_t d, int f, const 
 
 template <int N>
 static int launch_eval_op(int op, const float* const* rows, int h, int64_t d, int f, const float* avg, const float* dir,
-                          float t, double* out, double* partial, int reverse, hipStream_t s) {
+                          float t, double* out, double* partial, hipStream_t s) {
   switch (op) {
-    case BM_OP_TRMEAN: return launch_eval<N, BM_OP_TRMEAN>(rows, h, d, f, avg, dir, t, out, partial, reverse, s);
-    case BM_OP_PHOCAS: return launch_eval<N, BM_OP_PHOCAS>(rows, h, d, f, avg, dir, t, out, partial, reverse, s);
-    case BM_OP_MEAMED: return launch_eval<N, BM_OP_MEAMED>(rows, h, d, f, avg, dir, t, out, partial, reverse, s);
+    case BM_OP_TRMEAN: return launch_eval<N, BM_OP_TRMEAN>(rows, h, d, f, avg, dir, t, out, partial, s);
+    case BM_OP_PHOCAS: return launch_eval<N, BM_OP_PHOCAS>(rows, h, d, f, avg, dir, t, out, partial, s);
+    case BM_OP_MEAMED: return launch_eval<N, BM_OP_MEAMED>(rows, h, d, f, avg, dir, t, out, partial, s);
     default: return BM_EINVAL;
   }
 }
@@ -156,11 +142,9 @@ extern "C" int bm_colwise_eval_supported(int op, int n) {
 
 extern "C" int64_t bm_colwise_eval_workspace_bytes(void) { return (int64_t)(2 * bm::kEvalMaxBlocks) * (int64_t)sizeof(double); }
 
-extern "C" int bm_colwise_eval_walk(int op, const float* const* honests, int h, int copies, int64_t d, int f,
-                                    const float* avg, const float* dir, float t, int walk, double* out, void* ws,
-                                    void* stream) {
+extern "C" int bm_colwise_eval(int op, const float* const* honests, int h, int copies, int64_t d, int f,
+                               const float* avg, const float* dir, float t, double* out, void* ws, void* stream) {
   using namespace bm;
-  const int reverse = walk != 0 ? 1 : 0;
   const int n = h + copies;
   if (honests == nullptr || out == nullptr || ws == nullptr || h < 1 || copies < 1 || n > BM_MAX_ROWS || d < 0 || f < 0 ||
       n < 2 * f + 1 || (d > 0 && (avg == nullptr || dir == nullptr)) || !bm_colwise_eval_supported(op, n))
@@ -168,13 +152,8 @@ extern "C" int bm_colwise_eval_walk(int op, const float* const* honests, int h, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   double* partial = static_cast<double*>(ws);
   switch (n) {
-    case 11: return launch_eval_op<11>(op, honests, h, d, f, avg, dir, t, out, partial, reverse, s);
-    case 25: return launch_eval_op<25>(op, honests, h, d, f, avg, dir, t, out, partial, reverse, s);
-    default: return launch_eval_op<51>(op, honests, h, d, f, avg, dir, t, out, partial, reverse, s);
+    case 11: return launch_eval_op<11>(op, honests, h, d, f, avg, dir, t, out, partial, s);
+    case 25: return launch_eval_op<25>(op, honests, h, d, f, avg, dir, t, out, partial, s);
+    default: return launch_eval_op<51>(op, honests, h, d, f, avg, dir, t, out, partial, s);
   }
-}
-
-extern "C" int bm_colwise_eval(int op, const float* const* honests, int h, int copies, int64_t d, int f,
-                               const float* avg, const float* dir, float t, double* out, void* ws, void* stream) {
-  return bm_colwise_eval_walk(op, honests, h, copies, d, f, avg, dir, t, 0, out, ws, stream);
 }

@@ -234,22 +234,16 @@ def bulyan_ranking(gradients, f, m=None, **kwargs):
   return order[:n].tolist()
 
 
-def bulyan_pass2(gradients, order, f, m, walk=None):
-  """Second pass of Bulyan given the device-resident ranking (aggregators/bulyan.py:64-84).
-  walk: None = the library's default (from the last column: where the distance pass finished), 0 / 1 = from the first /
-  last column (bm_bulyan_pass2_walk; same output — a caller that repeats the pass over the same rows alternates it)."""
+def bulyan_pass2(gradients, order, f, m):
+  """Second pass of Bulyan given the device-resident ranking (aggregators/bulyan.py:64-84)."""
   n, d, device = _validate(gradients)
   lib = _lib.load()
   out = torch.empty(d, dtype=torch.float32, device=device)
   if d == 0:
     return out
   with torch.cuda.device(device):
-    if walk is None:
-      _lib.check(lib.bm_bulyan_pass2(_lib.pointer_table(gradients), n, _ptr(order), f, m, d, _ptr(out),
-                                     _stream(device)), "bm_bulyan_pass2")
-    else:
-      _lib.check(lib.bm_bulyan_pass2_walk(_lib.pointer_table(gradients), n, _ptr(order), f, m, d, _ptr(out),
-                                          1 if walk else 0, _stream(device)), "bm_bulyan_pass2_walk")
+    _lib.check(lib.bm_bulyan_pass2(_lib.pointer_table(gradients), n, _ptr(order), f, m, d, _ptr(out), _stream(device)),
+               "bm_bulyan_pass2")
   return out
 
 
@@ -303,19 +297,27 @@ def brute_selection(gradients, f, **kwargs):
   synchronises; raises when no subset of n-f rows has a finite diameter (the reference then has no selection)."""
   n = len(gradients)
   sel, status = _brute_sel(gradients, f)
-  brute_check(status)
+  if int(status.item()) == -2:  # the device search gave up: the host search has no budget
+    sel = brute_host_selection(gradients, f)
+    _rank_cache_put("brute", gradients, (f,), (sel, torch.zeros(1, dtype=torch.int32, device=sel.device)))
+  else:
+    brute_check(status)
   return sel[:n - f].tolist()
 
 
 BRUTE_NO_SUBSET = "brute: too many non-finite gradients, no subset of n-f rows has a finite diameter"
 BRUTE_BUDGET = ("brute: the device search gave up after its budget of search-tree nodes (csrc/brute.hip; a distance matrix "
                 "built against the search?) — gars.brute_select_host on the host has no such limit")
-last_brute_status = None   # int32[1] device tensor of the latest brute(): 0, or -1 when no subset was admissible
+# (convenience only: the status of the latest brute() of this PROCESS, whatever its device or stream; the status of a
+#  given call travels with its result, `result.brute_status`, and that is what callers with several devices, streams
+#  or aggregators must read — ShardedAggregator keeps its own)
+last_brute_status = None
 
 
 def brute_check(status=None):
-  """Raise when the latest (or the given) Brute search found no admissible subset — the reference's assertion
-  (brute.py:68).  Synchronises (one 4-byte read); not to be called while a stream is being captured."""
+  """Raise when the given Brute search (default: the latest one of this process) found no admissible subset — the
+  reference's assertion (brute.py:68) — or gave up on its node budget.  Synchronises (one 4-byte read); not to be
+  called while a stream is being captured."""
   status = last_brute_status if status is None else status
   code = 0 if status is None else int(status.item())
   if code == -2:
@@ -324,21 +326,47 @@ def brute_check(status=None):
     raise RuntimeError(BRUTE_NO_SUBSET)
 
 
+def brute_host_selection(gradients, f, sq=None):
+  """The selection of the Brute rule by the HOST search (bm_brute_select: no node budget), as a device index tensor;
+  one synchronisation.  What the checked paths fall back to when the device search reports status -2 — the reference
+  would keep computing (brute.py:47-68), so does this."""
+  n, d, device = _validate(gradients)
+  if sq is None:
+    sq = pairwise_sqdist(gradients)
+  sel = brute_select_host(sq.sqrt().cpu().contiguous(), n, f)
+  table = torch.zeros(_lib.MAX_ROWS, dtype=torch.int32)
+  table[:n - f] = torch.tensor(sel, dtype=torch.int32)
+  return table.to(device)
+
+
 def brute(gradients, f, check=False, **kwargs):
   """Brute rule (aggregators/brute.py:70-80): mean of the minimum-diameter subset, index order.  Distances, subset
-  search and average all run on the device, on the caller's stream: no host synchronisation (graph-capturable).  When
-  no subset of n-f rows has a finite diameter — more than f gradients with non-finite coordinates, where the reference
-  fails its assertion (brute.py:56-57,68) — the search reports status -1: it is kept in `last_brute_status`
-  (device), `brute_check()` / `brute_selection` raise on it, and `check=True` (what the `native-brute` plugin passes)
-  raises here, at the price of one host synchronisation, unless the stream is being captured into a graph.  Unchecked,
-  the result is then the average of n-f copies of one bad gradient, i.e. non-finite where that gradient is."""
+  search and average all run on the device, on the caller's stream: no host synchronisation (graph-capturable).
+  The search's status (device int32[1]) travels with the result as `result.brute_status`:
+    -1  no subset of n-f rows has a finite diameter — more than f gradients with non-finite coordinates, where the
+        reference fails its assertion (brute.py:56-57,68): the result is the average of n-f copies of one bad
+        gradient, i.e. non-finite where that gradient is;
+    -2  the device search gave up on its budget of search-tree nodes: the result is NaN EVERYWHERE (the index table
+        then holds -1, which the averaging kernel answers with NaN) — never an average of some rows.
+  check=True (what the `native-brute` plugin passes) reads the status, at the price of one host synchronisation,
+  unless the stream is being captured into a graph: -1 raises like the reference, -2 falls back to the host search,
+  which has no budget, and returns ITS average — the reference would have kept computing."""
   global last_brute_status
   n, d, device = _validate(gradients)
   sel, status = _brute_sel(gradients, f)
   last_brute_status = status
   if check and not torch.cuda.is_current_stream_capturing():
-    brute_check(status)
-  return selected_mean(gradients, sel, n - f)
+    code = int(status.item())
+    if code == -2:
+      sel = brute_host_selection(gradients, f)
+      status = torch.zeros(1, dtype=torch.int32, device=device)
+      _rank_cache_put("brute", gradients, (f,), (sel, status))
+      last_brute_status = status
+    elif code != 0:
+      raise RuntimeError(BRUTE_NO_SUBSET)
+  out = selected_mean(gradients, sel, n - f)
+  out.brute_status = status
+  return out
 
 
 def aksel_sqdist(gradients):

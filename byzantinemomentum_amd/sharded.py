@@ -126,8 +126,8 @@ class HipBackend:
   def selected_mean(self, gradients, order, m):
     return self.gars.selected_mean(gradients, order, m)
 
-  def bulyan_pass2(self, gradients, order, f, m, walk=None):
-    return self.gars.bulyan_pass2(gradients, order, f, m, walk)
+  def bulyan_pass2(self, gradients, order, f, m):
+    return self.gars.bulyan_pass2(gradients, order, f, m)
 
   def colwise(self, rule, gradients, f):
     return getattr(self.gars, rule)(gradients, f=f) if rule != "median" else self.gars.median(gradients)
@@ -451,21 +451,35 @@ class ShardedAggregator:
     self._all_reduce(sq)
     return self.backend.selected_mean(local, self.backend.argsort(sq, n), count)
 
-  def brute(self, local, f, d_total=None):
+  def brute(self, local, f, d_total=None, check=False):
     """Brute rule: all-reduced distances, then the (deterministic) subset search on every rank — on the device with
     the HIP backend (same bits in, same selection out on every rank, no host round trip).  The search's status is
-    kept in `self.brute_status` (device int32[1]); `check_brute()` raises when no subset was admissible, which
-    AggregationStep.floats() does at the step's one synchronisation."""
+    kept in `self.brute_status` (device int32[1]) — per aggregator, not per process.  Unchecked, a search without a
+    usable answer shows in the result (status -1: non-finite where a bad gradient is; -2, the node budget: NaN
+    everywhere).  check=True reads the status here (one 4-byte synchronisation; every rank holds the same status, the
+    search being a function of the all-reduced matrix): -1 raises like the reference (brute.py:68), -2 repeats the
+    search on the host, which has no budget — AggregationStep does this before it hands out the defense vector."""
     n = len(local)
     sq = self.global_sqdist(local, d_total)
     if hasattr(self.backend, "brute_select_device"):
       sel, self.brute_status = self.backend.brute_select_device(sq, n, f)
+      if check and not (sq.is_cuda and torch.cuda.is_current_stream_capturing()):
+        code = int(self.brute_status.item())
+        if code == -2:
+          host = self.backend.brute_select(sq.sqrt().cpu().contiguous(), n, f)
+          sel = self.backend.index_tensor(host, local[0])
+          self.brute_status = None
+        elif code != 0:
+          from . import gars
+          raise RuntimeError(gars.BRUTE_NO_SUBSET)
       return self.backend.selected_mean(local, sel, n - f)
+    self.brute_status = None
     sel = self.backend.brute_select(sq.sqrt().cpu().contiguous(), n, f)
     return self.backend.selected_mean(local, self.backend.index_tensor(sel, local[0]), n - f)
 
   def check_brute(self):
-    """Raise (the reference's assertion, brute.py:68) when the latest brute() found no admissible subset; syncs."""
+    """Raise when the latest unchecked brute() of THIS aggregator had no usable answer (-1: the reference's assertion,
+    brute.py:68; -2: the node budget); syncs."""
     status = getattr(self, "brute_status", None)
     if status is not None:
       from . import gars

@@ -95,10 +95,9 @@ def colwise_eval_supported(rule, n):
   return rule in _EVAL_OPS and bool(_lib.load().bm_colwise_eval_supported(_EVAL_OPS[rule], n))
 
 
-def colwise_eval(rule, honests, copies, f, h_avg, direction, t, reverse=False):
+def colwise_eval(rule, honests, copies, f, h_avg, direction, t):
   """| RULE(honests + [h_avg + t * direction] * copies) - h_avg |^2 as a device fp64[1] tensor, the candidate and the
-  rule's output formed in registers only (bm_colwise_eval): one candidate of attacks/identical.py:67-77. No sync.
-  reverse: walk the columns from the end (bm_colwise_eval_walk; a search alternates it, see AggregationStep)."""
+  rule's output formed in registers only (bm_colwise_eval): one candidate of attacks/identical.py:67-77. No sync."""
   honests = list(honests)
   h, d, device = gars._validate(honests)
   gars._validate([h_avg, direction] + honests[:1])
@@ -106,14 +105,9 @@ def colwise_eval(rule, honests, copies, f, h_avg, direction, t, reverse=False):
   out = torch.empty(1, dtype=torch.float64, device=device)
   ws = gars._Scratch.get(device, "ws_eval", nbytes=int(lib.bm_colwise_eval_workspace_bytes()))
   with torch.cuda.device(device):
-    if reverse:
-      _lib.check(lib.bm_colwise_eval_walk(_EVAL_OPS[rule], _lib.pointer_table(honests), h, copies, d, f, _ptr(h_avg),
-                                          _ptr(direction), float(t), 1, _ptr(out), _ptr(ws), gars._stream(device)),
-                 "bm_colwise_eval_walk")
-    else:
-      _lib.check(lib.bm_colwise_eval(_EVAL_OPS[rule], _lib.pointer_table(honests), h, copies, d, f, _ptr(h_avg),
-                                     _ptr(direction), float(t), _ptr(out), _ptr(ws), gars._stream(device)),
-                 "bm_colwise_eval")
+    _lib.check(lib.bm_colwise_eval(_EVAL_OPS[rule], _lib.pointer_table(honests), h, copies, d, f, _ptr(h_avg),
+                                   _ptr(direction), float(t), _ptr(out), _ptr(ws), gars._stream(device)),
+               "bm_colwise_eval")
   return out
 
 

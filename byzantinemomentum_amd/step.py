@@ -121,6 +121,11 @@ class AggregationStep:
       return agg.median(gradients)
     if self.gar == "average":
       return agg.average(gradients)
+    if self.gar == "brute":
+      # checked HERE, before anybody can apply the defense vector (one 4-byte synchronisation per step for this rule
+      # alone): no admissible subset raises like brute.py:68, a device search that ran out of its node budget is
+      # repeated on the host
+      return agg.brute(gradients, f, check=True, **self.gar_args)
     return getattr(agg, self.gar)(gradients, f, **self.gar_args)
 
   def _search_factor(self, honests, h_avg, direction):
@@ -141,13 +146,6 @@ class AggregationStep:
 
     rule = lambda cand, t: self._aggregate(list(honests) + [cand] * k)  # noqa: E731
     n = h + k
-    # BM_SEARCH_ALTERNATE=1 (experiments; default off until measured): the evaluations of a search read the same honest
-    # rows again and again — alternate the walk of the passes that can state one (bm_colwise_eval_walk,
-    # bm_bulyan_pass2_walk), so that each starts in what the previous one left in the 256 MB Infinity Cache
-    import itertools
-    import os
-    alternate = os.environ.get("BM_SEARCH_ALTERNATE", "0") not in ("", "0")
-    turn = itertools.count()
     if self.line_search == "auto" and self.gar == "bulyan" and k >= 1 and h + 2 <= 64 and hasattr(ops, "bulyan_pass2") \
        and not (set(self.gar_args) - {"m"}):
       # Bulyan's second pass needs the vectors, its ranking does not: the distances among honests + [avg + t*dir] * k
@@ -161,8 +159,6 @@ class AggregationStep:
       def rule(cand, t):  # noqa: F811
         order = linesearch.attack_ranking(ext, h, k, self.f_decl, "bulyan", t, m)
         rows, table = list(honests) + [cand] * k, ops.index_tensor(order + [0] * (64 - n), h_avg)
-        if alternate:  # (every pass 2 of the search starts where the previous one ended: same output)
-          return ops.bulyan_pass2(rows, table, self.f_decl, m, walk=next(turn) & 1)
         return ops.bulyan_pass2(rows, table, self.f_decl, m)
     if self.line_search == "auto" and self.gar == "median" and k >= 1:
       # The lower median of the h honest values and k copies of ONE value b is monotone in b, equals b while b lies
@@ -183,10 +179,7 @@ class AggregationStep:
       if fused_eval:
         # trmean / phocas / meamed: candidate, rule and objective in ONE pass over the honest rows, nothing written
         # (bm_colwise_eval: h + 2 row passes instead of h + 5 read and 2 written); the same value at every column
-        if alternate:
-          sq = ops.colwise_eval(self.gar, honests, k, self.f_decl, h_avg, direction, t, reverse=bool(next(turn) & 1))
-        else:
-          sq = ops.colwise_eval(self.gar, honests, k, self.f_decl, h_avg, direction, t)
+        sq = ops.colwise_eval(self.gar, honests, k, self.f_decl, h_avg, direction, t)
         agg.all_reduce_sum(sq)
         return sq.item()
       cand = torch.empty_like(h_avg)
@@ -426,7 +419,7 @@ class AggregationStep:
     if pend["floats"] is not None:
       return pend["floats"]
     if self.gar == "brute":
-      self.agg.check_brute()  # the reference's assertion (brute.py:68), at the step's synchronisation point
+      self.agg.check_brute()  # (a step replayed from a HIP graph could not check inside run(): here at the latest)
     if "packed" in pend:
       pend["floats"] = self._floats_from_packed(pend)
       return pend["floats"]

@@ -46,9 +46,12 @@ enum bm_colwise_op {
 
 /* ABI version of this header; bumped on any signature change. */
 int bm_abi_version(void);
-/* Sets one launch-shape knob by the name of its environment variable (BM_COL_BURST, BM_SECOND_PASS_REVERSE, ...:
- * csrc/bm_common.h, struct Tuning) for the calls that follow — for A/B measurements inside one process; results never
- * depend on a knob.  BM_EINVAL for an unknown name.  Not thread-safe against running calls. */
+/* TEST / MEASUREMENT ONLY — not part of the drop-in surface.  Sets one launch-shape knob by the name of its environment
+ * variable (BM_COL_BURST, BM_PAIR_MODE, BM_BRUTE_BUDGET, ...: csrc/bm_common.h, struct Tuning) for the calls that
+ * follow, so that an A/B of two settings can alternate inside one process; results never depend on a knob.  The knobs
+ * are the library's only process-global mutable state ("no global mutable state besides a workspace
+ * cache"): they are read from the environment once, and a production process never calls this.  No locking: the
+ * caller must not run it concurrently with any other entry point.  BM_EINVAL for an unknown name. */
 int bm_tuning_set(const char* name, int value);
 
 /* Human-readable text for a code returned by any entry point. */
@@ -105,7 +108,8 @@ int bm_pairwise_rank(const float* const* rows, int n, int64_t d, int64_t d_total
 
 /* out = (((0 + rows[idx[0]]) + rows[idx[1]]) + ...)/m, sequential fp32 like
  * `sum(...).div_(m)` at aggregators/krum.py:80, brute.py:80, aksel.py:64.
- * idx is a DEVICE array of m int32 (so no host sync between rank and mean). */
+ * idx is a DEVICE array of m int32 (so no host sync between rank and mean).  A NEGATIVE entry means "there is no
+ * selection" (bm_brute_select_device, status -2): out is then NaN everywhere. */
 int bm_selected_mean(const float* const* rows, int n, const int32_t* idx, int m,
                      int64_t d, float* out, void* stream);
 
@@ -116,13 +120,6 @@ int bm_selected_mean(const float* const* rows, int n, const int32_t* idx, int m,
  * order is the DEVICE output of bm_krum_rank(mode BULYAN). */
 int bm_bulyan_pass2(const float* const* rows, int n, const int32_t* order, int f, int m,
                     int64_t d, float* out, void* stream);
-/* bm_bulyan_pass2 with the walk over the columns stated: 0 = from the first column, 1 = from the last one, < 0 = the
- * library's default (what bm_bulyan_pass2 does: from the first one — starting at the end, where the distance pass
- * that produced `order` finished, measured 0-1 % SLOWER on the MI355X, profiles/r05_a_second_pass_walk_ab.txt).  The
- * output does not depend on the walk; a caller that runs pass 2 repeatedly over the same rows (the factor search of
- * attacks/identical.py:67-77 against Bulyan) may alternate it. */
-int bm_bulyan_pass2_walk(const float* const* rows, int n, const int32_t* order, int f, int m,
-                         int64_t d, float* out, int walk, void* stream);
 
 /* Aksel pass 1 (aggregators/aksel.py:35-41): coordinate-wise lower median
  * (written to median_out if non-NULL) and sq[i] = sum_j (rows[i][j]-median[j])^2. */
@@ -280,7 +277,9 @@ int bm_brute_select(const double* dist_nxn, int n, int f, int32_t* sel_out);
  * reference then fails its assertion) — sel_out then holds n-f copies of the first row all of whose distances are
  * non-finite, so that the average that follows is non-finite where that row is; -2 when the search gave up on its
  * budget of 2^18 search-tree nodes per wave (the tree is exponential in f in the worst case; a crafted matrix must
- * not hold the stream for seconds) — sel_out is then all zeros, and bm_brute_select on the host has no such limit.
+ * not hold the stream for seconds) — sel_out then holds n-f times the index -1, which bm_selected_mean answers with
+ * NaN in EVERY coordinate (never the average of some rows); bm_brute_select on the host has no such limit and is what
+ * the Python host falls back to.
  * Same selections as bm_brute_select (tests/test_gpu_parity_r4.py). */
 int bm_brute_select_device(const double* sq_nxn, int n, int f, int32_t* sel_out, int32_t* status, void* stream);
 
@@ -376,12 +375,6 @@ int bm_colwise_eval_supported(int op, int n);
 int64_t bm_colwise_eval_workspace_bytes(void);
 int bm_colwise_eval(int op, const float* const* honests, int h, int copies, int64_t d, int f, const float* avg,
                     const float* dir, float t, double* out, void* ws, void* stream);
-/* bm_colwise_eval with the walk over the columns stated (0 = from the first column, as bm_colwise_eval; 1 = from the last one): the
- * evaluations of one search read the same honest rows again and again, alternating the walk lets each start in what
- * the previous one left in the Infinity Cache.  A lane adds its columns in the order of the walk: the two walks agree
- * to the rounding of the objective's sum (fp32 over <= 64 elements per lane, fp64 beyond), not bit for bit. */
-int bm_colwise_eval_walk(int op, const float* const* honests, int h, int copies, int64_t d, int f, const float* avg,
-                         const float* dir, float t, int walk, double* out, void* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The factor search of the "identical" attacks (attacks/identical.py:67-77, the reference's default

@@ -1,0 +1,66 @@
+#!/bin/bash
+# One gpurun call = one named recipe (replaces the per-call wrappers of earlier rounds).  Everything a recipe writes goes
+# to gpurun_out/<round>_<name>/ on the GPU box and comes back merged into gpurun_out/ here.
+#   gpurun --timeout 1500 -- 'scripts/gpu_call.sh r06 hunt'
+set -u
+round=$1; name=$2; shift 2
+out=gpurun_out/${round}_${name}; mkdir -p $out
+cd /tmp && export TMPDIR=/tmp; cd /root/repo
+run() { echo "== $*" >> $out/commands.log; ( time "$@" ) ; }
+case $name in
+  hunt)   # the library-free probe under sharing, then the library-level hunt with the culprit report
+    P=scripts/probes/stale_line_probe
+    [ -x $P ] || hipcc --offload-arch=gfx950 -O2 -o $P $P.hip
+    timeout 60 $P k 3000 > $out/probe_alone_k.txt 2>&1
+    for i in 1 2 3 4 5; do timeout 200 $P k 3000 > $out/probe_5x_k_$i.txt 2>&1 & done; wait
+    timeout 100 $P idle 40 8 > $out/probe_idle.txt 2>&1 &
+    sleep 8
+    for i in 1 2 3 4; do timeout 200 $P k 3000 > $out/probe_4x_k_idle_$i.txt 2>&1 & done; wait
+    for i in 1 2 3 4 5; do timeout 300 $P h 300 > $out/probe_5x_h_$i.txt 2>&1 & done; wait
+    head -3 $out/probe_*.txt | cut -c1-400
+    timeout 900 python scripts/stale_read_hunt.py --procs 4 --iters ${HUNT_ITERS:-120} --hold-gb 6 > $out/hunt_parent_6gb.jsonl 2> $out/hunt_parent_6gb.err
+    tail -1 $out/hunt_parent_6gb.jsonl | cut -c1-1500
+    timeout 900 python scripts/stale_read_hunt.py --procs 4 --iters ${HUNT_ITERS:-120} --hold-gb 0 > $out/hunt_no_parent.jsonl 2> $out/hunt_no_parent.err
+    tail -1 $out/hunt_no_parent.jsonl | cut -c1-1500
+    ;;
+  variants)   # which property of the pass-2 kernel matters: scripts/probes/pass2_variants/build.sh, then the hunt per library
+    for lib in default ${VARIANTS:-noslp fminmax plainload vec2 ldsptr}; do
+      arg=""; [ $lib != default ] && arg="--lib scratch/pass2_variants/libbm_gar_$lib.so"
+      timeout 600 python scripts/stale_read_hunt.py --procs 4 --iters ${HUNT_ITERS:-400} --hold-gb 0 --kinds pass2 $arg > $out/hunt_$lib.jsonl 2> $out/hunt_$lib.err
+      tail -1 $out/hunt_$lib.jsonl | cut -c1-600
+    done
+    ;;
+  fixcheck)   # after the packed-fp32 fix: library-free probe, the hunt on the shipped library, bench A/B old flags / new flags, the pair, the suite
+    P=scripts/probes/pk_f32_probe
+    [ -x $P ] || hipcc --offload-arch=gfx950 -O2 -fno-slp-vectorize -o $P $P.hip
+    timeout 120 $P 3000 > $out/pk_alone.txt 2>&1; head -1 $out/pk_alone.txt
+    for i in 1 2 3 4 5; do timeout 300 $P 3000 > $out/pk_5x_$i.txt 2>&1 & done; wait
+    head -2 $out/pk_5x_*.txt | cut -c1-300
+    timeout 900 python scripts/stale_read_hunt.py --procs 4 --iters ${HUNT_ITERS:-400} --hold-gb 0 > $out/hunt_shipped.jsonl 2> $out/hunt_shipped.err
+    tail -1 $out/hunt_shipped.jsonl | cut -c1-900
+    for side in new old new old; do
+      lib=""; [ $side = old ] && lib=scratch/slp/libbm_gar_r5flags.so
+      BM_GAR_LIB=$lib timeout 600 python bench.py > $out/bench_${side}_$(date +%s).json 2>> $out/bench.err
+    done
+    for i in 1 2 3; do
+      BM_TEST_POISON=0 timeout 500 python -m pytest tests/test_gpu_full_size_o1.py tests/test_gpu_zz_multirank.py -m gpu -q > $out/pair_$i.log 2>&1
+      tail -2 $out/pair_$i.log
+    done
+    ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $out/pytest_gpu.log 2>&1; tail -4 $out/pytest_gpu.log
+    ;;
+  pair)   # the failing pair of files as the suite runs them, N times
+    for i in $(seq 1 ${PAIR_RUNS:-3}); do
+      BM_TEST_POISON=0 timeout 500 python -m pytest tests/test_gpu_full_size_o1.py tests/test_gpu_zz_multirank.py -m gpu -q > $out/pair_$i.log 2>&1
+      tail -2 $out/pair_$i.log
+    done
+    ;;
+  suite)  # what the driver runs at the end of a round
+    ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $out/pytest_gpu.log 2>&1; tail -4 $out/pytest_gpu.log
+    timeout 200 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -1 $out/smoke.log
+    timeout 600 python bench.py > $out/bench_default.json 2> $out/bench_default.err; wc -c $out/bench_default.json
+    ;;
+  *)      # anything else: the rest of the command line, logged
+    "$@" > $out/run.log 2>&1; tail -20 $out/run.log
+    ;;
+esac
+ls -la $out | head -40

@@ -36,6 +36,26 @@ def kernels(lib=LIB):
   return out
 
 
+def packed_fp32(lib=LIB):
+  """{kernel symbol: number of v_pk_{add,mul,fma}_f32 instructions} over the gfx950 code objects of the library — must
+  be empty (byzantinemomentum_amd/build.py: the packed forms gave wrong results under GPU sharing)."""
+  found = {}
+  with tempfile.TemporaryDirectory() as tmp:
+    local = pathlib.Path(tmp) / lib.name
+    shutil.copy(lib, local)
+    subprocess.run([LLVM / "llvm-objdump", "--offloading", local], cwd=tmp, capture_output=True, check=True)
+    for co in sorted(pathlib.Path(tmp).glob("*gfx950*")):
+      text = subprocess.run([LLVM / "llvm-objdump", "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
+      name = None
+      for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+        if m:
+          name = m.group(1)
+        elif re.search(r"\bv_pk_(add|mul|fma)_f32\b", line):
+          found[name] = found.get(name, 0) + 1
+  return found
+
+
 if __name__ == "__main__":
   pat = re.compile(sys.argv[1]) if len(sys.argv) > 1 else None
   print(f"{'vgpr':>5} {'sgpr':>5} {'s_spill':>7} {'v_spill':>7} {'lds':>7} {'scratch':>7}  kernel")

@@ -48,7 +48,7 @@ class OracleBackend:
       acc = acc + gradients[i]
     return acc.div_(m)
 
-  def bulyan_pass2(self, gradients, order, f, m, walk=None):  # (walk: where the HIP kernel starts; no effect on the output)
+  def bulyan_pass2(self, gradients, order, f, m):
     n = len(gradients)
     m_max, theta = n - f - 2, n - 2 * f - 2
     beta = theta - 2 * f

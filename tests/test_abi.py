@@ -169,17 +169,19 @@ int main(void) {
   assert run.stdout.split() == ["abi", str(_lib.ABI_VERSION), "ok"]
 
 
-def test_walk_entry_points_validate_arguments_without_gpu(lib):
-  """bm_bulyan_pass2_walk, bm_colwise_eval_walk (ABI 17): the argument checks of the entry points they extend."""
+def test_second_pass_entry_points_validate_arguments_without_gpu(lib):
+  """bm_bulyan_pass2, bm_colwise_eval: their argument checks (no launch).  ABI 19 dropped the `_walk` twins of both (a
+  measured no-win, profiles/r05_a_second_pass_walk_ab.txt): the library must not export them any more."""
   from byzantinemomentum_amd import _lib
   rows = (ctypes.c_void_p * 64)()
-  for walk in (-1, 0, 1):
-    assert lib.bm_bulyan_pass2_walk(rows, 25, None, 5, 18, 1000, rows, walk, None) == _lib.EINVAL      # no ranking
-    assert lib.bm_bulyan_pass2_walk(rows, 22, rows, 5, 15, 1000, rows, walk, None) == _lib.EINVAL      # n < 4 f + 3
-    assert lib.bm_bulyan_pass2_walk(rows, 25, rows, 5, 19, 1000, rows, walk, None) == _lib.EINVAL      # m > n - f - 2
-    assert lib.bm_bulyan_pass2_walk(rows, 25, rows, 5, 18, 0, None, walk, None) == 0                   # an empty shard
+  assert lib.bm_bulyan_pass2(rows, 25, None, 5, 18, 1000, rows, None) == _lib.EINVAL      # no ranking
+  assert lib.bm_bulyan_pass2(rows, 22, rows, 5, 15, 1000, rows, None) == _lib.EINVAL      # n < 4 f + 3
+  assert lib.bm_bulyan_pass2(rows, 25, rows, 5, 19, 1000, rows, None) == _lib.EINVAL      # m > n - f - 2
+  assert lib.bm_bulyan_pass2(rows, 25, rows, 5, 18, 0, None, None) == 0                   # an empty shard
   tail = (rows, rows, ctypes.c_float(1.0))
-  assert lib.bm_colwise_eval_walk(_lib.OP_MEDIAN, rows, 20, 5, 1000, 5, *tail, 1, rows, rows, None) == _lib.EINVAL
-  assert lib.bm_colwise_eval_walk(_lib.OP_TRMEAN, rows, 19, 5, 1000, 5, *tail, 1, rows, rows, None) == _lib.EINVAL
-  assert lib.bm_colwise_eval_walk(_lib.OP_TRMEAN, rows, 20, 5, 1000, 5, None, rows, ctypes.c_float(1.0), 0, rows, rows, None) == _lib.EINVAL
-  assert lib.bm_abi_version() == 18
+  assert lib.bm_colwise_eval(_lib.OP_MEDIAN, rows, 20, 5, 1000, 5, *tail, rows, rows, None) == _lib.EINVAL
+  assert lib.bm_colwise_eval(_lib.OP_TRMEAN, rows, 19, 5, 1000, 5, *tail, rows, rows, None) == _lib.EINVAL
+  assert lib.bm_colwise_eval(_lib.OP_TRMEAN, rows, 20, 5, 1000, 5, None, rows, ctypes.c_float(1.0), rows, rows, None) == _lib.EINVAL
+  for gone in ("bm_bulyan_pass2_walk", "bm_colwise_eval_walk"):
+    assert not hasattr(lib, gone), gone
+  assert lib.bm_abi_version() == 19

@@ -211,7 +211,7 @@ def test_burst_form_index_map_covers_every_column_group_once():
   column groups as v = it * (grid * T) + block * T + lane, in phases of `slots` iterations whose results sit in LDS
   slot (it - p0) * T + lane until the barrier.  Replay that arithmetic on the host: every group below nv is produced
   exactly once, staged in a slot no other live result of the same lane occupies, and written from that slot."""
-  def replay(nv, grid, threads, slots, reverse=False):
+  def replay(nv, grid, threads, slots):
     span = grid * threads
     iters = (nv + span - 1) // span
     written = np.zeros(nv, dtype=np.int32)
@@ -223,7 +223,7 @@ def test_burst_form_index_map_covers_every_column_group_once():
         p1 = min(p0 + slots, iters)
         stage = {}
         for it in range(p0, p1):
-          v = (iters - 1 - it if reverse else it) * span + first  # (selected_mean_burst_kernel: from the end by default)
+          v = it * span + first
           ok = v < nv
           slot = (it - p0) * threads + lanes
           assert slot.max() < slots * threads
@@ -231,7 +231,7 @@ def test_burst_form_index_map_covers_every_column_group_once():
             assert s not in stage
             stage[int(s)] = int(vv)
         for it in range(p0, p1):
-          v = (iters - 1 - it if reverse else it) * span + first
+          v = it * span + first
           ok = v < nv
           slot = (it - p0) * threads + lanes
           for s, vv in zip(slot[ok], v[ok]):
@@ -243,31 +243,23 @@ def test_burst_form_index_map_covers_every_column_group_once():
   for nv, grid, threads, slots in ((1, 4, 8, 3), (95, 4, 8, 3), (96, 4, 8, 3), (97, 4, 8, 3), (1000, 4, 8, 3),
                                    (513, 8, 16, 10), (5000, 3, 32, 9), (32 * 7 * 10, 7, 32, 10)):
     replay(nv, grid, threads, slots)
-    replay(nv, grid, threads, slots, reverse=True)
 
 
-def test_block_walk_from_the_end_covers_every_column_group_once():
-  """bulyan_pass2_kernel and selected_mean_kernel (the second pass of a two-pass rule) walk blocks of T column groups,
-  block b of the grid-stride loop being block nblk - 1 - b of the vector when BM_SECOND_PASS_REVERSE is set (the
-  default): v = (reverse ? nblk - 1 - b : b) * T + lane, guarded by v < nv.  Replay: every group exactly once either
-  way, the first workgroup starts at the END of the vector, and every block is T-aligned (whole cache lines per wave)."""
+def test_block_walk_covers_every_column_group_once():
+  """bulyan_pass2_kernel and selected_mean_kernel (the second pass of a two-pass rule) walk blocks of T column groups in a
+  grid-stride loop: v = b * T + lane, guarded by v < nv.  Replay: every group exactly once, every block T-aligned (whole
+  cache lines per wave)."""
   for nv, grid, threads in ((1, 4, 8), (7, 1, 8), (8, 3, 8), (9, 3, 8), (1000, 7, 16), (4096, 16, 256), (4097, 5, 256)):
-    for reverse in (False, True):
-      nblk = (nv + threads - 1) // threads
-      written = np.zeros(nv, dtype=np.int32)
-      starts = []
-      for block in range(grid):
-        b = block
-        while b < nblk:
-          base = (nblk - 1 - b if reverse else b) * threads
-          assert base % threads == 0
-          if block == 0 and b == 0:
-            starts.append(base)
-          v = base + np.arange(threads)
-          written[v[v < nv]] += 1
-          b += grid
-      assert (written == 1).all(), (nv, grid, threads, reverse)
-      assert starts == [(nblk - 1) * threads if reverse else 0]
+    nblk = (nv + threads - 1) // threads
+    written = np.zeros(nv, dtype=np.int32)
+    for block in range(grid):
+      b = block
+      while b < nblk:
+        base = b * threads
+        v = base + np.arange(threads)
+        written[v[v < nv]] += 1
+        b += grid
+    assert (written == 1).all(), (nv, grid, threads)
 
 
 def test_alloc_rows_layout_on_cpu():

@@ -284,37 +284,3 @@ def test_bulyan_factor_search_ranks_from_scalars(n, f, attack, negative, m):
     assert fa == fg and sa == sg and len(sa) == 10
     assert torch.equal(oa, og)
   assert max(y for _, y in runs["auto"][0][1]) > 0
-
-
-def test_search_alternation_knob_states_the_walk_and_changes_nothing(monkeypatch):
-  """BM_SEARCH_ALTERNATE=1 (experiments, default off): the factor search against Bulyan hands every pass 2 a walk,
-  0, 1, 0, 1, ... from its first evaluation on (each pass starts where the previous one ended: the Infinity Cache);
-  without the knob no walk is stated (the library's default).  The output of pass 2 does not depend on the walk: same
-  candidates, objective values, factor and aggregated gradient either way."""
-  from byzantinemomentum_amd.sharded import ShardedAggregator
-  from byzantinemomentum_amd.step import AggregationStep
-  from tests.sharded_backend import OracleBackend
-
-  class Recording(OracleBackend):
-    def __init__(self):
-      super().__init__()
-      self.walks = []
-
-    def bulyan_pass2(self, gradients, order, f, m, walk=None):
-      self.walks.append(walk)
-      return super().bulyan_pass2(gradients, order, f, m)
-
-  n, f = 11, 2
-  runs = {}
-  for knob in ("0", "1"):
-    monkeypatch.setenv("BM_SEARCH_ALTERNATE", knob)
-    backend = Recording()
-    step = AggregationStep(n, f, f, gar="bulyan", momentum=0.9, dampening=0.9, momentum_at="server", attack="empire",
-                           attack_factor=1.1, nb_past=2, aggregator=ShardedAggregator(backend=backend), attack_evals=6,
-                           line_search="auto")
-    out = step.run(sampled_for_step(0, n - f, d=401))
-    runs[knob] = (step.last_factor, list(step.last_search), out.clone(), list(backend.walks))
-  assert runs["0"][:2] == runs["1"][:2] and torch.equal(runs["0"][2], runs["1"][2])
-  assert all(w is None for w in runs["0"][3]) and len(runs["0"][3]) >= 6
-  searched = runs["1"][3][:6]
-  assert searched == [0, 1, 0, 1, 0, 1]
