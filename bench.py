@@ -304,7 +304,8 @@ def cpu_baseline_step(sampled, n, f, gar):
 # Live HBM traffic: rocprofv3 PMC passes of this very command (separate runs, --kernel-trace only)
 
 def measure_traffic(argv, kernel_substrings, extras=False):
-  """HBM bytes per launch of every kernel whose name contains one of `kernel_substrings` (dict key -> substring):
+  """HBM bytes per launch of every kernel whose name contains one of `kernel_substrings` (dict key -> substring, or
+  (substring, lowest grid size, highest grid size) in work-items when one kernel runs at two lengths in the command):
   FETCH_SIZE and WRITE_SIZE (KiB) from two rocprofv3 --pmc passes (their own runs, --kernel-trace only) of this very
   command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950.
   Returns {key: bytes} (keys whose kernel was not launched are absent); None if rocprofv3 is unavailable."""
@@ -330,6 +331,13 @@ def measure_traffic(argv, kernel_substrings, extras=False):
             if row["Counter_Name"] != counter:
               continue
             for key, sub in kernel_substrings.items():
+              if isinstance(sub, tuple):
+                sub, lo, hi = sub
+                try:
+                  if not lo <= int(row["Grid_Size"]) <= hi:
+                    continue
+                except (KeyError, ValueError):
+                  pass
               if sub in row["Kernel_Name"]:
                 slot = (key, row["Dispatch_Id"])
                 per_dispatch[slot] = per_dispatch.get(slot, 0.0) + float(row["Counter_Value"])
@@ -347,9 +355,14 @@ def traffic_kernels(d2, d5):
     "median": ("colwise_burst_kernel<25, 0", 4 * d2 * 26),
     "trmean": ("colwise_burst_kernel<25, 1", 4 * d2 * 26),
     "krum_c3.distances": ("gram3_partial_kernel<13, 2", 4 * d2 * 51),
-    "bulyan_c4_1gpu.pass2": ("bulyan_pass2_kernel<25, 5, 4>", 4 * d2 * 19),  # (not its 2-column tail launch <25, 5, 1>)
-    "step_c5.first_pass": ("momentum_gram_kernel", 4 * d5 * 63),  # (Krum step: first pass + distance pass in one kernel)
-    "step_c5.study": ("study_stats_burst_kernel<true, 3, false>", 4 * d5 * 8),
+    # (bulyan_pass2_kernel<25, 5, 4> runs at both lengths in the child command: told apart by the grid, 256 lanes per
+    #  workgroup, one workgroup per 256 column groups up to 16 384 workgroups)
+    "bulyan_c4_1gpu.pass2": (("bulyan_pass2_kernel<25, 5, 4>", 0, 256 * 16383), 4 * d2 * 19),
+    "step_c5.first_pass": ("momentum_gram_kernel", 4 * d5 * 63),  # (Krum / Bulyan step: first pass + distance pass in one kernel)
+    # the second pass of the Bulyan step: 18 ranked rows of which the f = 5 Byzantine ones are ONE buffer (the empire
+    # vector ranks first): 14 distinct rows read + 1 written — what HBM delivers — against 19 counted row by row
+    "step_c5.bulyan_pass2": (("bulyan_pass2_kernel<25, 5, 4>", 256 * 16384, 1 << 40), 4 * d5 * 15),
+    "step_c5.study": ("study_stats_burst_kernel<true, 3, false, false>", 4 * d5 * 8),
   }
 
 
@@ -807,8 +820,9 @@ def main():
         kernels = traffic_kernels(D_RESNET18, D_WRN)
         got = measure_traffic(child, {k: v[0] for k, v in kernels.items()}, extras=True)
         if got is not None:
-          per_kernel = {k: {"kernel": kernels[k][0], "traffic": got[k], "algorithmic_bytes": kernels[k][1],
-                            "ratio": got[k] / kernels[k][1]} for k in got}
+          per_kernel = {k: {"kernel": kernels[k][0] if isinstance(kernels[k][0], str) else kernels[k][0][0],
+                            "traffic": got[k], "algorithmic_bytes": kernels[k][1], "ratio": got[k] / kernels[k][1]}
+                        for k in got}
           traffic = got.get(dominant)
       else:
         got = measure_traffic(child, {"dominant": dominant_kernel})
@@ -857,7 +871,59 @@ def attack_search(bm, honests, n, f, d, evals=16, gar="krum"):
     res["scalar_form_ms" if mode == "auto" else "per_evaluation_form_ms"] = (time.perf_counter() - t0) / reps * 1e3
     res["factor_" + mode] = factor
   res["speedup"] = res["per_evaluation_form_ms"] / res["scalar_form_ms"]
+  if gar in ("krum", "bulyan"):
+    res["legs"] = search_legs(bm, honests, avg, direction, n, f, gar, evals)
   return res
+
+
+def search_legs(bm, honests, avg, direction, n, f, gar, evals, reps=10):
+  """Where the scalar form of the factor search spends its time, leg by leg (wall clock, each leg bracketed by a
+  synchronisation; the entry itself — `scalar_form_ms` — is timed without these brackets): the distance pass over
+  h + 2 rows, the copy of the (h+2)^2 fp64 matrix to the host both ways (`.cpu()` into pageable memory / an
+  asynchronous copy into a pinned buffer + stream synchronisation: what AggregationStep does), the host arithmetic of
+  `evals` candidates.  The same binaries measured 0.55 ms and 6-7 ms per search on one box in round 6, per PROCESS: the
+  box facts a slow process would need to explain itself ride along."""
+  from byzantinemomentum_amd import linesearch, stats
+  h = len(honests)
+  k = n - h
+  unit = torch.empty_like(avg)
+  pinned = torch.empty((h + 2, h + 2), dtype=torch.float64, pin_memory=True)
+  legs = {"distance_pass_ms": [], "d2h_pageable_ms": [], "d2h_pinned_ms": [], "host_search_ms": []}
+  for _ in range(reps):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    stats.multi_fma3([unit], [avg], [direction], 1.0, 1.0)
+    sq = bm.gars.pairwise_sqdist(list(honests) + [avg, unit])
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    ext = sq.cpu().contiguous()
+    t2 = time.perf_counter()
+    pinned.copy_(sq, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    t3 = time.perf_counter()
+    if gar == "krum":
+      linesearch.attack_line_search(ext, h, k, f, "krum", evals=evals)
+    else:
+      for e in range(evals):
+        linesearch.attack_ranking(ext, h, k, f, "bulyan", 0.5 + 0.25 * e)
+    t4 = time.perf_counter()
+    for key, dt in zip(legs, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+      legs[key].append(dt * 1e3)
+  out = {key: {"median": sorted(v)[len(v) // 2], "max": max(v)} for key, v in legs.items()}
+  def read(path):
+    try:
+      with open(path) as fh:
+        return fh.read().strip()
+    except OSError:
+      return None
+  import glob
+  stat = read("/proc/self/stat")
+  out["box"] = {"cpus_allowed": len(os.sched_getaffinity(0)), "cpu_now": int(stat.split()[38]) if stat else None,
+                "governor": read("/sys/devices/system/cpu/cpu0/cpufreq/scaling_governor"),
+                "gpu_numa_nodes": sorted({read(p) for p in glob.glob("/sys/class/drm/card*/device/numa_node")} - {None}),
+                "numa_nodes": len(glob.glob("/sys/devices/system/node/node[0-9]*")),
+                "loadavg": read("/proc/loadavg")}
+  return out
 
 
 def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
@@ -967,17 +1033,32 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
   # (one allocation per sampled gradient: for the step that placement measured best)
   sets = [[mu_vec + s * torch.randn(d, device=device, generator=gen) for s in torch.linspace(0.5, 1.5, h).tolist()]
           for _ in range(2)]
-  # (inside the PMC child run only the krum step: the median step would launch the C2 column kernel's instance at
-  #  another length and blur its per-launch average)
-  for gar in (("krum",) if "BM_BENCH_CHILD" in os.environ else ("krum", "median")):
+  def step_entry(ms, gar, runner):
+    """The entry of one step configuration.  Krum / Bulyan: the second pass reads the m selected / ranked rows, of which
+    the f_real Byzantine ones are ONE buffer — HBM delivers a buffer once however often the rule counts it — so the
+    entry carries both figures: `algorithmic_bytes` row by row as the reference's loop counts them, and
+    `distinct_bytes` / `frac_of_8TBps_distinct` with every buffer counted once (what a fraction of the HBM peak can
+    honestly be quoted on)."""
+    rec = entry(ms, step_algorithmic_bytes(d, n, f, gar), config=f"full step mirror, rule {gar}, n={n}, f={f}, d={d}, one GPU")
+    if gar in ("krum", "bulyan") and runner.buffers is not None and runner.last_byzantine is not None:
+      rows = list(runner.buffers) + [runner.last_byzantine] * f
+      bm.gars.invalidate_rank_cache()
+      ranked = (bm.gars.krum_selection(rows, f) if gar == "krum" else bm.gars.bulyan_ranking(rows, f))[:n - f - 2]
+      aliased = sum(1 for i in ranked if i >= h)
+      distinct = step_algorithmic_bytes(d, n, f, gar) - 4 * d * max(aliased - 1, 0)
+      rec.update(selected_aliased_rows=aliased, distinct_bytes=distinct, frac_of_8TBps_distinct=distinct / ms / 1e6 / HBM_PEAK_GBPS)
+    return rec
+
+  # (inside the PMC child run only the Krum and Bulyan steps — the median step would launch the C2 column kernel's
+  #  instance at another length and blur its per-launch average)
+  for gar in (("krum", "bulyan") if "BM_BENCH_CHILD" in os.environ else ("krum", "median")):
     runner = AggregationStep(n, f, f, gar=gar, momentum=0.99, dampening=0.99, attack_factor=1.1, nb_past=25)
 
     def one(i):
       runner.run(sets[i & 1])
       runner.floats()
     ms = timed_loop(one, 8, 27, timer, "step_" + gar)  # 27 warm-up steps: the deque of 25 past averages is full
-    out[f"step_c5_{gar}"] = entry(ms, step_algorithmic_bytes(d, n, f, gar),
-                                  config=f"full step mirror, rule {gar}, n={n}, f={f}, d={d}, one GPU")
+    out[f"step_c5_{gar}"] = step_entry(ms, gar, runner)
     del runner
   if "BM_BENCH_CHILD" not in os.environ:
     # the two other rules SURVEY 8d lists for C5: Bulyan (its distance pass rides along with the first pass like
@@ -990,8 +1071,7 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
           runner.run(sets[i & 1])
           runner.floats()
         ms = timed_loop(one_more, 8, 27, timer, "step_" + gar)
-        out[f"step_c5_{gar}"] = entry(ms, step_algorithmic_bytes(d, n, f, gar),
-                                      config=f"full step mirror, rule {gar}, n={n}, f={f}, d={d}, one GPU")
+        out[f"step_c5_{gar}"] = step_entry(ms, gar, runner)
         del runner
       except Exception as err:  # noqa: BLE001  (a side entry must not take the line down)
         out[f"step_c5_{gar}"] = {"error": repr(err)}
@@ -1005,9 +1085,17 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
         runner.run(sets[i & 1])
         runner.floats()
       ms = timed_loop(one_update, 8, 27, timer, "step_update_" + gar)
-      units = (h + 3 if gar == "median" else h + 2 + (n - f - 2) + 1) + 3 + 8  # first pass (+ average of m rows), update momentum, study block
-      out[f"step_c5_update_{gar}"] = entry(ms, 4 * d * units,
-                                           config=f"full step mirror, momentum at the update, rule {gar}, n={n}, f={f}, d={d}, one GPU")
+      # first pass (+ average of the m selected rows), study block carrying the momentum of the update (M read + written)
+      units = (h + 3 if gar == "median" else h + 2 + (n - f - 2) + 1) + 2 + 8
+      rec = entry(ms, 4 * d * units,
+                  config=f"full step mirror, momentum at the update, rule {gar}, n={n}, f={f}, d={d}, one GPU")
+      if gar == "krum" and runner.last_byzantine is not None:
+        rows = list(sets[1]) + [runner.last_byzantine] * f  # (the last timed step ran on sets[7 & 1])
+        bm.gars.invalidate_rank_cache()
+        aliased = sum(1 for i in bm.gars.krum_selection(rows, f) if i >= h)
+        distinct = 4 * d * (units - max(aliased - 1, 0))
+        rec.update(selected_aliased_rows=aliased, distinct_bytes=distinct, frac_of_8TBps_distinct=distinct / ms / 1e6 / HBM_PEAK_GBPS)
+      out[f"step_c5_update_{gar}"] = rec
       del runner
   # last: host threads busy with a baseline must not sit next to a GPU measurement.  Full size, the same stacks.
   if cpu_baseline and c3_sample is not None:

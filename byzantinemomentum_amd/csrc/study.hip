@@ -7,6 +7,10 @@
 //   cosine with the previous sampled average, curvature sum over the past ones     attack.py:861-866
 //   (params - origin).norm().item()                                                attack.py:830
 // and the update of this implementation's curvature combination C = sum_i mu^i past_i (step.py).
+// With the momentum at the update (the reference's DEFAULT placement, attack.py:832-839) the kernel also carries
+//   grad_momentum_server.mul_(mu).add_(grad_defense, alpha=1 - dampening)          attack.py:836-838
+// on the defense vector it reads anyway: M read and written here (2 row units) instead of a pass of its own that
+// re-read the defense vector (3 units and a launch: 74 us of a 0.95 ms step at d = 36.5 M, round 5).
 //
 // Round 2 ran these as five to seven d-sized passes (statistics of the attack stack, statistics of the defense
 // vector, the Gram of four vectors plus two dots, two passes over C, the two-row distance kernel): 16 + 2 row passes.
@@ -39,6 +43,8 @@ struct StudyArgs {
   const float* origin;  // (L2)
   float* curv;          // C, read (CM >= 2) and written (CM >= 1)
   float* a_out;         // attack average, optional
+  float* mom;           // momentum of the update (attack.py:836-838, --momentum-at update), or NULL: M <- fma(mom_b, defense, mom_a * M)
+  float mom_a, mom_b;   // mu, 1 - dampening
 };
 
 // CM: 0 no curvature term kept (nb_past = 0); 1 first step: C <- s, no dot with the past;
@@ -63,11 +69,12 @@ __global__ __launch_bounds__(kStudyBlock) void study_stats_kernel(StudyArgs a, i
   const int64_t stride = (int64_t)gridDim.x * kStudyBlock;
   for (int64_t v = (int64_t)blockIdx.x * kStudyBlock + threadIdx.x; v < nvec; v += stride) {
     const int64_t j = v * VEC;
-    float s[VEC], h[VEC], df[VEC], bz[VEC], pa[VEC], cv[VEC], ol[VEC], pp[VEC], oo[VEC];
+    float s[VEC], h[VEC], df[VEC], bz[VEC], pa[VEC], cv[VEC], ol[VEC], pp[VEC], oo[VEC], mm[VEC];
     // every load of the iteration is issued before the first use
     load_stream<VEC>(a.s + j, s);
     load_stream<VEC>(a.h + j, h);
     load_stream<VEC>(a.def + j, df);
+    if (a.mom != nullptr) load_stream<VEC>(a.mom + j, mm);  // (wave-uniform)
     if constexpr (ATT) load_stream<VEC>(a.byz + j, bz);
     if constexpr (CM >= 2) {
       load_stream<VEC>(a.past + j, pa);
@@ -125,6 +132,11 @@ __global__ __launch_bounds__(kStudyBlock) void study_stats_kernel(StudyArgs a, i
       if constexpr (CM >= 2) cv[c] = __builtin_fmaf(1.0f, s[c], mu * cv[c]);
     }
     if constexpr (CM >= 1) store_stream<VEC>(a.curv + j, cv);
+    if (a.mom != nullptr) {
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) mm[c] = __builtin_fmaf(a.mom_b, df[c], a.mom_a * mm[c]);  // bm_multi_fma3's bits
+      store_stream<VEC>(a.mom + j, mm);
+    }
     if constexpr (ATT) {
       if (a.a_out != nullptr) store_stream<VEC>(a.a_out + j, av);
     }
@@ -183,17 +195,22 @@ __global__ __launch_bounds__(kStudyBlock) void study_stats_kernel(StudyArgs a, i
 // chain no longer grows with d (the plain form: one chain per lane over the whole grid-stride loop).
 // ---------------------------------------------------------------------------------------------------
 constexpr int kStudyBurstThreads = 1024;
-constexpr int kStudySlots = 8;  // iterations staged per burst: 8 x 1024 lanes x 16 B = 128 KB of LDS
+constexpr int kStudySlotBudget = 8;  // staged iterations per burst over all written streams: 8 x 1024 lanes x 16 B = 128 KB of LDS
 
-template <bool ATT, int CM, bool L2>
+// MOM: the momentum of the update rides along (StudyArgs::mom), a second written stream: both are staged, four
+// iterations each per burst instead of eight.
+template <bool ATT, int CM, bool L2, bool MOM = false>
 __global__ __launch_bounds__(kStudyBurstThreads) void study_stats_burst_kernel(StudyArgs a, int f_real, float mu,
                                                                                float w_oldest, uint32_t nvec,
                                                                                double* __restrict__ partial) {
   static_assert(CM >= 1, "without a written stream there is nothing to burst");
   constexpr int VEC = 4;
-  constexpr int U = (L2 && CM >= 2) ? 1 : 2;  // column groups per lane and iteration (with params / origin two do not fit 128 VGPRs)
+  constexpr int kStudySlots = MOM ? kStudySlotBudget / 2 : kStudySlotBudget;
+  // column groups per lane and iteration (with params / origin, or with the momentum, two do not fit 128 VGPRs)
+  constexpr int U = ((L2 && CM >= 2) || MOM) ? 1 : 2;
   using V = typename VecLoad<VEC>::T;
   __shared__ V stage[kStudySlots * kStudyBurstThreads];
+  __shared__ V stage_mom[MOM ? kStudySlots * kStudyBurstThreads : 1];
   __shared__ double red[kStudyBurstThreads / 64];
   __shared__ float mred[kStudyBurstThreads / 64];
   float acc[kStudySums];
@@ -214,6 +231,7 @@ __global__ __launch_bounds__(kStudyBurstThreads) void study_stats_burst_kernel(S
     const uint32_t p1 = (p0 + kStudySlots < iters) ? p0 + kStudySlots : iters;
     for (uint32_t it = p0; it < p1; it += U) {
       float s[U][VEC], h[U][VEC], df[U][VEC], bz[U][VEC], pa[U][VEC], cv[U][VEC], ol[U][VEC], pp[U][VEC], oo[U][VEC];
+      float mm[U][VEC];
       bool live[U];
       // every load of the iteration is issued before the first use
 #pragma unroll
@@ -225,6 +243,7 @@ __global__ __launch_bounds__(kStudyBurstThreads) void study_stats_burst_kernel(S
           load_stream<VEC>(a.s + j, s[u]);
           load_stream<VEC>(a.h + j, h[u]);
           load_stream<VEC>(a.def + j, df[u]);
+          if constexpr (MOM) load_stream<VEC>(a.mom + j, mm[u]);
           if constexpr (ATT) load_stream<VEC>(a.byz + j, bz[u]);
           if constexpr (CM >= 2) {
             load_stream<VEC>(a.past + j, pa[u]);
@@ -287,6 +306,11 @@ __global__ __launch_bounds__(kStudyBurstThreads) void study_stats_burst_kernel(S
 #pragma unroll
         for (int c = 0; c < VEC; ++c) packed[c] = cv[u][c];
         stage[(it + u - p0) * kStudyBurstThreads + tid] = packed;
+        if constexpr (MOM) {
+#pragma unroll
+          for (int c = 0; c < VEC; ++c) packed[c] = __builtin_fmaf(a.mom_b, df[u][c], a.mom_a * mm[u][c]);  // bm_multi_fma3's bits
+          stage_mom[(it + u - p0) * kStudyBurstThreads + tid] = packed;
+        }
       }
     }
 #pragma unroll
@@ -297,8 +321,11 @@ __global__ __launch_bounds__(kStudyBurstThreads) void study_stats_burst_kernel(S
     __syncthreads();  // not for the data (a lane reads back its own slots): it is what makes the stores a burst
     for (uint32_t it = p0; it < p1; ++it) {
       const uint32_t v = it * span + first;
-      if (v < nvec)
+      if (v < nvec) {
         __builtin_nontemporal_store(stage[(it - p0) * kStudyBurstThreads + tid], reinterpret_cast<V*>(a.curv + (int64_t)v * VEC));
+        if constexpr (MOM)
+          __builtin_nontemporal_store(stage_mom[(it - p0) * kStudyBurstThreads + tid], reinterpret_cast<V*>(a.mom + (int64_t)v * VEC));
+      }
     }
   }
   if (a_nan) amax = __builtin_nanf("");
@@ -414,18 +441,24 @@ static int launch_study_cm(const StudyArgs& a, int cm, int vec, int f_real, floa
   }
 }
 
+template <bool ATT, bool L2, bool MOM>
+static int launch_study_burst_mom(const StudyArgs& a, int cm, int f_real, float mu, float w, int64_t n, int grid,
+                                  double* partial, hipStream_t s) {
+  const uint32_t nv = (uint32_t)n;
+  if (cm == 1)
+    hipLaunchKernelGGL((study_stats_burst_kernel<ATT, 1, L2, MOM>), dim3(grid), dim3(kStudyBurstThreads), 0, s, a, f_real, mu, w, nv, partial);
+  else if (cm == 2)
+    hipLaunchKernelGGL((study_stats_burst_kernel<ATT, 2, L2, MOM>), dim3(grid), dim3(kStudyBurstThreads), 0, s, a, f_real, mu, w, nv, partial);
+  else
+    hipLaunchKernelGGL((study_stats_burst_kernel<ATT, 3, L2, MOM>), dim3(grid), dim3(kStudyBurstThreads), 0, s, a, f_real, mu, w, nv, partial);
+  BM_LAUNCH_CHECK();
+  return 0;
+}
 template <bool ATT, bool L2>
 static int launch_study_burst(const StudyArgs& a, int cm, int f_real, float mu, float w, int64_t n, int grid,
                               double* partial, hipStream_t s) {
-  const uint32_t nv = (uint32_t)n;
-  if (cm == 1)
-    hipLaunchKernelGGL((study_stats_burst_kernel<ATT, 1, L2>), dim3(grid), dim3(kStudyBurstThreads), 0, s, a, f_real, mu, w, nv, partial);
-  else if (cm == 2)
-    hipLaunchKernelGGL((study_stats_burst_kernel<ATT, 2, L2>), dim3(grid), dim3(kStudyBurstThreads), 0, s, a, f_real, mu, w, nv, partial);
-  else
-    hipLaunchKernelGGL((study_stats_burst_kernel<ATT, 3, L2>), dim3(grid), dim3(kStudyBurstThreads), 0, s, a, f_real, mu, w, nv, partial);
-  BM_LAUNCH_CHECK();
-  return 0;
+  return a.mom != nullptr ? launch_study_burst_mom<ATT, L2, true>(a, cm, f_real, mu, w, n, grid, partial, s)
+                          : launch_study_burst_mom<ATT, L2, false>(a, cm, f_real, mu, w, n, grid, partial, s);
 }
 
 // The burst form pays from a few iterations per CU on (BM_STUDY_BURST, default 8; 0 = never, 1 = always: tests).
@@ -451,6 +484,15 @@ extern "C" int bm_study_stats(const float* sampled_avg, const float* honest_avg,
                               int f_real, float* attack_avg_out, const float* past_newest, float* curv,
                               const float* past_oldest, int curv_mode, float mu, float oldest_weight,
                               const float* params, const float* origin, int64_t d, double* out, void* ws, void* stream) {
+  return bm_study_stats_update(sampled_avg, honest_avg, defense, byz, f_real, attack_avg_out, past_newest, curv, past_oldest,
+                               curv_mode, mu, oldest_weight, params, origin, nullptr, 0.0f, 0.0f, d, out, ws, stream);
+}
+
+extern "C" int bm_study_stats_update(const float* sampled_avg, const float* honest_avg, const float* defense,
+                                     const float* byz, int f_real, float* attack_avg_out, const float* past_newest,
+                                     float* curv, const float* past_oldest, int curv_mode, float mu, float oldest_weight,
+                                     const float* params, const float* origin, float* update_momentum, float momentum_mu,
+                                     float one_minus_damp, int64_t d, double* out, void* ws, void* stream) {
   using namespace bm;
   const bool att = f_real > 0, l2 = params != nullptr && origin != nullptr;
   if (out == nullptr || ws == nullptr || d < 0 || f_real < 0 || f_real > BM_MAX_ROWS || curv_mode < 0 || curv_mode > 3 ||
@@ -461,9 +503,9 @@ extern "C" int bm_study_stats(const float* sampled_avg, const float* honest_avg,
   hipStream_t s = static_cast<hipStream_t>(stream);
   StudyArgs a{sampled_avg, honest_avg, defense, att ? byz : nullptr, curv_mode >= 2 ? past_newest : nullptr,
               curv_mode == 3 ? past_oldest : nullptr, l2 ? params : nullptr, l2 ? origin : nullptr,
-              curv_mode >= 1 ? curv : nullptr, att ? attack_avg_out : nullptr};
-  const void* ptrs[10] = {a.s, a.h, a.def, a.byz, a.past, a.oldest, a.params, a.origin, a.curv, a.a_out};
-  const int vec = common_vec_width(ptrs, 10, nullptr);  // null pointers do not constrain the width
+              curv_mode >= 1 ? curv : nullptr, att ? attack_avg_out : nullptr, update_momentum, momentum_mu, one_minus_damp};
+  const void* ptrs[11] = {a.s, a.h, a.def, a.byz, a.past, a.oldest, a.params, a.origin, a.curv, a.a_out, a.mom};
+  const int vec = common_vec_width(ptrs, 11, nullptr);  // null pointers do not constrain the width
   double* partial = static_cast<double*>(ws);
   int nparts = 0;
   int64_t body = 0;
@@ -501,6 +543,7 @@ extern "C" int bm_study_stats(const float* sampled_avg, const float* honest_avg,
     t.origin = adv(a.origin);
     t.curv = a.curv != nullptr ? a.curv + body : nullptr;
     t.a_out = a.a_out != nullptr ? a.a_out + body : nullptr;
+    t.mom = a.mom != nullptr ? a.mom + body : nullptr;
     const int64_t rest = d - body;
     const int grid = (body == 0) ? stream_grid(rest, kStudyBlock, kStudyMaxBlocks) : 1;
     rc = launch_study(t, att, l2, curv_mode, 1, f_real, mu, oldest_weight, rest, grid,

@@ -112,15 +112,18 @@ def colwise_eval(rule, honests, copies, f, h_avg, direction, t):
 
 
 def study_stats(s_avg, h_avg, defense, byz, f_real, past_newest=None, curv=None, past_oldest=None, curv_mode=0, mu=0.0,
-                oldest_weight=0.0, params=None, origin=None, attack_avg_out=None):
+                oldest_weight=0.0, params=None, origin=None, attack_avg_out=None, update_momentum=None, update_mu=0.0,
+                update_omd=0.0):
   """The study block of a step in ONE pass (bm_study_stats, include/bm_gar.h): statistics of the attack stack
   (f_real copies of `byz`) and of the defense vector, the Gram matrix of (sampled avg, honest avg, defense, attack
   avg), <s, past_newest>, <s, C>, |params - origin|^2, and the in-place update of the curvature combination C =
   `curv` for the next step (curv_mode: 0 none, 1 C <- s, 2 C <- s + mu C, 3 the same after taking
-  oldest_weight * past_oldest out of C).  Returns the device fp64 vector of STUDY_SLOTS statistics; no sync."""
+  oldest_weight * past_oldest out of C).  update_momentum: the momentum of the update (attack.py:836-838), updated in
+  place in the same pass: M <- update_omd * defense + update_mu * M (bm_study_stats_update).
+  Returns the device fp64 vector of STUDY_SLOTS statistics; no sync."""
   vecs = [t for t in (s_avg, h_avg, defense, byz if f_real > 0 else None, past_newest if curv_mode >= 2 else None,
                       curv if curv_mode >= 1 else None, past_oldest if curv_mode == 3 else None, params, origin,
-                      attack_avg_out) if t is not None]
+                      attack_avg_out, update_momentum) if t is not None]
   _, d, device = gars._validate(vecs)
   if (params is None) != (origin is None):
     raise gars.GarInputError("study_stats needs both params and origin, or neither")
@@ -129,10 +132,14 @@ def study_stats(s_avg, h_avg, defense, byz, f_real, past_newest=None, curv=None,
   ws = gars._workspace(device, _lib.WS_STUDY, 1, d, "ws_study")
   opt = lambda t: _ptr(t) if t is not None else None  # noqa: E731
   with torch.cuda.device(device):
-    _lib.check(lib.bm_study_stats(_ptr(s_avg), _ptr(h_avg), _ptr(defense), opt(byz if f_real > 0 else None), int(f_real),
-                                  opt(attack_avg_out), opt(past_newest), opt(curv), opt(past_oldest), int(curv_mode),
-                                  ctypes.c_float(mu), ctypes.c_float(oldest_weight), opt(params), opt(origin), d,
-                                  _ptr(out), _ptr(ws), gars._stream(device)), "bm_study_stats")
+    _lib.check(lib.bm_study_stats_update(_ptr(s_avg), _ptr(h_avg), _ptr(defense), opt(byz if f_real > 0 else None),
+                                         int(f_real), opt(attack_avg_out), opt(past_newest), opt(curv), opt(past_oldest),
+                                         int(curv_mode), ctypes.c_float(mu), ctypes.c_float(oldest_weight), opt(params),
+                                         opt(origin), opt(update_momentum), ctypes.c_float(update_mu),
+                                         ctypes.c_float(update_omd), d, _ptr(out), _ptr(ws), gars._stream(device)),
+               "bm_study_stats_update")
+  if update_momentum is not None:
+    gars.invalidate_rank_cache()  # (a user tensor was written)
   return out
 
 

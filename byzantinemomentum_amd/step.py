@@ -128,6 +128,21 @@ class AggregationStep:
       return agg.brute(gradients, f, check=True, **self.gar_args)
     return getattr(agg, self.gar)(gradients, f, **self.gar_args)
 
+  def _fetch(self, matrix):
+    """A small device matrix on the host, through a PINNED buffer this step keeps (one asynchronous copy + one stream
+    synchronisation).  `.cpu()` into pageable memory goes through the runtime's staging path, whose cost on the pool's
+    boxes is bimodal — 0.05 ms or several ms for 15 KB, per process (bench.py: attack_search legs) — and this copy
+    sits on the critical path of every factor search."""
+    if not matrix.is_cuda:
+      return matrix.contiguous()
+    key = (tuple(matrix.shape), matrix.dtype)
+    if getattr(self, "_pinned", None) is None or self._pinned[0] != key:
+      self._pinned = (key, torch.empty(matrix.shape, dtype=matrix.dtype, pin_memory=True))
+    host = self._pinned[1]
+    host.copy_(matrix, non_blocking=True)
+    torch.cuda.current_stream(matrix.device).synchronize()
+    return host
+
   def _search_factor(self, honests, h_avg, direction):
     """attacks/identical.py:67-77: the factor maximising |GAR(honests + [avg + t*dir]*f_real) - avg|^2 under
     the evaluation budget.  Like the reference, `negative` flips the sign of the candidates DURING the
@@ -138,7 +153,7 @@ class AggregationStep:
        not (set(self.gar_args) - {"m"}):
       unit = torch.empty_like(h_avg)
       ops.multi_fma3([unit], [h_avg], [direction], 1.0, 1.0)   # avg + dir: the candidate of factor 1
-      ext = agg.global_sqdist(list(honests) + [h_avg, unit]).cpu().contiguous()  # the search's only synchronisation
+      ext = self._fetch(agg.global_sqdist(list(honests) + [h_avg, unit]))  # the search's only synchronisation
       factor, self.last_search = linesearch.attack_line_search(
         ext, h, k, self.f_decl, self.gar, evals=self.attack_evals, negative=self.attack_negative,
         m=self.gar_args.get("m"))
@@ -154,7 +169,7 @@ class AggregationStep:
       m = self.gar_args.get("m") or n - self.f_decl - 2
       unit = torch.empty_like(h_avg)
       ops.multi_fma3([unit], [h_avg], [direction], 1.0, 1.0)
-      ext = agg.global_sqdist(list(honests) + [h_avg, unit]).cpu().contiguous()
+      ext = self._fetch(agg.global_sqdist(list(honests) + [h_avg, unit]))
 
       def rule(cand, t):  # noqa: F811
         order = linesearch.attack_ranking(ext, h, k, self.f_decl, "bulyan", t, m)
@@ -300,9 +315,10 @@ class AggregationStep:
       self.server_momentum = defense          # no clone, as attack.py:835
       self._update = defense
     elif self.momentum_at == "update":
+      # M <- mu * M + (1 - damp) * defense (attack.py:836-838) rides along with the study block below, which reads the
+      # defense vector anyway (bm_study_stats_update): no pass of its own
       if self.server_momentum is None:
         self.server_momentum = torch.zeros_like(defense)
-      ops.multi_fma3([self.server_momentum], [self.server_momentum], [defense], self.mu, omd)
       self._update = self.server_momentum
     else:
       self._update = defense
@@ -321,7 +337,9 @@ class AggregationStep:
                             past_newest=self.pasts[0] if count > 0 else None, curv=self._curv,
                             past_oldest=self.pasts[-1] if mode == 3 else None, curv_mode=mode, mu=self.mu,
                             oldest_weight=-(self.mu ** (self.nb_past - 1)) if self.nb_past > 0 else 0.0,
-                            params=params if has_l2 else None, origin=origin if has_l2 else None)
+                            params=params if has_l2 else None, origin=origin if has_l2 else None,
+                            **(dict(update_momentum=self.server_momentum, update_mu=self.mu, update_omd=omd)
+                               if self.momentum_at == "update" else {}))
     self._pending = dict(s=s_out3, h=h_out3, study=study, npast=2 if count > 0 else 0,
                          prev_s2=self._prev_s2 if count > 0 else None, has_l2=has_l2, ks=ks, floats=None)
     if self.nb_past > 0:

@@ -177,6 +177,16 @@ int bm_study_stats(const float* sampled_avg, const float* honest_avg, const floa
                    int f_real, float* attack_avg_out, const float* past_newest, float* curv,
                    const float* past_oldest, int curv_mode, float mu, float oldest_weight, const float* params,
                    const float* origin, int64_t d, double* out, void* ws, void* stream);
+/* bm_study_stats that also carries the momentum of the update (attack.py:836-838, `--momentum-at update`, the
+ * reference's default placement): update_momentum <- fma(one_minus_damp, defense, momentum_mu * update_momentum), in
+ * place, element by element with the bits of bm_multi_fma3(M, M, defense, mu, 1 - damp) — inside the pass that reads
+ * the defense vector anyway (2 row units more instead of a 3-unit pass and a launch of its own).  update_momentum
+ * NULL: exactly bm_study_stats.  The statistics are those of `defense`, not of the updated momentum. */
+int bm_study_stats_update(const float* sampled_avg, const float* honest_avg, const float* defense, const float* byz,
+                          int f_real, float* attack_avg_out, const float* past_newest, float* curv,
+                          const float* past_oldest, int curv_mode, float mu, float oldest_weight, const float* params,
+                          const float* origin, float* update_momentum, float momentum_mu, float one_minus_damp,
+                          int64_t d, double* out, void* ws, void* stream);
 
 /* sq_out[i] = |rows[i]|^2 (DEVICE, k doubles), every row read once: the `gradient.norm().item()` of
  * aggregators/cge.py:28-38 and of the clipping at attack.py:776-779,791-794 for all gradients in one call, without a

@@ -48,6 +48,20 @@ case $name in
     done
     ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $out/pytest_gpu.log 2>&1; tail -4 $out/pytest_gpu.log
     ;;
+  round2)   # new tests of round 6, the 4-experiment test five times, the pk probe with scalar operands, n = 51 timings + PMC, bench twice
+    P=scripts/probes/pk_f32_probe
+    [ -x $P ] || hipcc --offload-arch=gfx950 -O2 -fno-slp-vectorize -o $P $P.hip
+    timeout 120 $P 3000 > $out/pk_alone.txt 2>&1; head -1 $out/pk_alone.txt
+    for i in 1 2 3 4 5; do timeout 300 $P 3000 > $out/pk_5x_$i.txt 2>&1 & done; wait
+    head -1 $out/pk_5x_*.txt | cut -c1-300
+    timeout 900 python -m pytest tests/test_gpu_parity_r6.py tests/test_gpu_parity_r3.py tests/test_gpu_parity_r4.py -m gpu -x -q > $out/pytest_new.log 2>&1; tail -5 $out/pytest_new.log
+    for i in 1 2 3 4 5; do
+      timeout 900 python -m pytest tests/test_gpu_reference_loop.py -m gpu -q -k four_experiments > $out/four_$i.log 2>&1; tail -1 $out/four_$i.log
+    done
+    timeout 300 python scripts/n51_probe.py > $out/n51_probe.txt 2>&1; cat $out/n51_probe.txt
+    scripts/pmc_collect.sh $out n51 -- python scripts/n51_probe.py 3 > $out/n51_pmc.txt 2>&1; tail -3 $out/n51_pmc.txt
+    for i in 1 2; do timeout 600 python bench.py > $out/bench_$i.json 2> $out/bench_$i.err; wc -c $out/bench_$i.json; done
+    ;;
   pair)   # the failing pair of files as the suite runs them, N times
     for i in $(seq 1 ${PAIR_RUNS:-3}); do
       BM_TEST_POISON=0 timeout 500 python -m pytest tests/test_gpu_full_size_o1.py tests/test_gpu_zz_multirank.py -m gpu -q > $out/pair_$i.log 2>&1

@@ -154,8 +154,10 @@ class OracleBackend:
     return torch.where(norm > clip, clip / norm, torch.ones_like(norm)).float()
 
   def study_stats(self, s_avg, h_avg, defense, byz, f_real, past_newest=None, curv=None, past_oldest=None, curv_mode=0,
-                  mu=0.0, oldest_weight=0.0, params=None, origin=None, attack_avg_out=None):
-    """CPU restatement of bm_study_stats (include/bm_gar.h): same slots, fp64 reductions, C updated in place."""
+                  mu=0.0, oldest_weight=0.0, params=None, origin=None, attack_avg_out=None, update_momentum=None,
+                  update_mu=0.0, update_omd=0.0):
+    """CPU restatement of bm_study_stats_update (include/bm_gar.h): same slots, fp64 reductions, C — and the momentum
+    of the update when given (attack.py:836-838) — updated in place."""
     out = torch.zeros(32, dtype=torch.float64)
     core = [s_avg, h_avg, defense]
     if f_real > 0:
@@ -181,6 +183,8 @@ class OracleBackend:
       if curv_mode == 3:
         curv.add_(past_oldest, alpha=oldest_weight)
       curv.mul_(mu).add_(s_avg)
+    if update_momentum is not None:
+      update_momentum.mul_(update_mu).add_(defense, alpha=update_omd)
     return out
 
   def study_dots(self, core, extra):

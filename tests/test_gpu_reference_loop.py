@@ -27,12 +27,12 @@ ACCEPT = HEADER_COLUMNS - 1  # "Attack acceptation ratio", printed with str()
 
 
 def _start_attack(outdir, gar, device, n, f, attack, attack_args, momentum_at, model="simples-full", dataset="mnist",
-                  extra=()):
+                  extra=(), steps=None):
   """Launch one run of the unmodified driver; returns (process, command line, result directory)."""
   env = dict(os.environ)
   env["PYTHONPATH"] = os.pathsep.join([ROOT, STUBS] + ([env["PYTHONPATH"]] if env.get("PYTHONPATH") else []))
   cmd = [sys.executable, "-OO", os.path.join(reference_loader.REFERENCE_DIR, "attack.py"),
-         "--seed", "1", "--device", device, "--nb-steps", str(STEPS), "--nb-workers", str(n),
+         "--seed", "1", "--device", device, "--nb-steps", str(steps or STEPS), "--nb-workers", str(n),
          "--nb-decl-byz", str(f), "--nb-real-byz", str(f), "--gar", gar, "--attack", attack,
          "--attack-args", *attack_args, "--model", model, "--dataset", dataset, "--momentum-at", momentum_at,
          "--momentum", "0.9", "--evaluation-delta", "0", "--nb-for-study", "1", "--nb-for-study-past", "3",
@@ -43,8 +43,9 @@ def _start_attack(outdir, gar, device, n, f, attack, attack_args, momentum_at, m
   return proc, cmd, outdir
 
 
-def _finish_attack(started):
+def _finish_attack(started, steps=None):
   proc, cmd, outdir = started
+  steps = steps or STEPS
   try:
     proc.wait(timeout=600)
   except subprocess.TimeoutExpired:
@@ -55,7 +56,7 @@ def _finish_attack(started):
   study = (outdir / "study").read_text().splitlines()
   assert study[0].startswith("# Step number") and len(study[0].split("\t")) == HEADER_COLUMNS
   rows = [line.split("\t") for line in study[1:] if line.strip()]
-  assert len(rows) == STEPS and all(len(r) == HEADER_COLUMNS for r in rows), tail[-2000:]
+  assert len(rows) == steps and all(len(r) == HEADER_COLUMNS for r in rows), tail[-2000:]
   return study[0].lstrip("# ").split("\t"), rows
 
 
@@ -124,6 +125,33 @@ def test_unmodified_attack_py_with_native_rules(tmp_path, rule, n, f, attack, at
   worst = _compare(names, want, got, 1e-5, accept_exact)
   print(f"native-{rule} n={n} f={f} {attack}: worst relative difference over {STEPS} steps x 21 floats = "
         f"{worst[0]:.2e} ({worst[1]})")
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_four_experiments_share_the_gpu_like_reproduce_py_runs_them(tmp_path):
+  """The reference's own deployment mode: `reproduce.py:62-73,118` hands `tools/jobs.py:169-191` `devmult` experiments
+  per device to run CONCURRENTLY, and its README (64-68) recommends `--supercharge 4`.  Four `attack.py --gar native-*`
+  processes (Bulyan, Krum, median, trimmed mean; n = 25, f = 5; 20 steps) share cuda:0 here, next to their four twins
+  with the reference's own rules — eight processes time-slicing one MI355X — and every study file must agree with its
+  twin's as in the one-at-a-time cases above.  This is the condition under which Bulyan's second pass used to return
+  wrong coordinates in ~1.5 % of its launches (packed fp32 instructions; the library is built without them)."""
+  if not reference_loader.available():
+    pytest.skip("no reference checkout here: scripts/stage_reference.sh (run by build()) stages it into oracle/_ref/")
+  steps = 20
+  rules = [("bulyan", "empire", ["factor:1.1"], "worker"), ("krum", "empire", ["factor:1.1"], "worker"),
+           ("median", "little", ["factor:1.5"], "update"), ("trmean", "empire", ["factor:1.1"], "server")]
+  started = []
+  for rule, attack, attack_args, momentum_at in rules:
+    for side, gar in (("reference", rule), ("native", f"native-{rule}")):
+      started.append((rule, side, _start_attack(tmp_path / f"{side}-{rule}", gar, "cuda:0", 25, 5, attack, attack_args,
+                                                momentum_at, steps=steps)))
+  done = {(rule, side): _finish_attack(run, steps=steps) for rule, side, run in started}
+  for rule, _, _, _ in rules:
+    names, want = done[(rule, "reference")]
+    _, got = done[(rule, "native")]
+    worst = _compare(names, want, got, 1e-5, True)
+    print(f"4 x 2 concurrent, native-{rule}: worst relative difference over {steps} steps x 21 floats = {worst[0]:.2e} ({worst[1]})")
 
 
 @pytest.mark.reference

@@ -23,7 +23,8 @@ HOT = [
   # in the lanes of a vector register (v_writelane / v_readlane outside the streaming loop; measured: no change of the
   # step's time, profiles/r06_fixcheck_bench_ab.txt) — a handful is tolerated, a scratch spill is not
   (r"momentum_gram_kernel<20, false, false>", 256, 8),
-  (r"study_stats_burst_kernel<true, 3, false>", 128),  # C5 study block
+  (r"study_stats_burst_kernel<true, 3, false, false>", 128),  # C5 study block
+  (r"study_stats_burst_kernel<true, 3, false, true>", 128),   # ... carrying the momentum of the update (--momentum-at update)
 ]
 
 
