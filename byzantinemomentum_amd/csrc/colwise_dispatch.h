@@ -7,6 +7,7 @@
 namespace bm {
 
 constexpr int kBurstMaxRows = 25;  // 4 waves per SIMD (1024 lanes per CU) leave 128 VGPRs: trmean at n = 25 just fits, n = 26 spills
+constexpr int kBurstMaxRowsClosest = 22;  // phocas / meamed keep the centre and the window search live on top: n = 23 spills
 
 template <int N, int OP, int VEC>
 static int launch_colwise_vec(const RowTable& rows_all, int64_t d_all, int f, float* out_all,
@@ -20,7 +21,8 @@ static int launch_colwise_vec(const RowTable& rows_all, int64_t d_all, int f, fl
     for (int i = 0; i < N; ++i) rows.p[i] += lo;
     const int64_t nvec = d / VEC;
     const int tail = (int)(d - nvec * VEC);
-    if constexpr (VEC == 4 && N <= kBurstMaxRows && (OP == BM_OP_MEDIAN || OP == BM_OP_TRMEAN)) {
+    // (every rule: none needs the LDS for itself any more)
+    if constexpr (VEC == 4 && N <= ((OP == BM_OP_MEDIAN || OP == BM_OP_TRMEAN) ? kBurstMaxRows : kBurstMaxRowsClosest)) {
       // burst form: one workgroup per CU; worth it once every CU has several iterations to stage
       const int cus = compute_units();
       const int64_t burst_iters = nvec / ((int64_t)cus * kBurstThreads);

@@ -40,10 +40,62 @@ __device__ __forceinline__ float trimmed_sum(const float (&x)[N], int f) {
   return t;
 }
 
-// Per-column rule on N register-resident values.  `lds` points at this lane's slot of a
-// [N][STRIDE] scratch array, STRIDE = lanes of the workgroup (only used by the closest-to-centre rules).
+// closest(): the sum of the m = N - F sorted values nearest the centre c (trmean.py:35-50).  In sorted order they form a
+// window [s, s + m) with 0 <= s <= F: "value t is farther than value t + m" forces the window to start after t, and the
+// LAST such t decides (with duplicated values the predicate is not monotone: take the maximum, not the count).  The
+// window is summed in ascending order from s.  Everything on registers with static indices: rounds 2-5 wrote the
+// sorted values to LDS and walked them with run-time indices (N ds_write + 2f + m dependent ds_read per column: at
+// n = 51 the closest-to-centre rules ran at 0.59-0.60 of the HBM peak against 0.72 for the trimmed mean next to
+// them); here the ranks F .. N-F-1 lie in every possible window and are added unconditionally, the 2F ranks at the
+// ends are added as `x or 0` (adding +0 changes nothing: the sum has the bits of the walk from s).
+template <int N, int F>
+__device__ __forceinline__ float closest_sum_static(const float (&x)[N], float c) {
+  constexpr int M = N - F;  // (M > F: the host refuses n < 2f + 1)
+  int s = 0;
+#pragma unroll
+  for (int t = 0; t < F; ++t) {
+    const float dl = __builtin_fabsf(x[t] - c);
+    const float dh = __builtin_fabsf(x[t + M] - c);
+    s = (dl > dh) ? (t + 1) : s;
+  }
+  float w = 0.0f;
+#pragma unroll
+  for (int i = 0; i < N; ++i) {
+    if (i < F)
+      w += (i >= s) ? x[i] : 0.0f;
+    else if (i >= M)
+      w += (i < s + M) ? x[i] : 0.0f;
+    else
+      w += x[i];
+  }
+  return w;
+}
+
+// The same for a wave-uniform run-time f: a scalar branch to the instance of that f (see trimmed_sum).
+template <int N>
+__device__ __forceinline__ float closest_sum(const float (&x)[N], int f, float c) {
+  float w = 0.0f;
+  switch (f) {
+#define BM_CLOSE_CASE(F)                                              \
+  case F:                                                             \
+    if constexpr (2 * (F) < N) w = closest_sum_static<N, (F)>(x, c);  \
+    break;
+    BM_CLOSE_CASE(0) BM_CLOSE_CASE(1) BM_CLOSE_CASE(2) BM_CLOSE_CASE(3) BM_CLOSE_CASE(4) BM_CLOSE_CASE(5) BM_CLOSE_CASE(6)
+    BM_CLOSE_CASE(7) BM_CLOSE_CASE(8) BM_CLOSE_CASE(9) BM_CLOSE_CASE(10) BM_CLOSE_CASE(11) BM_CLOSE_CASE(12)
+    BM_CLOSE_CASE(13) BM_CLOSE_CASE(14) BM_CLOSE_CASE(15) BM_CLOSE_CASE(16) BM_CLOSE_CASE(17) BM_CLOSE_CASE(18)
+    BM_CLOSE_CASE(19) BM_CLOSE_CASE(20) BM_CLOSE_CASE(21) BM_CLOSE_CASE(22) BM_CLOSE_CASE(23) BM_CLOSE_CASE(24)
+    BM_CLOSE_CASE(25) BM_CLOSE_CASE(26) BM_CLOSE_CASE(27) BM_CLOSE_CASE(28) BM_CLOSE_CASE(29) BM_CLOSE_CASE(30)
+    BM_CLOSE_CASE(31)
+#undef BM_CLOSE_CASE
+    default:
+      break;
+  }
+  return w;
+}
+
+// Per-column rule on N register-resident values (no LDS: the last argument is kept for the call sites' sake).
 template <int N, int OP, int STRIDE = kColBlock>
-__device__ __forceinline__ float column_rule(float (&x)[N], int f, float inv_keep, float* lds) {
+__device__ __forceinline__ float column_rule(float (&x)[N], int f, float inv_keep, float* /*unused*/) {
   const float kNaN = __builtin_nanf("");
   const float kInf = __builtin_inff();
   // --- NaN scan (1 v_cmp per value, masks OR-ed on the scalar unit) ---
@@ -75,8 +127,7 @@ __device__ __forceinline__ float column_rule(float (&x)[N], int f, float inv_kee
       const float r = div_small_int(tsum, (float)(N - 2 * f), inv_keep);
       return (nan_count > f) ? kNaN : r;
     } else {
-      // closest(): mean of the m = N-f values nearest the centre.  In sorted order these
-      // form a window [s, s+m) with 0 <= s <= f; "drop low end t" is monotone in t.
+      // closest(): mean of the m = N-f values nearest the centre (closest_sum above)
       float c;
       if constexpr (OP == BM_OP_PHOCAS) {
         c = div_small_int(tsum, (float)(N - 2 * f), 1.0f / (float)(N - 2 * f));
@@ -85,18 +136,7 @@ __device__ __forceinline__ float column_rule(float (&x)[N], int f, float inv_kee
         c = has_nan ? kNaN : x[(N - 1) / 2];
       }
       const int m = N - f;
-#pragma unroll
-      for (int i = 0; i < N; ++i) lds[i * STRIDE] = x[i];
-      // "t is farther than t+m" forces the window to start after t; the last such t decides
-      // (with duplicated values the predicate is not monotone, so take the max, not the count).
-      int s = 0;
-      for (int t = 0; t < f; ++t) {
-        const float dl = __builtin_fabsf(lds[t * STRIDE] - c);
-        const float dh = __builtin_fabsf(lds[(t + m) * STRIDE] - c);
-        s = (dl > dh) ? (t + 1) : s;
-      }
-      float wsum = 0.0f;
-      for (int i = 0; i < m; ++i) wsum += lds[(s + i) * STRIDE];
+      const float wsum = closest_sum<N>(x, f, c);
       const float r = div_small_int(wsum, (float)m, inv_keep);
       return (c != c || nan_count > f) ? kNaN : r;
     }
@@ -113,10 +153,7 @@ template <int N, int OP, int VEC, bool ABLATE_STORE = false>
 __global__ __launch_bounds__(kColBlock) void colwise_kernel(RowTable rows, int64_t nvec, int tail,
                                                             int f, float inv_keep, int nt_result,
                                                             float* __restrict__ out) {
-  constexpr bool kNeedsLds = (OP == BM_OP_PHOCAS || OP == BM_OP_MEAMED);
-  __shared__ float scratch[kNeedsLds ? N * kColBlock : 1];
-  float* lds = scratch + (kNeedsLds ? threadIdx.x : 0);
-
+  float* const lds = nullptr;  // (no rule needs LDS any more, see closest_sum_static)
   // nvec * VEC * 4 < 2^32 (the host splits longer gradients): 32-bit byte offsets, saddr loads
   const uint32_t nv = (uint32_t)nvec;
   const uint32_t stride = gridDim.x * kColBlock;
@@ -152,7 +189,7 @@ __global__ __launch_bounds__(kColBlock) void colwise_kernel(RowTable rows, int64
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Burst form (median / trmean, VEC = 4, N <= 26, long gradients): the same loads and the same rule, but
+// Burst form (VEC = 4, N <= 25 — the closest-to-centre rules up to their own row limit, colwise_dispatch.h —, long gradients): the same loads and the same rule, but
 // the results leave the CU in bursts that coincide across the chip.
 //
 // A result stream that trickles out between the reads of 256 CUs costs 10-14 % of the kernel for 3.8 % of
@@ -179,7 +216,6 @@ constexpr int kBurstLdsBytes = 160 * 1024;
 template <int N, int OP, int VEC>
 __global__ __launch_bounds__(kBurstThreads) void colwise_burst_kernel(RowTable rows, int64_t nvec, int tail, int f,
                                                                       float inv_keep, float* __restrict__ out) {
-  static_assert(OP == BM_OP_MEDIAN || OP == BM_OP_TRMEAN, "the closest-to-centre rules need the LDS for themselves");
   using V = typename VecLoad<VEC>::T;
   constexpr int kSlots = kBurstLdsBytes / (kBurstThreads * VEC * (int)sizeof(float));
   __shared__ V stage[kSlots * kBurstThreads];

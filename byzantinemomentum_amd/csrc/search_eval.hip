@@ -27,10 +27,8 @@ template <int N, int OP, int VEC>
 __global__ __launch_bounds__(kColBlock) void colwise_eval_kernel(RowTable rows, int h, const float* __restrict__ avg,
                                                                  const float* __restrict__ dir, float t, int64_t nvec,
                                                                  int f, float inv_keep, double* __restrict__ partial) {
-  constexpr bool kNeedsLds = (OP == BM_OP_PHOCAS || OP == BM_OP_MEAMED);
-  __shared__ float scratch[kNeedsLds ? N * kColBlock : 1];
   __shared__ double red[kColBlock / 64];
-  float* lds = scratch + (kNeedsLds ? threadIdx.x : 0);
+  float* const lds = nullptr;  // (column_rule needs no LDS)
   float acc = 0.0f;
   double wide = 0.0;
   int since = 0;

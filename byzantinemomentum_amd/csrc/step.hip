@@ -80,9 +80,6 @@ __global__ __launch_bounds__(BURST ? kStepBurstBlock : kStepBlock) void momentum
   constexpr int BLOCK = BURST ? kStepBurstBlock : kStepBlock;
   __shared__ double red[BLOCK / 64];
   __shared__ float mred[BLOCK / 64];
-  // the closest-to-centre rules search their window in a per-lane LDS column ([T + NB][BLOCK] floats: 51 KB at 512 lanes)
-  constexpr bool kRuleLds = (RULE == BM_OP_PHOCAS || RULE == BM_OP_MEAMED);
-  __shared__ float rule_scratch[kRuleLds ? (T + NB) * BLOCK : 1];
   const float fks = (float)(EXACT ? T : ks_rt), fh = (float)(EXACT ? T : h_rt);
   float n2s = 0.0f, dvs = 0.0f, mxs = 0.0f, n2h = 0.0f, dvh = 0.0f, mxh = 0.0f;
   bool nan_s = false, nan_h = false;
@@ -179,7 +176,7 @@ __global__ __launch_bounds__(BURST ? kStepBurstBlock : kStepBlock) void momentum
           for (int i = 0; i < T; ++i) x[i] = b[i][c];
 #pragma unroll
           for (int i = 0; i < NB; ++i) x[T + i] = bz[c];
-          df[c] = column_rule<T + NB, RULE, BLOCK>(x, rule_f, rule_inv_keep, rule_scratch + (kRuleLds ? threadIdx.x : 0));
+          df[c] = column_rule<T + NB, RULE, BLOCK>(x, rule_f, rule_inv_keep, nullptr);
         }
       }
     }

@@ -62,6 +62,11 @@ case $name in
     scripts/pmc_collect.sh $out n51 -- python scripts/n51_probe.py 3 > $out/n51_pmc.txt 2>&1; tail -3 $out/n51_pmc.txt
     for i in 1 2; do timeout 600 python bench.py > $out/bench_$i.json 2> $out/bench_$i.err; wc -c $out/bench_$i.json; done
     ;;
+  round3)   # the static window search / Aksel lane pointers: n = 51 again, the whole suite, the bench
+    timeout 300 python scripts/n51_probe.py > $out/n51_probe.txt 2>&1; cat $out/n51_probe.txt
+    ( time timeout 1800 python -m pytest tests -m gpu -x -q ) > $out/pytest_gpu.log 2>&1; tail -4 $out/pytest_gpu.log
+    timeout 600 python bench.py > $out/bench_1.json 2> $out/bench_1.err; wc -c $out/bench_1.json
+    ;;
   pair)   # the failing pair of files as the suite runs them, N times
     for i in $(seq 1 ${PAIR_RUNS:-3}); do
       BM_TEST_POISON=0 timeout 500 python -m pytest tests/test_gpu_full_size_o1.py tests/test_gpu_zz_multirank.py -m gpu -q > $out/pair_$i.log 2>&1
