@@ -150,15 +150,29 @@ class KernelTimer:
     return out
 
   def mean_ms(self, name):
+    """Mean over the calls — a float that also carries their median (`.median`): on a loaded host one call in ten or
+    twenty can be held up for 10-130 ms between two launches (seen in round 6: profiles/r06_search_each.txt), which a
+    mean over a dozen sub-millisecond calls turns into a different kernel."""
     ps = self.pairs[name]
-    return sum(a.elapsed_time(b) for a, b in ps) / len(ps)
+    each = sorted(a.elapsed_time(b) for a, b in ps)
+    out = Milliseconds(sum(each) / len(each))
+    out.median = each[len(each) // 2]
+    return out
+
+
+class Milliseconds(float):
+  median = None
 
 
 def entry(ms, nbytes, gpus=1, units=1, **more):
   """One per_gar record: `nbytes` = algorithmic bytes moved by ALL `gpus` ranks in `ms`; `units` = aggregations (of the
   metric's n x d stack) that completes; the roofline fraction is against the HBM peak of the GPUs involved."""
-  return dict({"avg_ms": ms, "algorithmic_bytes": nbytes, "gbps": nbytes / ms / 1e6,
-               "frac_of_8TBps": nbytes / ms / 1e6 / (HBM_PEAK_GBPS * gpus), "agg_per_s": units * 1e3 / ms}, **more)
+  rec = {"avg_ms": float(ms), "algorithmic_bytes": nbytes, "gbps": nbytes / ms / 1e6,
+         "frac_of_8TBps": nbytes / ms / 1e6 / (HBM_PEAK_GBPS * gpus), "agg_per_s": units * 1e3 / ms}
+  median = getattr(ms, "median", None)
+  if median:  # the same figures on the median call (robust against a host that stalls between two launches)
+    rec.update(median_ms=median, frac_of_8TBps_median=nbytes / median / 1e6 / (HBM_PEAK_GBPS * gpus))
+  return dict(rec, **more)
 
 
 def timed_loop(fn, steps, warmup, timer, name):

@@ -241,50 +241,27 @@ static int launch_bulyan_fast(const float* const* rows_host, const int32_t* orde
 // ---------------------------------------------------------------------------
 // Aksel pass 1: median + per-row squared distance to the median.
 // ---------------------------------------------------------------------------
-// Row pointers: up to 28 rows they stay in scalar registers (the loads take them as saddr).  Beyond that 2 N scalar
-// registers do not exist — round 5's kernel parked 158 of them in vector-register lanes at n = 51 and, short of vector
-// registers on top, loaded 4 bytes per lane.  Here the table lives in the LANES of one register pair (lane i holds the
-// pointer of row i, fetched from the kernarg segment once) and every load takes its pointer with two v_readlane at a
-// static lane; the pair is made opaque at the top of every iteration so that the compiler does not hoist the 2 N scalar
-// values out of the loop again.  That leaves room for 8 bytes per lane and row at n = 51.
+// (Beyond ~28 rows the 2 N row pointers do not fit the scalar registers and the compiler parks them in the lanes of vector
+// registers — 158 such slots at n = 51 — re-reading them with v_readlane inside the loop; short of vector registers on
+// top, the kernel loads 4 bytes per lane there.  Measured alternative, round 6, removed: the table kept by hand in the
+// lanes of ONE register pair, two v_readlane per load at a static lane, no spilled SGPR, 4 or 8 bytes per lane: 1 157 /
+// 921 us against 638 us for this form at n = 51, d = 11.2 M (profiles/r06_n51_aksel_forms.txt) — every load then waits
+// for its own pair of v_readlane results instead of a batch the compiler schedules ahead.)
 template <int N, int VEC>
 __global__ __launch_bounds__(kColBlock) void aksel_pass1_kernel(RowTable rows, int64_t nvec,
                                                                 float* __restrict__ median_out,
                                                                 double* __restrict__ partial) {
-  constexpr bool kLanePointers = N > 28;
   __shared__ double red[kColBlock / 64];
-  uint32_t ptr_lo = 0, ptr_hi = 0;
-  if constexpr (kLanePointers) {
-    // (the row table is the first kernel argument: pointer i at byte 8 i of the kernarg segment)
-    const uint64_t* karg = reinterpret_cast<const uint64_t*>((uint64_t)__builtin_amdgcn_kernarg_segment_ptr());
-    const uint32_t lane = threadIdx.x & 63;
-    const uint64_t mine = karg[lane < (uint32_t)N ? lane : 0];
-    ptr_lo = (uint32_t)mine;
-    ptr_hi = (uint32_t)(mine >> 32);
-  }
-  auto row_pointer = [&](int i) -> const float* {
-    if constexpr (kLanePointers) {
-      const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)ptr_lo, i);
-      const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)ptr_hi, i);
-      return reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
-    } else {
-      return rows.p[i];
-    }
-  };
   float acc[N];
 #pragma unroll
   for (int i = 0; i < N; ++i) acc[i] = 0.0f;
-  // nvec * VEC * 4 < 2^32 (the host splits longer gradients): 32-bit byte offsets, saddr loads
-  const uint32_t nv = (uint32_t)nvec;
-  const uint32_t stride = gridDim.x * kColBlock;
-  for (uint32_t v = blockIdx.x * kColBlock + threadIdx.x; v < nv; v += stride) {
-    const uint32_t off = v * (uint32_t)(VEC * sizeof(float));
-    if constexpr (kLanePointers) asm volatile("" : "+v"(ptr_lo), "+v"(ptr_hi));  // (not loop-invariant for the compiler)
+  const int64_t stride = (int64_t)gridDim.x * kColBlock;
+  for (int64_t v = (int64_t)blockIdx.x * kColBlock + threadIdx.x; v < nvec; v += stride) {
     float x[VEC][N];
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       float t[VEC];
-      load_stream_off<VEC>(row_pointer(i), off, t);
+      load_stream<VEC>(rows.p[i] + v * VEC, t);
 #pragma unroll
       for (int c = 0; c < VEC; ++c) x[c][i] = t[c];
     }
@@ -301,7 +278,7 @@ __global__ __launch_bounds__(kColBlock) void aksel_pass1_kernel(RowTable rows, i
         acc[i] += df * df;  // (x - m).pow_(2).sum()
       }
     }
-    if (median_out != nullptr) store_stream_off<VEC>(median_out, off, med);
+    if (median_out != nullptr) store_stream<VEC>(median_out + v * VEC, med);
   }
 #pragma unroll
   for (int i = 0; i < N; ++i) {
@@ -341,7 +318,7 @@ static int launch_aksel_n(const float* const* rows_host, int64_t d, float* media
   RowTable tab{};
   for (int i = 0; i < N; ++i) tab.p[i] = rows_host[i];
   int vec = common_vec_width(reinterpret_cast<const void* const*>(rows_host), N, median_out);
-  constexpr int kMaxVec = (N <= 56) ? 2 : 1;  // (n = 64 at 8 bytes per lane would need 267 vector registers)
+  constexpr int kMaxVec = (N <= 28) ? 2 : 1;
   if (vec > kMaxVec) vec = kMaxVec;
   int nparts = 0;
   int64_t body = 0;
@@ -430,8 +407,7 @@ extern "C" int bm_aksel_pass1(const float* const* rows, int n, int64_t d, float*
                               double* sq_out, void* ws, void* stream) {
   using namespace bm;
   // d == 0 (an empty shard) is legal: no partials, the finish kernel writes zeros
-  // (32-bit byte offsets inside the kernel: rows of up to 2^30 coordinates, 4 GB each)
-  if (rows == nullptr || sq_out == nullptr || ws == nullptr || n < 1 || n > BM_MAX_ROWS || d < 0 || d >= ((int64_t)1 << 30))
+  if (rows == nullptr || sq_out == nullptr || ws == nullptr || n < 1 || n > BM_MAX_ROWS || d < 0)
     return BM_EINVAL;
   return dispatch_aksel(std::make_integer_sequence<int, BM_MAX_ROWS>{}, rows, n, d, median_out,
                         sq_out, static_cast<double*>(ws), static_cast<hipStream_t>(stream));

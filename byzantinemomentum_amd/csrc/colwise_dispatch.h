@@ -50,7 +50,9 @@ static int launch_colwise_n(const float* const* rows_host, int64_t d, int f, flo
   for (int i = 0; i < N; ++i) tab.p[i] = rows_host[i];
   // Register budget: N*VEC live values.  Keep it at or below ~112 so that >= 4 waves/SIMD fit.
   int vec = common_vec_width(reinterpret_cast<const void* const*>(rows_host), N, out);
-  constexpr int kMaxVec = (N <= 28) ? 4 : (N <= 56 ? 2 : 1);
+  // (phocas / meamed at n = 55, 56 with two columns per lane: the unrolled window instances exceed the unroller's budget)
+  constexpr bool kClosest = (OP == BM_OP_PHOCAS || OP == BM_OP_MEAMED);
+  constexpr int kMaxVec = (N <= 28) ? 4 : (N <= (kClosest ? 54 : 56) ? 2 : 1);
   if (vec > kMaxVec) vec = kMaxVec;
   if (vec == 4 && kMaxVec >= 4)
     return launch_colwise_vec < N, OP, (kMaxVec >= 4 ? 4 : 1) > (tab, d, f, out, stream);

@@ -454,15 +454,23 @@ __device__ __forceinline__ void gram_to_sqdist(const double* __restrict__ gram, 
 // G = sum over workgroups (fixed order); the workgroup that finishes LAST (arrival counter in the row-list area,
 // zeroed by the Gram kernel of the same call) then forms the squared distances and the gate's row list: one launch
 // instead of two (the second one was 5-7 us of a 76 us per-rank aggregation at 8 GPUs).  Which workgroup comes
-// last does not matter for the result: every entry of G is summed by one workgroup in a fixed order.
+// last does not matter for the result: every entry of G is summed in a fixed order.
+//
+// The grid is (entries / 64) x slices: a workgroup owns 64 consecutive entries of G (coalesced 512-byte reads) and ONE
+// slice of the partial blocks; its wave w adds the blocks lo + w, lo + w + 16, ... of the slice (independent loads in
+// flight), wave 0 adds the 16 wave sums in order, and the last workgroup adds the slice sums in slice order before it
+// goes on.  Rounds 4-5 ran this with one slice: 6 workgroups (n = 25) pulling 2 MB of partials through 6 CUs took most
+// of the launch's 21-25 us; with 8 slices 48 CUs share it.  (With one slice — short vectors — the order of the
+// additions is the round-5 one.)
 constexpr int kGramRedWaves = 16;  // 16 waves x 16 loads in flight: the sum is a latency chain over L2/HBM
+constexpr int kGramSlicesMax = 8;
 static_assert(64 * kGramRedWaves == kSqThreads, "the last workgroup of the reduction runs gram_to_sqdist");
 // rk.on (bm_pairwise_rank): that last workgroup also RANKS the rows when the gate listed nothing — 16 waves, one row
 // each, right where the distances were formed; when rows were listed the gated direct kernel, next on the stream,
 // ranks after it has corrected them (pairwise.hip).
 __global__ __launch_bounds__(64 * kGramRedWaves) void gram_reduce_sqdist_kernel(
     const double* __restrict__ partial, int nblocks, int n, double* __restrict__ gram, double tau,
-    double* __restrict__ sq, int* __restrict__ sub, int n_full, RankArgs rk) {
+    double* __restrict__ sq, int* __restrict__ sub, int n_full, RankArgs rk, double* __restrict__ slice_sums) {
   // dynamic LDS: the wave sums of the reduction, then (last workgroup, rk.on) the ranking's arrays in the same place
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double* lds = reinterpret_cast<double*>(smem);
@@ -471,11 +479,14 @@ __global__ __launch_bounds__(64 * kGramRedWaves) void gram_reduce_sqdist_kernel(
   __shared__ int last;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int per_block = n * (n + 1) / 2;
+  const int slices = (int)gridDim.y, slice = (int)blockIdx.y;
+  const int per_slice = (nblocks + slices - 1) / slices;
+  const int lo = slice * per_slice, hi = (lo + per_slice < nblocks) ? lo + per_slice : nblocks;
   const int e = blockIdx.x * 64 + lane;
   double s = 0.0;
   if (e < per_block) {
 #pragma unroll 16
-    for (int blk = wave; blk < nblocks; blk += kGramRedWaves) s += partial[(int64_t)blk * per_block + e];
+    for (int blk = lo + wave; blk < hi; blk += kGramRedWaves) s += partial[(int64_t)blk * per_block + e];
   }
   wsum[wave][lane] = s;
   __syncthreads();
@@ -483,10 +494,21 @@ __global__ __launch_bounds__(64 * kGramRedWaves) void gram_reduce_sqdist_kernel(
     double tot = wsum[0][lane];
 #pragma unroll
     for (int w = 1; w < kGramRedWaves; ++w) tot += wsum[w][lane];
-    gram[e] = tot;
+    if (slices == 1)
+      gram[e] = tot;
+    else
+      slice_sums[(int64_t)slice * per_block + e] = tot;
   }
-  // arrival: release this workgroup's entries of G, take a ticket; the last ticket acquires everybody's
-  if (!arrive_last(sub + kArrivalSlot, (int)gridDim.x, &last)) return;
+  // arrival: release this workgroup's sums, take a ticket; the last ticket acquires everybody's
+  if (!arrive_last(sub + kArrivalSlot, (int)(gridDim.x * gridDim.y), &last)) return;
+  if (slices > 1) {
+    for (int q = threadIdx.x; q < per_block; q += 64 * kGramRedWaves) {
+      double tot = slice_sums[q];
+      for (int sl = 1; sl < slices; ++sl) tot += slice_sums[(int64_t)sl * per_block + q];
+      gram[q] = tot;
+    }
+    __syncthreads();  // (this workgroup's own stores, read back below)
+  }
   gram_to_sqdist(gram, n, tau, sq, sub, listed, n_full, rk.on ? lds : nullptr);  // (the wave sums are done with)
   if (threadIdx.x == 0) {
     sub[kArrivalSlot] = 0;
@@ -498,6 +520,8 @@ __global__ __launch_bounds__(64 * kGramRedWaves) void gram_reduce_sqdist_kernel(
     if (last == 0) krum_rank_from_distances(lds, n_full, rk.f, rk.m, rk.mode, rk.order, rk.scores, rk.bitonic != 0);
   }
 }
+
+constexpr int kB3MaxBlocks = 1024;  // partial blocks the workspace holds (gram3_partial_doubles); the slice sums sit behind the used ones
 
 // Fixed-order sum of the per-workgroup partial Gram matrices (n rows), then the squared distances of the n_full >= n
 // rows of the stack (rows n-1 .. n_full-1 alias the last row of G) + accuracy flag.
@@ -515,8 +539,15 @@ int gram_finish(const double* partial, int blocks, int n, int n_full, double* gr
   if (const int rc = lds_opt_in(reinterpret_cast<const void*>(gram_reduce_sqdist_kernel), (size_t)lds_bytes,
                                 (BM_MAX_ROWS + 1) * sizeof(int)))
     return rc;
-  hipLaunchKernelGGL(gram_reduce_sqdist_kernel, dim3((int)((per_block + 63) / 64)), dim3(64 * kGramRedWaves), lds_bytes, s,
-                     partial, blocks, n, gram, tau, sq_nxn, sub, n_full, rk);
+  const int chunks = (int)((per_block + 63) / 64);
+  // ~48-64 workgroups in all, at least 32 partial blocks per slice, and room for the slice sums behind the partials
+  int slices = 64 / chunks;
+  if (slices > kGramSlicesMax) slices = kGramSlicesMax;
+  if (slices > blocks / 32) slices = blocks / 32;
+  if (slices < 1 || blocks + slices > kB3MaxBlocks) slices = 1;
+  double* slice_sums = const_cast<double*>(partial) + (int64_t)blocks * per_block;
+  hipLaunchKernelGGL(gram_reduce_sqdist_kernel, dim3(chunks, slices), dim3(64 * kGramRedWaves), lds_bytes, s,
+                     partial, blocks, n, gram, tau, sq_nxn, sub, n_full, rk, slice_sums);
   BM_LAUNCH_CHECK();
   return 0;
 }
@@ -543,8 +574,6 @@ static int launch_gram3(const RowTable& tab, int n, int64_t d, bool aligned, int
   return planes == 2 ? launch_gram3_planes<K, 2>(tab, n, d, aligned, centre, partial, arrival, blocks, s)
                      : launch_gram3_planes<K, 3>(tab, n, d, aligned, centre, partial, arrival, blocks, s);
 }
-
-constexpr int kB3MaxBlocks = 1024;
 
 int64_t gram3_partial_doubles(int n) { return (int64_t)kB3MaxBlocks * ((int64_t)n * (n + 1) / 2); }
 

@@ -129,10 +129,11 @@ class AggregationStep:
     return getattr(agg, self.gar)(gradients, f, **self.gar_args)
 
   def _fetch(self, matrix):
-    """A small device matrix on the host, through a PINNED buffer this step keeps (one asynchronous copy + one stream
-    synchronisation).  `.cpu()` into pageable memory goes through the runtime's staging path, whose cost on the pool's
-    boxes is bimodal — 0.05 ms or several ms for 15 KB, per process (bench.py: attack_search legs) — and this copy
-    sits on the critical path of every factor search."""
+    """A small device matrix on the host, through a pinned buffer this step keeps (one asynchronous copy + one stream
+    synchronisation, no allocation per search).  Measured next to `.cpu()` into pageable memory: 0.019 against 0.017 ms
+    for the 15 KB of a C3 search (bench.py, `attack_search_c3_krum.legs`) — the copy is not where a slow search loses
+    its time (that was a stalled host, profiles/r06_search_each.txt); the buffer only keeps the path free of the
+    runtime's staging allocations."""
     if not matrix.is_cuda:
       return matrix.contiguous()
     key = (tuple(matrix.shape), matrix.dtype)

@@ -67,6 +67,25 @@ case $name in
     ( time timeout 1800 python -m pytest tests -m gpu -x -q ) > $out/pytest_gpu.log 2>&1; tail -4 $out/pytest_gpu.log
     timeout 600 python bench.py > $out/bench_1.json 2> $out/bench_1.err; wc -c $out/bench_1.json
     ;;
+  round4)   # Aksel forms A/B at n = 51, the whole suite, the bench
+    for lanes in 0 1 2 0 1 2; do echo "BM_AKSEL_LANES=$lanes"; BM_AKSEL_LANES=$lanes timeout 300 python scripts/n51_probe.py 2>&1 | grep -v amdgpu.ids; done > $out/n51_probe_aksel_forms.txt; grep "LANES\|aksel" $out/n51_probe_aksel_forms.txt
+    ( time timeout 1800 python -m pytest tests -m gpu -x -q ) > $out/pytest_gpu.log 2>&1; tail -4 $out/pytest_gpu.log
+    timeout 600 python bench.py > $out/bench_1.json 2> $out/bench_1.err; wc -c $out/bench_1.json
+    ;;
+  round5)   # the sliced Gram reduction: suite, kernel traces of C4 / C3, the per-rank probe, bench twice, then the round-5 failing pair N times
+    ( time timeout 1800 python -m pytest tests -m gpu -x -q ) > $out/pytest_gpu.log 2>&1; tail -4 $out/pytest_gpu.log
+    for w in bulyan krum; do
+      rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$w -o trace -- python bench.py --workload $w --steps 20 --warmup 3 --no-extras --no-cpu-baseline --no-traffic > $out/trace_$w.json 2> $out/trace_$w.err
+      f=$(ls $out/trace_$w/*/*kernel_stats.csv $out/trace_$w/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $out/${w}_kernel_stats.csv && head -8 $out/${w}_kernel_stats.csv | cut -c1-160
+      find $out/trace_$w -name "*kernel_trace.csv" -size +20M -delete
+    done
+    timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29531 scripts/per_rank_probe.py > $out/per_rank_probe.txt 2>&1; tail -12 $out/per_rank_probe.txt
+    for i in 1 2; do timeout 600 python bench.py > $out/bench_$i.json 2> $out/bench_$i.err; wc -c $out/bench_$i.json; done
+    for i in $(seq 1 ${PAIR_RUNS:-8}); do
+      BM_TEST_POISON=0 timeout 500 python -m pytest tests/test_gpu_full_size_o1.py tests/test_gpu_zz_multirank.py -m gpu -q > $out/pair_$i.log 2>&1
+      tail -1 $out/pair_$i.log
+    done
+    ;;
   pair)   # the failing pair of files as the suite runs them, N times
     for i in $(seq 1 ${PAIR_RUNS:-3}); do
       BM_TEST_POISON=0 timeout 500 python -m pytest tests/test_gpu_full_size_o1.py tests/test_gpu_zz_multirank.py -m gpu -q > $out/pair_$i.log 2>&1

@@ -3,9 +3,11 @@
 torch.distributed form of the same rules, the packed statistics exchange, all_to_all_single with real splits, and a
 full step.  SURVEY.md section 8e; BASELINE.json configs[3], configs[4].
 
-`gpurun` and the driver's test box hand out ONE GPU, so this file is SKIPPED there (and has never run: the code below
-repeats, call for call, what tests/test_gpu_zz_multirank.py and test_rccl_path_on_one_gpu do on one device, where they
-pass); it is the vehicle for a node with several GPUs.  It sorts last among the GPU tests on purpose.
+`gpurun` and the driver's test box hand out ONE GPU, so the cases with 2 and 4 ranks are SKIPPED there; they are the
+vehicle for a node with several GPUs.  The rank body itself does run on every box: the first case is the SAME function
+with world = 1 — a one-rank RCCL group with forced collectives (every all-reduce, all-gather and all-to-all goes through
+RCCL, alone) — so that on the day a multi-GPU node appears only `nranks` changes.  It sorts late among the GPU tests on
+purpose.
 """
 
 import math
@@ -64,8 +66,9 @@ def _rank_body(rank, world, rendezvous, d, queue):
 
     lo, hi = shard_bounds(d, world, rank)
     report = {"shard": (lo, hi)}
-    native = ShardedAggregator()                      # libbm_gar's own RCCL communicator: one C call per rule
-    plain = ShardedAggregator(native_comm=False)      # the same rules through torch.distributed
+    forced = dict(force_collectives=True) if world == 1 else {}   # (one rank: the collectives are issued all the same)
+    native = ShardedAggregator(**forced)                      # libbm_gar's own RCCL communicator: one C call per rule
+    plain = ShardedAggregator(native_comm=False, **forced)    # the same rules through torch.distributed
     assert native.world_size == world and native.collective and plain.native is None and not plain.single_call
     report["native_comm"] = native.native is not None
     rows, h = O.make_stack("hetero", N, F, d, seed=1234)
@@ -144,7 +147,7 @@ def _visible_gpus():
 
 
 @pytest.mark.timeout(900)
-@pytest.mark.parametrize("world,d", [(2, 200003), (4, 1 << 20)])
+@pytest.mark.parametrize("world,d", [(1, 40007), (2, 200003), (4, 1 << 20)])
 def test_rccl_ranks_on_separate_gpus(world, d):
   if _visible_gpus() < world:
     pytest.skip(f"{world} GPUs needed, {_visible_gpus()} visible (gpurun boxes have one)")
