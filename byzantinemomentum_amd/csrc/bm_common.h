@@ -258,12 +258,12 @@ __device__ __forceinline__ bool arrive_last(int* counter, int total, int* lds_fl
 }
 
 // One entry of a small index table that the PREVIOUS kernel on the stream wrote (the ranking, the selected rows), read
-// coherently at agent scope (`global_load_dword ... sc1`: the load cannot be served from a stale line of this XCD's L2
-// or of the scalar cache).  Kernel boundaries make such tables visible by themselves — in one process per GPU no read
-// of one has ever been seen stale — but with five processes time-sharing one MI355X (tests/test_gpu_zz_multirank.py) a
-// second-pass kernel that fetched the ranking with SCALAR loads computed 11 % of its workgroups (one XCD's worth) from
-// the ranking of the call before, in 4 of 11 runs: right ranking in memory, right result on the next launch.  The
-// tables are 72-256 bytes per launch: reading them the careful way costs nothing.
+// at agent scope (`global_load_dword ... sc1`) by a vector lane instead of through the scalar cache.  Kernel boundaries
+// make such tables visible by themselves; this form dates from round 5, when wrong coordinates out of Bulyan's second
+// pass under GPU sharing were taken for a stale read of the ranking.  They were not (round 6: a library-free probe finds
+// no stale word across kernel boundaries under sharing, and the failures followed the packed-fp32 instructions of that
+// kernel — build.py).  The loads stay as they are: 72-256 bytes per launch, and one vector load + v_readlane
+// per entry keeps the scalar registers free for the row pointers.
 __device__ __forceinline__ int32_t load_index_coherent(const int32_t* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }

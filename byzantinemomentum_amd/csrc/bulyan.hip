@@ -43,8 +43,7 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(
   if constexpr (MMAX <= 25) {
     typedef const float* __attribute__((address_space(4))) const* KargTable;
     const KargTable karg = (KargTable)__builtin_amdgcn_kernarg_segment_ptr();
-    // (the ranking: ONE coherent load per wave — lane t fetches order[t] — then a v_readlane per pointer; scalar loads
-    //  of `order` go through the scalar cache, see load_index_coherent)
+    // (the ranking: ONE vector load per wave — lane t fetches order[t] — then a v_readlane per pointer, see load_index_coherent)
     const int mine = (int)(threadIdx.x & 63) < MMAX ? load_index_coherent(order + (threadIdx.x & 63)) : 0;
 #pragma unroll
     for (int t = 0; t < MMAX; ++t) ranked[t] = (const float*)karg[__builtin_amdgcn_readlane(mine, t)];

@@ -3,9 +3,7 @@ environment knob of the library — which reads its knobs once per process — f
 
     for v in 0 1 0 1; do BM_BULYAN_SHORT=$v python scripts/bulyan_pass2_probe.py; done
 
-(knobs of this kernel: BM_BULYAN_SHORT, the window search; BM_SECOND_PASS_REVERSE, where the walk starts — for the
-latter use scripts/second_pass_walk_probe.py, which runs the distance pass before it: the walk only matters through what
-that pass leaves in the Infinity Cache).  The checksums of the runs must agree to the last digit."""
+(knob of this kernel: BM_BULYAN_SHORT, the window search).  The checksums of the runs must agree to the last digit."""
 import os
 import sys
 

@@ -86,11 +86,23 @@ case $name in
       tail -1 $out/pair_$i.log
     done
     ;;
+  census)   # every rule of the library under GPU sharing, three launches each on unchanged rows (scripts/stale_read_hunt.py)
+    timeout 1500 python scripts/stale_read_hunt.py --procs 4 --iters ${HUNT_ITERS:-250} --hold-gb 0 --kinds gram,mean,pass2,median,trmean,phocas,meamed,aksel,cge,brute,krum,bulyan,stats > $out/census.jsonl 2> $out/census.err
+    tail -1 $out/census.jsonl | cut -c1-2500
+    ;;
   pair)   # the failing pair of files as the suite runs them, N times
     for i in $(seq 1 ${PAIR_RUNS:-3}); do
       BM_TEST_POISON=0 timeout 500 python -m pytest tests/test_gpu_full_size_o1.py tests/test_gpu_zz_multirank.py -m gpu -q > $out/pair_$i.log 2>&1
       tail -2 $out/pair_$i.log
     done
+    ;;
+  final)  # the end of a round: suite with -x, smoke, bench as the driver runs it, a kernel trace of the headline alone
+    ( time timeout 1800 python -m pytest tests -m gpu -x -q ) > $out/pytest_gpu.log 2>&1; tail -4 $out/pytest_gpu.log
+    timeout 200 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -1 $out/smoke.log
+    timeout 600 python bench.py > $out/bench_default.json 2> $out/bench_default.err; wc -c $out/bench_default.json
+    rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_headline -o trace -- python bench.py --no-extras --no-cpu-baseline --no-traffic --steps 20 > $out/trace_headline.json 2> $out/trace_headline.err
+    f=$(find $out/trace_headline -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/headline_kernel_stats.csv && head -6 $out/headline_kernel_stats.csv | cut -c1-200
+    find $out/trace_headline -name "*kernel_trace.csv" -size +20M -delete
     ;;
   suite)  # what the driver runs at the end of a round
     ( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $out/pytest_gpu.log 2>&1; tail -4 $out/pytest_gpu.log

@@ -134,6 +134,14 @@ def child(args):
         return gars.selected_mean(rows, korder, m)
       if kind == "pass2":
         return gars.bulyan_pass2(rows, order, F, m)
+      if kind in ("trmean", "phocas", "meamed"):
+        return getattr(bm, kind)(rows, F)
+      if kind in ("aksel", "cge", "brute", "krum", "bulyan"):   # whole rules, distance pass and ranking included
+        gars.invalidate_rank_cache()
+        return getattr(bm, kind)(rows, F)
+      if kind == "stats":
+        avg, norm, dev_, mx = bm.compute_avg_dev_max(rows[:h])
+        return torch.cat([avg, torch.tensor([norm, dev_, mx], device=dev)])
       return bm.median(rows)
     for q in range(len(kinds)):
       kind = kinds[(q + it) % len(kinds)]

@@ -103,3 +103,55 @@ def test_closest_to_centre_window_of_phocas_and_meamed_is_a_valid_topk(n, f):
         assert 0 <= s <= f and inside.size == m
         if outside.size:
           assert inside.max() <= outside.min(), (n, f, c, x, s)
+
+
+# ---------------------------------------------------------------------------- #
+# phocas / meamed (aggregators/trmean.py:35-50): the n - f values closest to the centre, as csrc/colwise_kernels.h
+# (closest_sum_static) sums them on registers with static indices.
+
+def _closest_forms(x, f, c):
+  """(window start, fp32 sum walking from s — the form of rounds 2-5 —, fp32 sum of the static-index form) of a sorted column."""
+  n = len(x)
+  m = n - f
+  s = 0
+  for t in range(f):
+    if abs(np.float32(x[t] - c)) > abs(np.float32(x[t + m] - c)):
+      s = t + 1
+  walk = np.float32(0.0)
+  for i in range(m):
+    walk = np.float32(walk + x[s + i])
+  static = np.float32(0.0)
+  for i in range(n):
+    if i < f:
+      static = np.float32(static + (x[i] if i >= s else np.float32(0.0)))
+    elif i >= m:
+      static = np.float32(static + (x[i] if i < s + m else np.float32(0.0)))
+    else:
+      static = np.float32(static + x[i])
+  return s, walk, static
+
+
+@pytest.mark.parametrize("n,f", [(3, 1), (7, 1), (11, 2), (11, 5), (25, 5), (25, 11), (25, 12), (51, 12), (51, 25), (64, 31), (9, 0)])
+def test_closest_to_centre_sum_on_static_indices_has_the_bits_of_the_walk(n, f):
+  """The ranks f .. n-f-1 lie in every possible window [s, s + n - f), 0 <= s <= f, and are added unconditionally; the 2f
+  ranks at the ends are added as `x or +0`.  Same bits as walking the window from s — on random columns, columns with
+  ties and repeated values, negative zeros, infinities (NaN replaced by +inf sorts last), and for every centre the
+  two rules use (the median, the trimmed mean)."""
+  rng = np.random.default_rng(n * 100 + f)
+  for trial in range(400):
+    x = rng.standard_normal(n).astype(np.float32)
+    kind = trial % 5
+    if kind == 1:
+      x = np.round(x)                      # many ties
+    elif kind == 2:
+      x[rng.integers(0, n, size=max(1, n // 4))] = np.float32(np.inf)
+    elif kind == 3:
+      x[:] = x[0]                          # one value
+    elif kind == 4:
+      x[rng.integers(0, n)] = np.float32(-0.0)
+    x = np.sort(x)
+    for c in (x[(n - 1) // 2], np.float32(x[f:n - f].astype(np.float64).mean()) if n - 2 * f > 0 else x[0]):
+      with np.errstate(invalid="ignore"):  # (inf - inf: the comparison is then false, as on the device)
+        s, walk, static = _closest_forms(x, f, np.float32(c))
+      assert 0 <= s <= f
+      assert walk.tobytes() == static.tobytes() or (np.isnan(walk) and np.isnan(static)), (n, f, trial, s, walk, static)
