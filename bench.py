@@ -176,10 +176,18 @@ def entry(ms, nbytes, gpus=1, units=1, **more):
 
 
 def timed_loop(fn, steps, warmup, timer, name):
+  """`steps` timed calls of fn(i) behind `warmup` untimed ones.  The ranking cache of the host mirror (gars.py: `influence`
+  right after `aggregate` reuses the ranking, attack.py:821-822) is emptied before EVERY call: with an odd warm-up the
+  first timed call of a two-stack rotation met the stack of the last warm-up call, skipped its distance pass and pulled
+  the mean of a dozen calls 4 % down (Krum, Bulyan, Brute, Aksel entries of rounds 2-5; found in round 6 when the
+  per-call medians came out ABOVE the means)."""
+  from byzantinemomentum_amd import gars
   for i in range(warmup):
+    gars.invalidate_rank_cache()
     fn(i)
   torch.cuda.synchronize()
   for i in range(steps):
+    gars.invalidate_rank_cache()
     timer.run(name, lambda: fn(i))
   torch.cuda.synchronize()
   return timer.mean_ms(name)
@@ -688,6 +696,7 @@ def main():
 
     def step(i, timed):
       st = stacks[i & 1]
+      bm.gars.invalidate_rank_cache()  # (every call runs its distance pass: see timed_loop)
       if timed:
         timer.run(workload, lambda: rule(st, f))
       else:

@@ -386,11 +386,15 @@ class AggregationStep:
     if pend["prev_s2"] is not None:
       sums.append(pend["prev_s2"])
     # ONE copy to the host, ONE synchronisation: sums and maxima leave the device together (two `tolist()` were two
-    # copies with a host round trip between them: ~30 us of a 0.95 ms step, profiles/r05_c_full_kernel_trace.csv)
+    # copies with a host round trip between them: ~30 us of a 0.95 ms step, profiles/r05_c_full_kernel_trace.csv), and
+    # the whole tensors travel — three or four of them in one concatenation — to be taken apart on the host (eight
+    # slices were two batched-copy launches)
     if not self.agg.collective:
-      ns = sum(int(t.numel()) for t in sums)
-      flat = torch.cat(sums + maxes).tolist()
-      return flat[:ns], flat[ns:]
+      parts = [pend["s"], pend["h"], st] + ([pend["prev_s2"]] if pend["prev_s2"] is not None else [])
+      flat = torch.cat(parts).tolist()
+      s3, h3, stl = flat[0:3], flat[3:6], flat[6:6 + int(st.numel())]
+      host_sums = s3[:2] + h3[:2] + stl[:20] + stl[22:23] + (flat[6 + int(st.numel()):] if pend["prev_s2"] is not None else [])
+      return host_sums, s3[2:] + h3[2:] + stl[20:22]
     sums, maxes = self.agg.exchange(torch.cat(sums), torch.cat(maxes))
     ns = int(sums.numel())
     flat = torch.cat([sums, maxes]).tolist()
