@@ -90,6 +90,12 @@ case $name in
     timeout 1500 python scripts/stale_read_hunt.py --procs 4 --iters ${HUNT_ITERS:-250} --hold-gb 0 --kinds gram,mean,pass2,median,trmean,phocas,meamed,aksel,cge,brute,krum,bulyan,stats > $out/census.jsonl 2> $out/census.err
     tail -1 $out/census.jsonl | cut -c1-2500
     ;;
+  updatestep)   # where a step with the momentum at the update spends its time (kernel trace)
+    timeout 300 python scripts/step_update_probe.py > $out/wall.txt 2>&1; cat $out/wall.txt | grep -v amdgpu
+    rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o trace -- python scripts/step_update_probe.py > $out/traced.txt 2>&1
+    f=$(find $out/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/kernel_stats.csv && head -14 $out/kernel_stats.csv | cut -c1-150
+    find $out/trace -name "*kernel_trace.csv" -size +20M -delete
+    ;;
   pair)   # the failing pair of files as the suite runs them, N times
     for i in $(seq 1 ${PAIR_RUNS:-3}); do
       BM_TEST_POISON=0 timeout 500 python -m pytest tests/test_gpu_full_size_o1.py tests/test_gpu_zz_multirank.py -m gpu -q > $out/pair_$i.log 2>&1
