@@ -24,7 +24,7 @@ case $name in
     tail -1 $out/hunt_no_parent.jsonl | cut -c1-1500
     ;;
   variants)   # which property of the pass-2 kernel matters: scripts/probes/pass2_variants/build.sh, then the hunt per library
-    for lib in default ${VARIANTS:-noslp fminmax plainload vec2 ldsptr}; do
+    for lib in ${VARIANTS:-default noslp fminmax plainload vec2 ldsptr}; do
       arg=""; [ $lib != default ] && arg="--lib scratch/pass2_variants/libbm_gar_$lib.so"
       timeout 600 python scripts/stale_read_hunt.py --procs 4 --iters ${HUNT_ITERS:-400} --hold-gb 0 --kinds pass2 $arg > $out/hunt_$lib.jsonl 2> $out/hunt_$lib.err
       tail -1 $out/hunt_$lib.jsonl | cut -c1-600
@@ -95,6 +95,13 @@ case $name in
     rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -o trace -- python scripts/step_update_probe.py > $out/traced.txt 2>&1
     f=$(find $out/trace -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/kernel_stats.csv && head -14 $out/kernel_stats.csv | cut -c1-150
     find $out/trace -name "*kernel_trace.csv" -size +20M -delete
+    ;;
+  slppair)   # the two-build reproducer attempt (scripts/probes/slp_pair_probe): alone, then five processes
+    P=scripts/probes/slp_pair_probe/slp_pair_probe
+    [ -x $P ] || scripts/probes/slp_pair_probe/build.sh
+    timeout 200 $P 3000 > $out/alone.txt 2>&1; head -3 $out/alone.txt | cut -c1-300
+    for i in 1 2 3 4 5; do timeout 600 $P ${SLP_ITERS:-6000} > $out/five_$i.txt 2>&1 & done; wait
+    head -4 $out/five_*.txt | cut -c1-300
     ;;
   pair)   # the failing pair of files as the suite runs them, N times
     for i in $(seq 1 ${PAIR_RUNS:-3}); do

@@ -42,7 +42,51 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 constexpr int R = 18, PAIRS = 7, LOGCAP = 1024;
 struct Table { const float* p[R]; };
 struct Entry { uint32_t it, form, v, lane, c, pair, half, got, want, xcc; };
-struct Log { unsigned int count, wrong[2]; Entry e[LOGCAP]; };
+struct Log { unsigned int count, wrong[3]; Entry e[LOGCAP]; };
+
+// FORM 2 — what the narrowing of round 6 points at (profiles/r06_pass2_narrowing.txt: the failures follow the packed
+// ADDITIONS of the suffix sums, `v_pk_add_f32 d, d, v[a:a+1] op_sel_hi:[1,0]`, whose source pair is (component 0,
+// component 1) of a loaded 16-byte group while only component 0 is used — and every wrong coordinate was a component 1):
+// the source pair is the loaded pair itself, its HIGH half is live data, and after the chains of component 0 the high
+// halves are compared with copies taken before.  A difference means the instruction (or a wave switched out around
+// it) damaged a register it only names.
+__global__ __launch_bounds__(256) void pk_live_kernel(Table rows, uint32_t nvec, uint32_t it, Log* log, float* sink) {
+  const uint32_t v = blockIdx.x * 256 + threadIdx.x;
+  if (v >= nvec) return;
+  f4 x[R];
+#pragma unroll
+  for (int t = 0; t < R; ++t) x[t] = __builtin_nontemporal_load(reinterpret_cast<const f4*>(rows.p[t]) + v);
+  float kept[R];
+#pragma unroll
+  for (int t = 0; t < R; ++t) asm volatile("v_mov_b32 %0, %1" : "=v"(kept[t]) : "v"(x[t][1]));
+  float keep = 0.0f;
+#pragma unroll
+  for (int q = 0; q < PAIRS; ++q) {
+    const int i = 2 * q;
+    f2 acc = {x[i][0], 0.0f};
+#pragma unroll
+    for (int t = i + 1; t < R; ++t) {
+      f2 src = __builtin_shufflevector(x[t], x[t], 0, 1);  // (component 0, component 1): the registers of the load
+      asm volatile("v_pk_add_f32 %0, %0, %1 op_sel_hi:[1,0]" : "+v"(acc), "+v"(src));
+      x[t][0] = src[0];
+      x[t][1] = src[1];
+    }
+    keep += acc.x + acc.y;
+  }
+#pragma unroll
+  for (int t = 0; t < R; ++t) {
+    float now = x[t][1];
+    asm volatile("" : "+v"(now));
+    if (__float_as_uint(now) != __float_as_uint(kept[t])) {
+      atomicAdd(&log->wrong[2], 1u);
+      const unsigned int slot = atomicAdd(&log->count, 1u);
+      if (slot < LOGCAP)
+        log->e[slot] = Entry{it, 2u, v, threadIdx.x & 63, 1u, (uint32_t)t, 1u, __float_as_uint(now), __float_as_uint(kept[t]),
+                             (uint32_t)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11))};
+    }
+  }
+  if (keep == 12345.678f) sink[0] = keep;
+}
 
 template <int FORM>
 __global__ __launch_bounds__(256) void pk_kernel(Table rows, uint32_t nvec, uint32_t it, Log* log, float* sink) {
@@ -108,6 +152,7 @@ int main(int argc, char** argv) {
   for (uint32_t it = 0; it < iters; ++it) {
     hipLaunchKernelGGL(pk_kernel<0>, dim3(grid), dim3(256), 0, 0, tab, nvec, it, log, sink);
     hipLaunchKernelGGL(pk_kernel<1>, dim3(grid), dim3(256), 0, 0, tab, nvec, it, log, sink);
+    hipLaunchKernelGGL(pk_live_kernel, dim3(grid), dim3(256), 0, 0, tab, nvec, it, log, sink);
     if (it % 5 == 0) {  // a host round trip now and then, like the callers of the library
       unsigned int seen;
       CHECK(hipMemcpy(&seen, &log->count, 4, hipMemcpyDeviceToHost));
@@ -117,8 +162,8 @@ int main(int argc, char** argv) {
   std::vector<char> raw(sizeof(Log));
   CHECK(hipMemcpy(raw.data(), log, sizeof(Log), hipMemcpyDeviceToHost));
   const Log* l = reinterpret_cast<const Log*>(raw.data());
-  printf("{\"pid\": %d, \"launches_per_form\": %u, \"d\": %u, \"wrong_results\": {\"op_sel_hi_broadcast\": %u, \"plain_pairs\": %u}}\n",
-         (int)getpid(), iters, d, l->wrong[0], l->wrong[1]);
+  printf("{\"pid\": %d, \"launches_per_form\": %u, \"d\": %u, \"wrong_results\": {\"op_sel_hi_broadcast\": %u, \"plain_pairs\": %u, "
+         "\"live_high_half_of_the_source_pair\": %u}}\n", (int)getpid(), iters, d, l->wrong[0], l->wrong[1], l->wrong[2]);
   for (unsigned int i = 0; i < (l->count < 64 ? l->count : 64); ++i) {
     const Entry& e = l->e[i];
     printf("  launch %u form %u group %u lane %u component %u pair %u half %u got %08x want %08x xcc %u\n", e.it, e.form, e.v, e.lane,
