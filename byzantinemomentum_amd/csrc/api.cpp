@@ -23,7 +23,7 @@ Tuning& tuning_mutable() {
                            env_int("BM_PAIR_PLANES", 0), env_int("BM_PAIR_DITHER", 0), env_double("BM_PAIR_TAU", 2e-3),
                            env_int("BM_STUDY_BURST", 8), env_int("BM_STEP_STAGGER_US", 0),
                            env_int("BM_GRAM_STEADY", 1), env_int("BM_BULYAN_SHORT", 1),
-                           env_int("BM_PAIR_LOAD_NT", 1), env_int("BM_RANK_ALGO", 0), env_int("BM_BRUTE_BUDGET", 0)};
+                           env_int("BM_PAIR_LOAD_NT", 1), env_int("BM_RANK_ALGO", 0), env_int("BM_COL_WIDE", 1), env_int("BM_BRUTE_BUDGET", 0)};
   return t;
 }
 const Tuning& tuning() { return tuning_mutable(); }
@@ -43,7 +43,7 @@ extern "C" int bm_tuning_set(const char* name, int value) {
       {"BM_PAIR_DITHER", &t.pair_dither}, {"BM_STUDY_BURST", &t.study_burst},
       {"BM_STEP_STAGGER_US", &t.step_stagger_us}, {"BM_GRAM_STEADY", &t.gram_steady},
       {"BM_BULYAN_SHORT", &t.bulyan_short}, {"BM_PAIR_LOAD_NT", &t.pair_load_nt},
-      {"BM_RANK_ALGO", &t.rank_algo}, {"BM_BRUTE_BUDGET", &t.brute_budget}};
+      {"BM_RANK_ALGO", &t.rank_algo}, {"BM_COL_WIDE", &t.col_wide}, {"BM_BRUTE_BUDGET", &t.brute_budget}};
   for (const auto& k : knobs)
     if (strcmp(name, k.key) == 0) {
       *k.slot = value;

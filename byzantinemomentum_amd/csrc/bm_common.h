@@ -305,6 +305,7 @@ struct Tuning {
   int bulyan_short;    // BM_BULYAN_SHORT: 1 (default) = Bulyan pass 2 searches its window among the positions that straddle the median only (same bits), 0 = all positions (A/B)
   int pair_load_nt;    // BM_PAIR_LOAD_NT: 1 (default) = the Gram kernel's row loads carry the non-temporal hint, 0 = default cache policy (aligned rows; A/B)
   int rank_algo;       // BM_RANK_ALGO: how the rows' distances are put in order for the scores (rank_body.h): 0 (default) = counting up to 32 rows, a bitonic network per row beyond; 1 = bitonic, 2 = counting (A/B; same scores)
+  int col_wide;        // BM_COL_WIDE: 1 (default) = median / trimmed mean at 29-52 rows take 16-byte columns, 0 = 8-byte ones (A/B)
   int brute_budget;    // BM_BRUTE_BUDGET: search-tree nodes per wave of the device Brute search before it gives up with status -2 (default 0 = 2^18; tests set a tiny one)
 };
 const Tuning& tuning();

@@ -317,8 +317,9 @@ static int launch_aksel_n(const float* const* rows_host, int64_t d, float* media
   RowTable tab{};
   for (int i = 0; i < N; ++i) tab.p[i] = rows_host[i];
   int vec = common_vec_width(reinterpret_cast<const void* const*>(rows_host), N, median_out);
-  constexpr int kMaxVec = (N <= 28) ? 2 : 1;
+  constexpr int kMaxVec = (N <= 52) ? 2 : 1;
   if (vec > kMaxVec) vec = kMaxVec;
+  if (vec == 2 && N > 28 && tuning().col_wide == 0) vec = 1;  // (BM_COL_WIDE: 8 against 4 bytes per lane beyond 28 rows, A/B)
   int nparts = 0;
   int64_t body = 0;
   if (vec == 2 && kMaxVec >= 2 && d / 2 > 0) {

@@ -50,13 +50,17 @@ static int launch_colwise_n(const float* const* rows_host, int64_t d, int f, flo
   for (int i = 0; i < N; ++i) tab.p[i] = rows_host[i];
   // Register budget: N*VEC live values.  Keep it at or below ~112 so that >= 4 waves/SIMD fit.
   int vec = common_vec_width(reinterpret_cast<const void* const*>(rows_host), N, out);
-  // (phocas / meamed at n = 55, 56 with two columns per lane: the unrolled window instances exceed the unroller's budget)
+  // (phocas / meamed at n = 55, 56 with two columns per lane, and beyond 28 rows with four: the unrolled window instances
+  //  exceed the unroller's budget and the column arrays land in scratch)
   constexpr bool kClosest = (OP == BM_OP_PHOCAS || OP == BM_OP_MEAMED);
-  constexpr int kMaxVec = (N <= 28) ? 4 : (N <= (kClosest ? 54 : 56) ? 2 : 1);
+  constexpr int kMaxVec = (N <= 28) ? 4 : ((!kClosest && N <= 52) ? 4 : (N <= (kClosest ? 54 : 56) ? 2 : 1));
   if (vec > kMaxVec) vec = kMaxVec;
+  // 29-52 rows, median / trimmed mean: 16-byte columns (2 waves per SIMD at ~210-240 VGPRs) against 8-byte ones (3 waves
+  // at ~165): BM_COL_WIDE (default 1) — measured at n = 51, profiles/r06_n51_wide_columns.txt
+  if (vec == 4 && N > 28 && tuning().col_wide == 0) vec = 2;
   if (vec == 4 && kMaxVec >= 4)
     return launch_colwise_vec < N, OP, (kMaxVec >= 4 ? 4 : 1) > (tab, d, f, out, stream);
-  if (vec == 2 && kMaxVec >= 2)
+  if (vec >= 2 && kMaxVec >= 2)
     return launch_colwise_vec < N, OP, (kMaxVec >= 2 ? 2 : 1) > (tab, d, f, out, stream);
   return launch_colwise_vec<N, OP, 1>(tab, d, f, out, stream);
 }

@@ -103,6 +103,10 @@ case $name in
     for i in 1 2 3 4 5; do timeout 600 $P ${SLP_ITERS:-6000} > $out/five_$i.txt 2>&1 & done; wait
     head -4 $out/five_*.txt | cut -c1-300
     ;;
+  wide)   # 16-byte columns (median / trmean) and 8-byte ones (Aksel) at 29-52 rows: A/B at n = 51, then the parity files
+    for w in 1 0 1 0; do echo "BM_COL_WIDE=$w"; BM_COL_WIDE=$w timeout 300 python scripts/n51_probe.py 2>&1 | grep -v amdgpu.ids; done > $out/n51_wide_ab.txt; grep "WIDE\|median\|trmean\|aksel" $out/n51_wide_ab.txt
+    timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_parity_r2.py tests/test_gpu_full_size_o1.py -m gpu -x -q > $out/pytest_parity.log 2>&1; tail -3 $out/pytest_parity.log
+    ;;
   pair)   # the failing pair of files as the suite runs them, N times
     for i in $(seq 1 ${PAIR_RUNS:-3}); do
       BM_TEST_POISON=0 timeout 500 python -m pytest tests/test_gpu_full_size_o1.py tests/test_gpu_zz_multirank.py -m gpu -q > $out/pair_$i.log 2>&1
