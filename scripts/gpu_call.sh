@@ -126,7 +126,8 @@ case $name in
     timeout 200 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -1 $out/smoke.log
     timeout 600 python bench.py > $out/bench_default.json 2> $out/bench_default.err; wc -c $out/bench_default.json
     ;;
-  *)      # anything else: the rest of the command line, logged
+  *)      # anything else: the rest of the command line, logged (an unknown recipe name with nothing behind it is an error)
+    [ $# -gt 0 ] || { echo "unknown recipe: $name"; exit 64; }
     "$@" > $out/run.log 2>&1; tail -20 $out/run.log
     ;;
 esac
