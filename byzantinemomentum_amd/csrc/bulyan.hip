@@ -77,7 +77,7 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(
     for (int c = 0; c < W; ++c) {
       // selected[i]: forward sequential sum from rank i to m_max-1, exact division by the count
       float sel[THETA];
-      bool has_nan = false;
+      bool all_finite = true;
 #pragma unroll
       for (int i = 0; i < THETA; ++i) {
         float s = 0.0f;
@@ -85,23 +85,23 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(
         for (int t = i; t < MMAX; ++t) s += x[c][t];
         const float cnt = (float)(MMAX - i);
         sel[i] = div_small_int(s, cnt, 1.0f / cnt);
-        has_nan |= (sel[i] != sel[i]);
+        all_finite &= (__builtin_fabsf(sel[i]) < __builtin_inff());  // (false for NaN as well)
       }
-      sort_network<THETA>(sel);
       constexpr int MED = (THETA - 1) / 2;
-      const float med = sel[MED];
       // beta closest to the median: window [s, s+BETA) of the sorted values, s = 1 + the last t with
-      // |sel[t] - med| > |sel[t+BETA] - med|.  With a FINITE median and no NaN only the t whose window straddles the
-      // median can decide anything that shows in the result: for t + BETA <= MED both values lie at or below the
-      // median, the test is sel[t] < sel[t+BETA], and when such a t is the last one to fire every value from t+1 up to
-      // the median EQUALS the median — the window it selects and the default window [MED-BETA+1, MED] then hold the
-      // same BETA values; for t >= MED the test never fires.  So the short form looks at BETA-1 positions and sums
-      // over 2 BETA - 1 instead of THETA - BETA and THETA (n = 25, f = 5: 2 and 5 instead of 10 and 13): same bits,
-      // a fifth of the kernel's VALU work less.  A wave that holds a column with a non-finite median (or a NaN) takes
-      // the long form for all its columns (wave-uniform branch).
-      const bool odd = has_nan || !(__builtin_fabsf(med) < __builtin_inff());
-      float w = 0.0f;
-      if (short_window != 0 && __builtin_amdgcn_ballot_w64(odd) == 0ull) {
+      // |sel[t] - med| > |sel[t+BETA] - med|.  With FINITE values only the t whose window straddles the median can decide
+      // anything that shows in the result: for t + BETA <= MED both values lie at or below the median, the test is
+      // sel[t] < sel[t+BETA], and when such a t is the last one to fire every value from t+1 up to the median EQUALS the
+      // median — the window it selects and the default window [MED-BETA+1, MED] then hold the same BETA values; for
+      // t >= MED the test never fires.  So the short form looks at BETA-1 positions and sums over 2 BETA - 1 instead of
+      // THETA - BETA and THETA (n = 25, f = 5: 2 and 5 instead of 10 and 13): same bits, a fifth of the kernel's VALU work
+      // less.  It needs the sorted values around the median ONLY, so its sorting network — its own copy, inside the branch
+      // — is pruned by dead-code elimination to a selection network (n = 51, f = 12: beta = 1, the result IS the median of
+      // the 25 values; round 6, until then the full sorter ran in front of both forms).  A wave that holds a column with
+      // a non-finite value takes the long form for all its columns (wave-uniform branch).
+      if (short_window != 0 && __builtin_amdgcn_ballot_w64(!all_finite) == 0ull) {
+        sort_network<THETA>(sel);
+        const float med = sel[MED];
         constexpr int LO = (MED - BETA + 1 > 0) ? MED - BETA + 1 : 0;               // first t whose window reaches the median
         constexpr int TEND = (MED < THETA - BETA) ? MED : THETA - BETA;             // t >= MED never fires
         constexpr int IEND = (MED + BETA < THETA) ? MED + BETA : THETA;
@@ -112,9 +112,16 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(
           const float dh = __builtin_fabsf(sel[t + BETA] - med);
           s0 = (dl > dh) ? (t + 1) : s0;
         }
+        float w = 0.0f;
 #pragma unroll
         for (int i = LO; i < IEND; ++i) w += (i >= s0 && i < s0 + BETA) ? sel[i] : 0.0f;
+        r[c] = div_small_int(w, (float)BETA, 1.0f / (float)BETA);
       } else {
+        bool has_nan = false;
+#pragma unroll
+        for (int i = 0; i < THETA; ++i) has_nan |= (sel[i] != sel[i]);
+        sort_network<THETA>(sel);
+        const float med = sel[MED];
         int s0 = 0;
 #pragma unroll
         for (int t = 0; t < THETA - BETA; ++t) {
@@ -122,11 +129,12 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(
           const float dh = __builtin_fabsf(sel[t + BETA] - med);
           s0 = (dl > dh) ? (t + 1) : s0;
         }
+        float w = 0.0f;
 #pragma unroll
         for (int i = 0; i < THETA; ++i) w += (i >= s0 && i < s0 + BETA) ? sel[i] : 0.0f;
+        const float res = div_small_int(w, (float)BETA, 1.0f / (float)BETA);
+        r[c] = has_nan ? kNaN : res;
       }
-      const float res = div_small_int(w, (float)BETA, 1.0f / (float)BETA);
-      r[c] = has_nan ? kNaN : res;
     }
   };
   // the d % VEC trailing columns: one lane each, in the last workgroup (no second launch: 4.3 us of a C4 aggregation),

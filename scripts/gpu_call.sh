@@ -107,6 +107,14 @@ case $name in
     for w in 1 0 1 0; do echo "BM_COL_WIDE=$w"; BM_COL_WIDE=$w timeout 300 python scripts/n51_probe.py 2>&1 | grep -v amdgpu.ids; done > $out/n51_wide_ab.txt; grep "WIDE\|median\|trmean\|aksel" $out/n51_wide_ab.txt
     timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_parity_r2.py tests/test_gpu_full_size_o1.py -m gpu -x -q > $out/pytest_parity.log 2>&1; tail -3 $out/pytest_parity.log
     ;;
+  split)   # Bulyan pass 2 with the sorter inside each window branch: A/B against the library before (scratch/old), then parity
+    for lib in new old new old; do
+      L=""; [ $lib = old ] && L=scratch/old/libbm_gar_before_split.so
+      echo "== $lib"; BM_GAR_LIB=$L timeout 300 python scripts/n51_probe.py 2>&1 | grep "bulyan\|krum"
+      BM_GAR_LIB=$L timeout 300 python scripts/bulyan_pass2_probe.py 2>&1 | grep -v amdgpu.ids | tail -4
+    done > $out/split_ab.txt 2>&1; cat $out/split_ab.txt | cut -c1-220
+    timeout 1800 python -m pytest tests/test_gpu_parity.py tests/test_gpu_parity_r2.py tests/test_gpu_parity_r3.py tests/test_gpu_parity_r4.py tests/test_gpu_parity_r5.py tests/test_gpu_full_size_o1.py -m gpu -x -q > $out/pytest_parity.log 2>&1; tail -3 $out/pytest_parity.log
+    ;;
   pair)   # the failing pair of files as the suite runs them, N times
     for i in $(seq 1 ${PAIR_RUNS:-3}); do
       BM_TEST_POISON=0 timeout 500 python -m pytest tests/test_gpu_full_size_o1.py tests/test_gpu_zz_multirank.py -m gpu -q > $out/pair_$i.log 2>&1
