@@ -873,8 +873,10 @@ def step_algorithmic_bytes(d, n, f, gar):
 
 def attack_search(bm, honests, n, f, d, evals=16, gar="krum"):
   """The factor search of the "identical" attacks (attacks/identical.py:67-77, the reference's default
-  factor=-16), wall-clock of the whole search in its two forms.  Against Multi-Krum (C3): scalar form (one distance
-  pass over h+2 rows, then host only) and the reference's form (the rule on the vectors once per evaluation).
+  factor=-16), wall-clock of the whole search in its forms.  Against Multi-Krum (C3): scalar form (one distance
+  pass over h+2 rows, then the sixteen candidates from its (h+2)^2 scalars: ON THE DEVICE by default,
+  `scalar_form_ms`, the factor never leaves the GPU; on the host after a copy, `host_scalar_form_ms`, what rounds 2-5
+  measured) and the reference's form (the rule on the vectors once per evaluation).
   Against the median (C2 shape): every candidate as the middle of (candidate, lo, hi), lo / hi being two order
   statistics of the honest rows formed once per search (the key stays `scalar_form_ms`), and the reference's form.
   Against Bulyan (C4 shape): every candidate ranked on the host from one distance pass, pass 2 alone on the vectors.
@@ -883,17 +885,19 @@ def attack_search(bm, honests, n, f, d, evals=16, gar="krum"):
   from byzantinemomentum_amd.step import AggregationStep
   avg, _, direction = bm.stats.stack_stats_async(honests, scale=1.0, attack="empire", direction=True)
   res = {"config": f"empire against {gar}, n={n}, f={f}, d={d}, {evals} evaluations, one GPU"}
-  for mode, reps in (("auto", 10), ("generic", 3)):
+  modes = (("auto", 10), ("host", 10), ("generic", 3)) if gar in bm.stats.DEVICE_SEARCH_RULES else (("auto", 10), ("generic", 3))
+  for mode, reps in modes:
     runner = AggregationStep(n, f, f, gar=gar, attack_evals=evals, line_search=mode, nb_past=0)
     runner._search_factor(honests, avg, direction)
     torch.cuda.synchronize()
     each = []
     for _ in range(reps):
       t0 = time.perf_counter()
-      factor = runner._search_factor(honests, avg, direction)
+      runner.last_factor = runner._search_factor(honests, avg, direction)
       torch.cuda.synchronize()
       each.append((time.perf_counter() - t0) * 1e3)
-    key = "scalar_form" if mode == "auto" else "per_evaluation_form"
+    factor = runner.last_factor  # (the device form leaves it on the GPU: fetched here, outside the timed calls)
+    key = {"auto": "scalar_form", "host": "host_scalar_form", "generic": "per_evaluation_form"}[mode]
     # the MEDIAN search: one search in ten taking 40-60 ms (a stall of the host process, seen on loaded boxes in every
     # round: the same binaries gave a mean of 0.55 ms in one process and 4.7-7.5 ms in the next, with identical legs)
     # would otherwise be the whole figure; the mean, the slowest and every single search ride along
@@ -919,7 +923,7 @@ def search_legs(bm, honests, avg, direction, n, f, gar, evals, reps=10):
   k = n - h
   unit = torch.empty_like(avg)
   pinned = torch.empty((h + 2, h + 2), dtype=torch.float64, pin_memory=True)
-  legs = {"distance_pass_ms": [], "d2h_pageable_ms": [], "d2h_pinned_ms": [], "host_search_ms": []}
+  legs = {"distance_pass_ms": [], "d2h_pageable_ms": [], "d2h_pinned_ms": [], "host_search_ms": [], "device_search_ms": []}
   for _ in range(reps):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -938,7 +942,11 @@ def search_legs(bm, honests, avg, direction, n, f, gar, evals, reps=10):
       for e in range(evals):
         linesearch.attack_ranking(ext, h, k, f, "bulyan", 0.5 + 0.25 * e)
     t4 = time.perf_counter()
-    for key, dt in zip(legs, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+    if gar == "krum":  # the same candidates by one workgroup where the matrix is (what line_search="auto" runs)
+      stats.attack_search_device(sq, h, k, f, "krum", evals=evals)
+      torch.cuda.synchronize()
+    t5 = time.perf_counter()
+    for key, dt in zip(legs, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
       legs[key].append(dt * 1e3)
   out = {key: {"median": sorted(v)[len(v) // 2], "max": max(v)} for key, v in legs.items()}
   def read(path):

@@ -20,7 +20,7 @@ _PKG_DIR = pathlib.Path(__file__).resolve().parent
 # scripts/gram_variant_probe.py); the default, and the only thing the tests and the bench load, is the in-tree build.
 LIB_PATH = pathlib.Path(os.environ["BM_GAR_LIB"]).resolve() if os.environ.get("BM_GAR_LIB") else _PKG_DIR / "libbm_gar.so"
 
-ABI_VERSION = 19
+ABI_VERSION = 20
 MAX_ROWS = 64
 EINVAL = -100000
 ENOCOMM, ECOMM = -100001, -100002
@@ -100,6 +100,8 @@ SIGNATURES = {
                                        ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
   "bm_multi_fma3": (ctypes.c_int, [_c_float_pp, _c_float_pp, _c_float_pp, ctypes.c_int, ctypes.c_int64,
                                    ctypes.c_float, ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p]),
+  "bm_multi_fma3_bdev": (ctypes.c_int, [_c_float_pp, _c_float_pp, _c_float_pp, ctypes.c_int, ctypes.c_int64,
+                                        ctypes.c_float, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
   "bm_clip_factors": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_void_p,
                                      ctypes.c_void_p]),
   "bm_multi_scale": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]),
@@ -139,6 +141,9 @@ SIGNATURES = {
                                          ctypes.c_void_p]),
   "bm_attack_line_search": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]),
+  "bm_attack_line_search_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                  ctypes.c_void_p, ctypes.c_void_p]),
   "bm_attack_ranking": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                        ctypes.c_int, ctypes.c_double, ctypes.c_void_p]),
 }

@@ -18,64 +18,13 @@
 #include <vector>
 
 #include "bm_common.h"
+#include "search_core.h"  // the cursor and the closed forms, shared with the device form (search_device.hip)
 
 extern "C" int bm_brute_select(const double* dist_nxn, int n, int f, int32_t* sel_out);
 
 namespace {
 
-// The exploration of tools/misc.py:468-514 as a CURSOR the caller drives: propose() names the next abscissa,
-// report() takes the value measured there.  The library never calls back into the caller (no function pointer
-// crosses the ABI), so the same object serves the per-evaluation search of the Python host mirror (one device
-// evaluation between propose and report) and the scalar search below.
-// Behaviour to reproduce (the candidates must be the reference's, evaluation for evaluation):
-//   GROW    probe = incumbent + step; a strictly better value moves the incumbent there and doubles the step,
-//           the first value that is not better multiplies the step by `ratio` and ends the phase;
-//   SHRINK  the probe walks towards the incumbent and oscillates around it (+step while left of it, else
-//           -step, folded back into x >= 0 by repeated halving of the overshoot); the step is multiplied by
-//           `ratio` after every evaluation; strictly better values move the incumbent.
-enum { kSearchFirst = 0, kSearchGrow = 1, kSearchShrink = 2 };
-
-void cursor_propose(bm_search* c) {
-  switch (c->phase) {
-    case kSearchFirst:
-      break;  // probe already holds the starting point
-    case kSearchGrow:
-      c->probe = c->best_x + c->step;
-      break;
-    default:
-      if (c->probe < c->best_x) {
-        c->probe += c->step;
-      } else {
-        double x = c->probe - c->step;
-        while (x < 0.0) x = 0.5 * (x + c->probe);
-        c->probe = x;
-      }
-  }
-}
-
-void cursor_report(bm_search* c, double y) {
-  const bool better = (c->phase == kSearchFirst) || (y > c->best_y);  // strict: equal values never move the incumbent
-  if (better) {
-    c->best_x = c->probe;
-    c->best_y = y;
-  }
-  switch (c->phase) {
-    case kSearchFirst:
-      c->phase = kSearchGrow;
-      break;
-    case kSearchGrow:
-      if (better) {
-        c->step *= 2.0;
-      } else {
-        c->step *= c->ratio;
-        c->phase = kSearchShrink;
-      }
-      break;
-    default:
-      c->step *= c->ratio;
-  }
-  ++c->evaluations;
-}
+using namespace bm;
 
 struct AttackGeometry {
   int h, k, n;
@@ -90,12 +39,12 @@ struct AttackGeometry {
     c = ext[h * e + h + 1];
     for (int i = 0; i < h; ++i) {
       a[i] = ext[i * e + h];
-      w[i] = 0.5 * (a[i] + c - ext[i * e + h + 1]);
+      w[i] = attack_w(a[i], c, ext[i * e + h + 1]);
     }
     for (int i = 0; i < h; ++i)
       for (int j = 0; j < h; ++j) {
         hh[(size_t)i * h + j] = ext[i * e + j];
-        uu[(size_t)i * h + j] = (i == j) ? a[i] : 0.5 * (a[i] + a[j] - ext[i * e + j]);
+        uu[(size_t)i * h + j] = attack_uu(a[i], a[j], ext[i * e + j], i == j);
       }
   }
 
@@ -104,8 +53,7 @@ struct AttackGeometry {
     sq.assign((size_t)n * n, 0.0);
     for (int i = 0; i < h; ++i) {
       for (int j = 0; j < h; ++j) sq[(size_t)i * n + j] = hh[(size_t)i * h + j];
-      double q = a[i] - 2.0 * t * w[i] + t * t * c;
-      if (q < 0.0) q = 0.0;  // rounding of a candidate that coincides with an honest row
+      const double q = attack_candidate_sq(a[i], w[i], c, t);
       for (int j = h; j < n; ++j) {
         sq[(size_t)i * n + j] = q;
         sq[(size_t)j * n + i] = q;
@@ -113,9 +61,7 @@ struct AttackGeometry {
     }
   }
 
-  // |mean(selected rows) - avg|^2; the honest part is summed in index order so that the value depends on
-  // the selected SET only (two candidates that select the same honest rows and no Byzantine one compare
-  // equal, as they do in the reference where the rule then returns the same vector)
+  // |mean(selected rows) - avg|^2 (search_core.h: row sums in index order, then their sum in index order)
   double objective(const std::vector<int>& sel_sorted, double t) const {
     int kb = 0;
     double quad = 0.0, lin = 0.0;
@@ -125,11 +71,12 @@ struct AttackGeometry {
         continue;
       }
       lin += w[i];
+      double row = 0.0;
       for (int j : sel_sorted)
-        if (j < h) quad += uu[(size_t)i * h + j];
+        if (j < h) row += uu[(size_t)i * h + j];
+      quad += row;
     }
-    const double count = (double)sel_sorted.size();
-    return (quad + 2.0 * kb * t * lin + (double)kb * kb * t * t * c) / (count * count);
+    return attack_objective_value(quad, lin, kb, t, c, (int)sel_sorted.size());
   }
 };
 
@@ -197,14 +144,7 @@ bool valid(const double* ext, int h, int k, int f, int rule, int& m) {
 
 extern "C" int bm_search_begin(bm_search* c, double start, double delta, double ratio) {
   if (c == nullptr || !(start >= 0.0) || !(delta > 0.0) || !(ratio > 0.5 && ratio < 1.0)) return BM_EINVAL;
-  c->best_x = start;
-  c->best_y = 0.0;
-  c->probe = start;
-  c->step = delta;
-  c->ratio = ratio;
-  c->phase = kSearchFirst;
-  c->evaluations = 0;
-  c->awaiting = 0;
+  cursor_begin(c, start, delta, ratio);
   return 0;
 }
 

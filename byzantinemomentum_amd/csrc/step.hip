@@ -762,8 +762,12 @@ struct Fma3Table {
 };
 
 template <int VEC>
-__global__ __launch_bounds__(kStepBlock) void multi_fma3_kernel(Fma3Table tab, int64_t nvec, float a, float b,
-                                                                const float* __restrict__ pscale) {
+__global__ __launch_bounds__(kStepBlock) void multi_fma3_kernel(Fma3Table tab, int64_t nvec, float a, float b_host,
+                                                                const float* __restrict__ pscale,
+                                                                const double* __restrict__ b_dev) {
+  // b from device memory (bm_multi_fma3_bdev: the factor bm_attack_line_search_device left there), rounded to fp32 as
+  // the host's double -> float conversion of the same number would be
+  const float b = b_dev != nullptr ? (float)b_dev[0] : b_host;
   float* out = tab.out[blockIdx.y];
   const float* p = tab.p[blockIdx.y];
   const float* q = tab.q[blockIdx.y];
@@ -1233,8 +1237,8 @@ extern "C" int bm_stack_stats_sqdist(const float* const* rows, int k, int64_t d,
   return pairwise_from_gram_partials(all, n, k + 1, cus, d, sq_nxn, ws_pair, s);
 }
 
-extern "C" int bm_multi_fma3(float* const* out, const float* const* p, const float* const* q, int k, int64_t d,
-                             float a, float b, const float* p_scale, void* stream) {
+static int multi_fma3_launch(float* const* out, const float* const* p, const float* const* q, int k, int64_t d, float a,
+                             float b, const float* p_scale, const double* b_dev, void* stream) {
   using namespace bm;
   if (out == nullptr || p == nullptr || q == nullptr || k < 1 || k > BM_MAX_ROWS || d < 0) return BM_EINVAL;
   if (d == 0) return 0;
@@ -1253,9 +1257,9 @@ extern "C" int bm_multi_fma3(float* const* out, const float* const* p, const flo
     const int64_t nvec = d / vec;
     const int grid = stream_grid(nvec, kStepBlock, 2048);
     if (vec == 4)
-      hipLaunchKernelGGL(multi_fma3_kernel<4>, dim3(grid, k), dim3(kStepBlock), 0, s, tab, nvec, a, b, p_scale);
+      hipLaunchKernelGGL(multi_fma3_kernel<4>, dim3(grid, k), dim3(kStepBlock), 0, s, tab, nvec, a, b, p_scale, b_dev);
     else
-      hipLaunchKernelGGL(multi_fma3_kernel<2>, dim3(grid, k), dim3(kStepBlock), 0, s, tab, nvec, a, b, p_scale);
+      hipLaunchKernelGGL(multi_fma3_kernel<2>, dim3(grid, k), dim3(kStepBlock), 0, s, tab, nvec, a, b, p_scale, b_dev);
     BM_LAUNCH_CHECK();
     body = nvec * vec;
   }
@@ -1268,10 +1272,21 @@ extern "C" int bm_multi_fma3(float* const* out, const float* const* p, const flo
     }
     const int64_t rest = d - body;
     hipLaunchKernelGGL(multi_fma3_kernel<1>, dim3(stream_grid(rest, kStepBlock, 2048), k), dim3(kStepBlock), 0, s,
-                       tail, rest, a, b, p_scale);
+                       tail, rest, a, b, p_scale, b_dev);
     BM_LAUNCH_CHECK();
   }
   return 0;
+}
+
+extern "C" int bm_multi_fma3(float* const* out, const float* const* p, const float* const* q, int k, int64_t d,
+                             float a, float b, const float* p_scale, void* stream) {
+  return multi_fma3_launch(out, p, q, k, d, a, b, p_scale, nullptr, stream);
+}
+
+extern "C" int bm_multi_fma3_bdev(float* const* out, const float* const* p, const float* const* q, int k, int64_t d,
+                                  float a, const double* b_dev, const float* p_scale, void* stream) {
+  if (b_dev == nullptr) return BM_EINVAL;
+  return multi_fma3_launch(out, p, q, k, d, a, 0.0f, p_scale, b_dev, stream);
 }
 
 extern "C" int bm_multi_scale(float* const* y, int k, int64_t d, const float* factors, void* stream) {

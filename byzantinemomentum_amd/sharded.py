@@ -191,6 +191,14 @@ class HipBackend:
   def multi_fma3(self, outs, ps, qs, a, b, p_scale=None):
     return self.stats.multi_fma3(outs, ps, qs, a, b, p_scale)
 
+  @property
+  def device_search_rules(self):
+    """Rules whose factor search runs on the device (step.AggregationStep, line_search="auto")."""
+    return self.stats.DEVICE_SEARCH_RULES
+
+  def attack_search_device(self, *args, **kwargs):
+    return self.stats.attack_search_device(*args, **kwargs)
+
   def multi_scale(self, ys, factors):
     return self.stats.multi_scale(ys, factors)
 

@@ -296,7 +296,9 @@ def stack_stats_sqdist(rows, attack_scale, attack, n_byz, d_total=None):
 
 def multi_fma3(outs, ps, qs, a, b, p_scale_dev=None):
   """out_i = b*q_i + a*(p_scale_i*p_i) for every triple (outs may alias ps; qs may repeat one tensor):
-  worker / server / update momentum and the Nesterov look-ahead of attack.py:757-810,832-839."""
+  worker / server / update momentum and the Nesterov look-ahead of attack.py:757-810,832-839.
+  b: a number, or a DEVICE float64 tensor whose first element is read by the kernel (bm_multi_fma3_bdev: the factor
+  attack_search_device left on the device — no host round trip)."""
   outs, ps, qs = list(outs), list(ps), list(qs)
   k, d, device = gars._validate(outs)
   gars._validate(ps + [outs[0]])
@@ -305,11 +307,40 @@ def multi_fma3(outs, ps, qs, a, b, p_scale_dev=None):
     raise gars.GarInputError("multi_fma3 needs as many p and q as out vectors")
   lib = _lib.load()
   gars.invalidate_rank_cache()
+  scale = _ptr(p_scale_dev) if p_scale_dev is not None else None
   with torch.cuda.device(device):
-    _lib.check(lib.bm_multi_fma3(_lib.pointer_table(outs), _lib.pointer_table(ps), _lib.pointer_table(qs), k, d,
-                                 ctypes.c_float(a), ctypes.c_float(b),
-                                 _ptr(p_scale_dev) if p_scale_dev is not None else None, gars._stream(device)),
-               "bm_multi_fma3")
+    if isinstance(b, torch.Tensor):
+      if not (b.is_cuda and b.device == device and b.dtype == torch.float64 and b.numel() >= 1 and b.is_contiguous()):
+        raise gars.GarInputError("multi_fma3: a tensor b must be a contiguous float64 tensor on the vectors' device")
+      _lib.check(lib.bm_multi_fma3_bdev(_lib.pointer_table(outs), _lib.pointer_table(ps), _lib.pointer_table(qs), k, d,
+                                        ctypes.c_float(a), _ptr(b), scale, gars._stream(device)), "bm_multi_fma3_bdev")
+    else:
+      _lib.check(lib.bm_multi_fma3(_lib.pointer_table(outs), _lib.pointer_table(ps), _lib.pointer_table(qs), k, d,
+                                   ctypes.c_float(a), ctypes.c_float(b), scale, gars._stream(device)), "bm_multi_fma3")
+
+
+DEVICE_SEARCH_RULES = ("krum", "average")
+
+
+def attack_search_device(ext, h, k, f, rule, evals=16, negative=False, m=None):
+  """The factor search of attacks/identical.py:67-77 on the device (bm_attack_line_search_device) from the DEVICE
+  (h+2) x (h+2) squared distances among honests + [avg, avg + att]: a float64 device tensor of 1 + 2 * evals values —
+  [0] the factor, then (abscissa, objective) per evaluation — with the candidates and the bits of
+  linesearch.attack_line_search.  Nothing is copied or awaited: hand `out[:1]` to multi_fma3 as b."""
+  if rule not in DEVICE_SEARCH_RULES:
+    raise ValueError(f"no device form of the search for rule {rule!r}")
+  if not (isinstance(ext, torch.Tensor) and ext.is_cuda and ext.dtype == torch.float64 and ext.is_contiguous()
+          and tuple(ext.shape) == (h + 2, h + 2)):
+    raise gars.GarInputError(f"ext must be a contiguous float64 device tensor of shape ({h + 2}, {h + 2})")
+  if not isinstance(evals, int) or evals < 1:
+    _lib.check(_lib.EINVAL, "attack_search_device (evals must be a positive integer)")
+  lib = _lib.load()
+  out = torch.empty(1 + 2 * evals, dtype=torch.float64, device=ext.device)
+  with torch.cuda.device(ext.device):
+    _lib.check(lib.bm_attack_line_search_device(_ptr(ext), h, k, f, _lib.RULE_IDS[rule], m or 0, evals,
+                                                1 if negative else 0, _ptr(out), gars._stream(ext.device)),
+               "bm_attack_line_search_device")
+  return out
 
 
 def clip_factors_from_sq(sq, k, clip):

@@ -51,8 +51,10 @@ class AggregationStep:
     attack_evals: None = the fixed `attack_factor`; a positive integer E = the reference's `factor:-E` (its
     default is -16): the factor is searched each step with tools.line_maximize's exploration
     (identical.py:67-77), `attack_negative` being the attack's `negative` argument during the search.
-    line_search: "auto" evaluates the search from scalars when the rule allows it (krum, brute, average),
-    "generic" always runs the rule on the device once per evaluation like the reference does."""
+    line_search: "auto" evaluates the search from scalars when the rule allows it (krum, brute, average) — on the
+    device for krum / average (bm_attack_line_search_device: the step then has no synchronisation but `floats()`),
+    "host" the same scalars copied to the host (bm_attack_line_search, what "auto" does for brute), "generic" always
+    runs the rule on the device once per evaluation like the reference does."""
     if gar not in _RULES:
       raise ValueError(f"unknown aggregation rule {gar!r}")
     if momentum_at not in ("worker", "server", "update"):
@@ -61,8 +63,8 @@ class AggregationStep:
       raise ValueError(f"unknown attack {attack!r} (empire: factor, little: factor, use a negative one for negative:True)")
     if attack_evals is not None and (not isinstance(attack_evals, int) or attack_evals < 1):
       raise ValueError(f"attack_evals must be a positive number of evaluations, got {attack_evals!r}")
-    if line_search not in ("auto", "generic"):
-      raise ValueError(f"line_search must be 'auto' or 'generic', got {line_search!r}")
+    if line_search not in ("auto", "host", "generic"):
+      raise ValueError(f"line_search must be 'auto', 'host' or 'generic', got {line_search!r}")
     if not 0 <= nb_past <= MAX_PAST:
       raise ValueError(f"nb_past must be within 0..{MAX_PAST}")
     if aggregator is None:
@@ -85,8 +87,8 @@ class AggregationStep:
     self.attack_evals = attack_evals
     self.attack_negative = bool(attack_negative)
     self.line_search = line_search
-    self.last_factor = attack_factor  # the factor of the last step (the searched one with attack_evals)
-    self.last_search = None           # [(x, objective)] of the last search, in evaluation order
+    self._factor_now = attack_factor  # last_factor / last_search (below): a number and a list, or what the device
+    self._search_now = None           # search left in device memory (fetched when somebody asks)
     self.last_byzantine = None        # the Byzantine vector of the last step (aliased f_real times by the rule)
     self.buffers = None        # worker placement: one momentum buffer per honest worker (attack.py:676)
     self.server_momentum = None  # server / update placements: grad_momentum_server (attack.py:678)
@@ -107,6 +109,34 @@ class AggregationStep:
                             and (not self.agg.collective or self.agg.native is not None))
 
   # ------------------------------------------------------------------------ #
+
+  @property
+  def last_factor(self):
+    """The factor of the last step (the searched one with attack_evals).  After a device search this is the read that
+    synchronises; a step that never looks costs nothing."""
+    if isinstance(self._factor_now, torch.Tensor):
+      self._settle_search()
+    return self._factor_now
+
+  @last_factor.setter
+  def last_factor(self, value):
+    self._factor_now = value
+
+  @property
+  def last_search(self):
+    """[(x, objective)] of the last search, in evaluation order."""
+    if isinstance(self._search_now, torch.Tensor):
+      self._settle_search()
+    return self._search_now
+
+  @last_search.setter
+  def last_search(self, value):
+    self._search_now = value
+
+  def _settle_search(self):
+    values = self._fetch(self._search_now).tolist()
+    self._factor_now = values[0]
+    self._search_now = [(values[1 + 2 * i], values[2 + 2 * i]) for i in range((len(values) - 1) // 2)]
 
   @staticmethod
   def _new_rows(count, like, zero=False):
@@ -150,11 +180,19 @@ class AggregationStep:
     search only; the factor returned (and then applied) is the positive abscissa the search settled on."""
     from . import linesearch
     ops, agg, h, k = self.ops, self.agg, self.h, self.f_real
-    if self.line_search == "auto" and self.gar in linesearch.ANALYTIC_RULES and h + 2 <= 64 and \
+    if self.line_search in ("auto", "host") and self.gar in linesearch.ANALYTIC_RULES and h + 2 <= 64 and \
        not (set(self.gar_args) - {"m"}):
       unit = torch.empty_like(h_avg)
       ops.multi_fma3([unit], [h_avg], [direction], 1.0, 1.0)   # avg + dir: the candidate of factor 1
-      ext = self._fetch(agg.global_sqdist(list(honests) + [h_avg, unit]))  # the search's only synchronisation
+      sq = agg.global_sqdist(list(honests) + [h_avg, unit])
+      if self.line_search == "auto" and self.gar in getattr(ops, "device_search_rules", ()):
+        # every candidate evaluated where the distances are: no copy, no synchronisation; the factor stays on the
+        # device (a tensor: multi_fma3 reads it there) and last_factor / last_search fetch it when asked
+        found = ops.attack_search_device(sq, h, k, self.f_decl, self.gar, evals=self.attack_evals,
+                                         negative=self.attack_negative, m=self.gar_args.get("m"))
+        self.last_search = found
+        return found
+      ext = self._fetch(sq)  # the search's only synchronisation
       factor, self.last_search = linesearch.attack_line_search(
         ext, h, k, self.f_decl, self.gar, evals=self.attack_evals, negative=self.attack_negative,
         m=self.gar_args.get("m"))
@@ -162,7 +200,7 @@ class AggregationStep:
 
     rule = lambda cand, t: self._aggregate(list(honests) + [cand] * k)  # noqa: E731
     n = h + k
-    if self.line_search == "auto" and self.gar == "bulyan" and k >= 1 and h + 2 <= 64 and hasattr(ops, "bulyan_pass2") \
+    if self.line_search in ("auto", "host") and self.gar == "bulyan" and k >= 1 and h + 2 <= 64 and hasattr(ops, "bulyan_pass2") \
        and not (set(self.gar_args) - {"m"}):
       # Bulyan's second pass needs the vectors, its ranking does not: the distances among honests + [avg + t*dir] * k
       # are functions of the inner products of ONE distance pass over honests + [avg, avg + dir] (as for krum above),
@@ -176,7 +214,7 @@ class AggregationStep:
         order = linesearch.attack_ranking(ext, h, k, self.f_decl, "bulyan", t, m)
         rows, table = list(honests) + [cand] * k, ops.index_tensor(order + [0] * (64 - n), h_avg)
         return ops.bulyan_pass2(rows, table, self.f_decl, m)
-    if self.line_search == "auto" and self.gar == "median" and k >= 1:
+    if self.line_search in ("auto", "host") and self.gar == "median" and k >= 1:
       # The lower median of the h honest values and k copies of ONE value b is monotone in b, equals b while b lies
       # between two order statistics of the honest values and stays at them outside: median(honests + [b] * k) =
       # middle of (b, lo, hi) per coordinate, with lo / hi the medians of the honest values and k copies of -inf /
@@ -187,7 +225,7 @@ class AggregationStep:
       hi = agg.median(list(honests) + [torch.full_like(h_avg, math.inf)] * k)
       rule = lambda cand, t: agg.median([cand, lo, hi])  # noqa: E731
 
-    fused_eval = (self.line_search == "auto" and k >= 1 and not self.gar_args and hasattr(ops, "colwise_eval")
+    fused_eval = (self.line_search in ("auto", "host") and k >= 1 and not self.gar_args and hasattr(ops, "colwise_eval")
                   and ops.colwise_eval_supported(self.gar, n))
 
     def scape(x):
@@ -299,9 +337,10 @@ class AggregationStep:
         s_avg, s_out3 = ops.stack_stats(sampled)
     if self.attack_evals is not None and self.f_real > 0:
       direction = byz
-      self.last_factor = self._search_factor(honests, h_avg, direction)
+      factor = self._search_factor(honests, h_avg, direction)  # a number, or the device search's tensor ([0]: the factor)
+      self.last_factor = factor
       byz = torch.empty_like(h_avg)  # grad_att.mul_(factor); byz_grad = grad_avg.add_(grad_att)  (identical.py:82-84)
-      ops.multi_fma3([byz], [h_avg], [direction], 1.0, self.last_factor)
+      ops.multi_fma3([byz], [h_avg], [direction], 1.0, factor)
     attacks = [byz] * self.f_real
     self.last_byzantine = byz if self.f_real > 0 else None  # the Byzantine vector of this step (callers, tests)
     # 3. aggregation

@@ -264,6 +264,11 @@ int bm_stack_stats_sqdist(const float* const* rows, int k, int64_t d, int64_t d_
  * worker (attack.py:800-804), server (:805-808), update (:838-839), Nesterov look-ahead (:762,767). */
 int bm_multi_fma3(float* const* out, const float* const* p, const float* const* q, int k, int64_t d,
                   float a, float b, const float* p_scale, void* stream);
+/* The same with b read from DEVICE memory (one double, rounded to fp32 like the host's conversion of the same number):
+ * the Byzantine vector avg + factor * att (identical.py:82-84) from the factor bm_attack_line_search_device left on
+ * the device, without a host round trip. */
+int bm_multi_fma3_bdev(float* const* out, const float* const* p, const float* const* q, int k, int64_t d,
+                       float a, const double* b_dev, const float* p_scale, void* stream);
 
 /* Gradient clipping (attack.py:776-779,791-794) without a host round trip:
  * bm_clip_factors: factors[i] = clip/sqrt(row_sq[i]) if sqrt(row_sq[i]) > clip else 1 (device arrays);
@@ -388,7 +393,7 @@ int bm_colwise_eval(int op, const float* const* honests, int h, int copies, int6
 
 /* ---------------------------------------------------------------------------------------------
  * The factor search of the "identical" attacks (attacks/identical.py:67-77, the reference's default
- * factor=-16) — HOST functions, no stream.
+ * factor=-16) — HOST functions, no stream (but bm_attack_line_search_device).
  *
  * bm_search_*: the exploration of tools/misc.py:468-514 (best-effort arg-max over x >= 0 within a budget of
  * evaluations; reference defaults: start 0, delta 1, ratio 0.8) as a cursor the CALLER drives:
@@ -421,6 +426,13 @@ int bm_attack_objective(const double* ext, int h, int k, int f, int rule, int m,
                         int32_t* sel_out, int32_t* count_out);
 int bm_attack_line_search(const double* ext, int h, int k, int f, int rule, int m, int evals, int negative,
                           double* factor_out, double* trace_out);
+/* bm_attack_line_search on the DEVICE, for BM_RULE_KRUM and BM_RULE_AVERAGE (BM_EINVAL for BM_RULE_BRUTE: its search
+ * is the host form's): ext is the DEVICE matrix where bm_pairwise_sqdist left it, one workgroup evaluates the `evals`
+ * candidates (csrc/search_device.hip) and writes out[0] = the factor, out[1 + 2e], out[2 + 2e] = abscissa and objective
+ * of evaluation e (out: DEVICE, 1 + 2 * evals doubles).  Same candidates and the same bits as the host form; no copy,
+ * no synchronisation — the factor is consumed where it is by bm_multi_fma3_bdev. */
+int bm_attack_line_search_device(const double* ext, int h, int k, int f, int rule, int m, int evals, int negative,
+                                 double* out, void* stream);
 /* The ranking bm_krum_rank(mode, m) would give for honests + [avg + t*att] * k, from the same scalars (order_out: n
  * int32, indices >= h being Byzantine copies): for the rules whose output needs the vectors but whose ranking does not
  * — Bulyan (aggregators/bulyan.py:48-62 rank, :64-84 second pass): a candidate of the factor search then costs

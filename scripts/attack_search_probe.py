@@ -20,7 +20,7 @@ bench.SEPARATE_ROWS = True
 stacks = bench.make_stacks(n, f, d, dev, 1, 4321, False)
 honests = stacks[0][:n - f]
 avg, _, direction = bm.stats.stack_stats_async(honests, scale=1.0, attack="empire", direction=True)
-runner = AggregationStep(n, f, f, gar="krum", attack_evals=16, line_search="auto", nb_past=0)
+runner = AggregationStep(n, f, f, gar="krum", attack_evals=16, line_search="host", nb_past=0)  # the host form: the one with a copy and a host leg to time
 runner._search_factor(honests, avg, direction)
 torch.cuda.synchronize()
 for rep in range(5):

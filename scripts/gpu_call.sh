@@ -115,6 +115,16 @@ case $name in
     done > $out/split_ab.txt 2>&1; cat $out/split_ab.txt | cut -c1-220
     timeout 1800 python -m pytest tests/test_gpu_parity.py tests/test_gpu_parity_r2.py tests/test_gpu_parity_r3.py tests/test_gpu_parity_r4.py tests/test_gpu_parity_r5.py tests/test_gpu_full_size_o1.py -m gpu -x -q > $out/pytest_parity.log 2>&1; tail -3 $out/pytest_parity.log
     ;;
+  devsearch)   # the factor search on the device: parity with the host form, the three forms timed, a kernel trace; Brute's kernel trace
+    timeout 900 python -m pytest tests/test_gpu_search_device.py -m gpu -x -q > $out/pytest_search_device.log 2>&1; tail -5 $out/pytest_search_device.log
+    timeout 1500 python -m pytest tests/test_gpu_parity_r2.py tests/test_gpu_parity_r3.py tests/test_gpu_parity_r4.py -m gpu -x -q -k "search or factor" > $out/pytest_search_forms.log 2>&1; tail -3 $out/pytest_search_forms.log
+    timeout 600 python scripts/search_forms_probe.py 2>&1 | grep -v amdgpu.ids > $out/search_forms.txt; grep "^rep" $out/search_forms.txt | cut -c1-600
+    REPS=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_search -o search -- python scripts/search_forms_probe.py > $out/prof_search.log 2>&1
+    find $out/prof_search -name "*kernel_stats.csv" | head -1 | xargs -r head -12 | cut -c1-200
+    timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_brute -o brute -- python scripts/brute_probe.py > $out/prof_brute.log 2>&1
+    grep -v amdgpu.ids $out/prof_brute.log | tail -6 | cut -c1-300
+    find $out/prof_brute -name "*kernel_stats.csv" | head -1 | xargs -r head -12 | cut -c1-200
+    ;;
   pair)   # the failing pair of files as the suite runs them, N times
     for i in $(seq 1 ${PAIR_RUNS:-3}); do
       BM_TEST_POISON=0 timeout 500 python -m pytest tests/test_gpu_full_size_o1.py tests/test_gpu_zz_multirank.py -m gpu -q > $out/pair_$i.log 2>&1

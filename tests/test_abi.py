@@ -184,4 +184,23 @@ def test_second_pass_entry_points_validate_arguments_without_gpu(lib):
   assert lib.bm_colwise_eval(_lib.OP_TRMEAN, rows, 20, 5, 1000, 5, None, rows, ctypes.c_float(1.0), rows, rows, None) == _lib.EINVAL
   for gone in ("bm_bulyan_pass2_walk", "bm_colwise_eval_walk"):
     assert not hasattr(lib, gone), gone
-  assert lib.bm_abi_version() == 19
+  assert lib.bm_abi_version() >= 19
+
+
+def test_device_search_entry_points_validate_arguments_without_gpu(lib):
+  """ABI 20: bm_attack_line_search_device (krum / average only: Brute's search is the host form's) and
+  bm_multi_fma3_bdev — their argument checks (no launch)."""
+  from byzantinemomentum_amd import _lib
+  buf = (ctypes.c_double * 64)()
+  krum, brute, average = _lib.RULE_IDS["krum"], _lib.RULE_IDS["brute"], _lib.RULE_IDS["average"]
+  search = lib.bm_attack_line_search_device
+  assert search(None, 20, 5, 5, krum, 0, 16, 0, buf, None) == _lib.EINVAL       # no matrix
+  assert search(buf, 20, 5, 5, krum, 0, 16, 0, None, None) == _lib.EINVAL       # nowhere to write
+  assert search(buf, 20, 5, 5, brute, 0, 16, 0, buf, None) == _lib.EINVAL       # host form only
+  assert search(buf, 60, 5, 5, average, 0, 16, 0, buf, None) == _lib.EINVAL     # n > BM_MAX_ROWS
+  assert search(buf, 20, 5, 5, krum, 26, 16, 0, buf, None) == _lib.EINVAL       # m > n
+  assert search(buf, 20, 5, 5, krum, 0, 0, 0, buf, None) == _lib.EINVAL         # no evaluation
+  rows = (ctypes.c_void_p * 64)()
+  assert lib.bm_multi_fma3_bdev(rows, rows, rows, 1, 1000, ctypes.c_float(1.0), None, None, None) == _lib.EINVAL
+  assert lib.bm_multi_fma3_bdev(rows, rows, rows, 1, 0, ctypes.c_float(1.0), buf, None, None) == 0   # empty vectors
+  assert lib.bm_abi_version() == 20

@@ -475,7 +475,8 @@ def test_factor_search_full_size_c3_both_forms_and_fp64(bm, kind, attack):
   found = {}
   for mode in ("auto", "generic"):
     runner = AggregationStep(n, f, f, gar="krum", attack=attack, attack_evals=16, line_search=mode, nb_past=0)
-    found[mode] = (runner._search_factor(honests, avg, direction), runner.last_search)
+    runner.last_factor = runner._search_factor(honests, avg, direction)  # ("auto": the device search's tensor)
+    found[mode] = (runner.last_factor, runner.last_search)
   (fa, ta), (fg, tg) = found["auto"], found["generic"]
   top = max(y for _, y in tg)
   for (x, y), (xo, yo) in zip(ta, tg):

@@ -1,0 +1,180 @@
+"""The attacks' factor search evaluated on the device (csrc/search_device.hip, bm_attack_line_search_device) against the
+host form (csrc/linesearch.cpp, bm_attack_line_search) — attacks/identical.py:67-77 with tools/misc.py:468-514.
+
+Both forms work from the (h+2) x (h+2) squared distances of one distance pass and share their closed forms and their
+cursor (csrc/search_core.h), so the bar is bit identity: the same sixteen abscissae, the same sixteen objectives, the
+same factor — on matrices that come from real stacks and on adversarial ones (ties everywhere, zero and non-finite
+entries, geometry no set of vectors has).  The host form itself is pinned to the reference's loop elsewhere
+(tests/test_step_cpu.py, tests/test_gpu_parity_r2.py / _r4.py: same candidates, objectives within 2e-5).
+Needs an MI355X: `pytest -m gpu`.
+"""
+
+import math
+
+import pytest
+import torch
+
+from tests.test_gpu_parity_r2 import DEV
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bm():
+  import byzantinemomentum_amd
+  byzantinemomentum_amd._lib.load()
+  return byzantinemomentum_amd
+
+
+def _both(bm, ext_dev, h, k, f, rule, evals, negative, m):
+  from byzantinemomentum_amd import linesearch
+  out = bm.stats.attack_search_device(ext_dev, h, k, f, rule, evals=evals, negative=negative, m=m).cpu().tolist()
+  got = (out[0], [(out[1 + 2 * i], out[2 + 2 * i]) for i in range(evals)])
+  want = linesearch.attack_line_search(ext_dev.cpu().contiguous(), h, k, f, rule, evals=evals, negative=negative, m=m)
+  return got, want
+
+
+def _same_bits(got, want, tag):
+  (fg, tg), (fw, tw) = got, want
+  assert len(tg) == len(tw), tag
+  for e, ((x, y), (xo, yo)) in enumerate(zip(tg, tw)):
+    same_y = (y == yo) or (math.isnan(y) and math.isnan(yo))
+    assert x == xo and same_y, (tag, e, (x, y), (xo, yo))
+  assert fg == fw, (tag, fg, fw)
+
+
+def _ext_of_stack(bm, h, d, seed, kind):
+  """(h+2) x (h+2) device matrix of honests + [avg, avg + att] as AggregationStep forms it."""
+  gen = torch.Generator().manual_seed(seed)
+  base = torch.randn(d, generator=gen)
+  if kind == "hetero":
+    rows = [base + (0.3 + 0.05 * i) * torch.randn(d, generator=gen) for i in range(h)]
+  elif kind == "tight":
+    rows = [base + 1e-3 * torch.randn(d, generator=gen) for _ in range(h)]
+  elif kind == "duplicates":  # exact ties among the honest distances
+    few = [base + torch.randn(d, generator=gen) for _ in range(max(1, h // 3))]
+    rows = [few[i % len(few)].clone() for i in range(h)]
+  else:
+    raise ValueError(kind)
+  honests = [r.to(DEV) for r in rows]
+  avg, _, direction = bm.stats.stack_stats_async(honests, scale=1.0, attack="empire", direction=True)
+  unit = torch.empty_like(avg)
+  bm.stats.multi_fma3([unit], [avg], [direction], 1.0, 1.0)
+  return bm.gars.pairwise_sqdist(honests + [avg, unit])
+
+
+SHAPES = [
+  # h, k, f, m, evals
+  (9, 2, 2, None, 16),
+  (20, 5, 5, None, 16),      # C2 / C4 worker counts
+  (20, 5, 5, 1, 12),         # plain Krum
+  (39, 12, 12, None, 16),    # C3
+  (39, 12, 12, 51, 16),      # every row selected
+  (62, 2, 2, None, 16),      # the most honest rows the tables hold (64 KB of LDS: the opt-in)
+  (33, 31, 15, None, 16),    # as many copies as the row count allows
+  (14, 0, 3, None, 8),       # no Byzantine row at all
+  (1, 0, 0, 1, 4),           # one row
+  (2, 1, 0, 1, 16),
+]
+
+
+@pytest.mark.parametrize("kind", ["hetero", "tight", "duplicates"])
+@pytest.mark.parametrize("shape", SHAPES, ids=lambda s: "h%d-k%d-f%d-m%s-e%d" % s)
+def test_device_search_equals_host_search_on_stacks(bm, shape, kind):
+  h, k, f, m, evals = shape
+  ext = _ext_of_stack(bm, h, 20011, 7 * h + k, kind)
+  for rule in ("krum", "average"):
+    for negative in (False, True):
+      got, want = _both(bm, ext, h, k, f, rule, evals, negative, m if rule == "krum" else None)
+      _same_bits(got, want, (shape, kind, rule, negative))
+
+
+def test_device_search_equals_host_search_on_adversarial_matrices(bm):
+  """Matrices no stack produces: small integers (ties in every row and among the scores), zeros off the diagonal,
+  +inf / NaN entries (krum.py:46-47: a non-finite distance counts as +inf), a huge |att|^2 and a zero one."""
+  gen = torch.Generator().manual_seed(99)
+  cases = 0
+  for h, k, f in ((7, 2, 2), (20, 5, 5), (39, 12, 12), (50, 14, 14)):
+    e = h + 2
+    for trial in range(12):
+      a = torch.randint(0, 6, (e, e), generator=gen).double()
+      ext = a + a.t()
+      ext.fill_diagonal_(0.0)
+      if trial % 4 == 1:
+        ext[h, h + 1] = ext[h + 1, h] = 0.0          # att = 0: every candidate is the honest average
+      if trial % 4 == 2:
+        ext[h, h + 1] = ext[h + 1, h] = 1e12
+      if trial % 4 == 3:
+        i, j = int(torch.randint(0, h, (1,), generator=gen)), int(torch.randint(0, h, (1,), generator=gen))
+        ext[i, j] = ext[j, i] = math.inf if trial % 8 == 3 else math.nan
+        ext[i, h + 1] = ext[h + 1, i] = math.inf
+      if trial >= 8:
+        ext = ext * (0.5 + torch.rand(e, e, generator=gen).double())  # no ties, not symmetric in its low bits
+      dev = ext.contiguous().to(DEV)
+      for rule in ("krum", "average"):
+        got, want = _both(bm, dev, h, k, f, rule, 16, trial % 2 == 1, None)
+        _same_bits(got, want, (h, k, f, trial, rule))
+        cases += 1
+  assert cases == 96
+
+
+def test_factor_applied_from_device_memory_has_the_bits_of_the_host_factor(bm):
+  """bm_multi_fma3_bdev: avg + factor * att with the factor read from device memory = the same call with the number."""
+  gen = torch.Generator().manual_seed(5)
+  for d in (1, 7, 4096, 100003):
+    avg, att = torch.randn(d, generator=gen).to(DEV), torch.randn(d, generator=gen).to(DEV)
+    for factor in (0.0, 1.0, 0.8 ** 7, 1234.56789, 1e-30):
+      want, got = torch.empty_like(avg), torch.empty_like(avg)
+      bm.stats.multi_fma3([want], [avg], [att], 1.0, factor)
+      where = torch.tensor([factor, 777.0, -1.0], dtype=torch.float64, device=DEV)
+      bm.stats.multi_fma3([got], [avg], [att], 1.0, where)
+      assert torch.equal(got, want), (d, factor)
+  with pytest.raises(bm.gars.GarInputError):
+    bm.stats.multi_fma3([got], [avg], [att], 1.0, torch.tensor([1.0], dtype=torch.float32, device=DEV))
+
+
+def test_step_with_device_search_has_no_host_round_trip_and_matches_the_host_form(bm):
+  """AggregationStep(line_search="auto") against Multi-Krum: the factor never leaves the device during run() (the
+  search and the Byzantine vector are captured in a HIP graph together with the distance pass, which a copy to the host
+  or a stream synchronisation would refuse), and the step equals the one that searches on the host, bit for bit."""
+  from byzantinemomentum_amd.step import AggregationStep
+  n, f, d = 25, 5, 60013
+  h = n - f
+  gen = torch.Generator().manual_seed(11)
+  steps = {mode: AggregationStep(n, f, f, gar="krum", momentum=0.9, dampening=0.9, momentum_at="update",
+                                 attack="empire", nb_past=2, attack_evals=16, line_search=mode) for mode in ("auto", "host")}
+  origin = torch.randn(d, generator=gen).to(DEV)
+  for it in range(3):
+    sampled = [(0.2 * torch.randn(d, generator=gen) + (0.5 + 0.1 * i) * torch.randn(d, generator=gen)).to(DEV) for i in range(h)]
+    outs = {}
+    for mode, step in steps.items():
+      outs[mode] = step.run([g.clone() for g in sampled], origin, origin).clone()
+      if mode == "auto":
+        assert isinstance(step._factor_now, torch.Tensor), "the device search must leave its factor on the device"
+    assert torch.equal(outs["auto"], outs["host"]), it
+    assert steps["auto"].last_search == steps["host"].last_search and steps["auto"].last_factor == steps["host"].last_factor
+    assert steps["auto"].floats() == steps["host"].floats()
+  # the search + the Byzantine vector under stream capture
+  honests = sampled
+  avg, _, direction = bm.stats.stack_stats_async(honests, scale=1.0, attack="empire", direction=True)
+  unit, byz = torch.empty_like(avg), torch.empty_like(avg)
+  bm.stats.multi_fma3([unit], [avg], [direction], 1.0, 1.0)
+  sq = bm.gars.pairwise_sqdist(honests + [avg, unit])
+  eager = bm.stats.attack_search_device(sq, h, f, f, "krum", evals=16)
+  bm.stats.multi_fma3([byz], [avg], [direction], 1.0, eager)
+  torch.cuda.synchronize()
+  want_byz, want_out = byz.clone(), eager.clone()
+  stream = torch.cuda.Stream()
+  stream.wait_stream(torch.cuda.current_stream())
+  graph = torch.cuda.CUDAGraph()
+  with torch.cuda.stream(stream):
+    out_graph = torch.empty_like(eager)
+    byz_graph = torch.empty_like(byz)
+    with torch.cuda.graph(graph, stream=stream):
+      found = bm.stats.attack_search_device(sq, h, f, f, "krum", evals=16)
+      out_graph.copy_(found)
+      bm.stats.multi_fma3([byz_graph], [avg], [direction], 1.0, found)
+  byz_graph.zero_()
+  graph.replay()
+  torch.cuda.synchronize()
+  assert torch.equal(out_graph, want_out) and torch.equal(byz_graph, want_byz)
