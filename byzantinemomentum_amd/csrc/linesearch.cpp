@@ -61,22 +61,22 @@ struct AttackGeometry {
     }
   }
 
-  // |mean(selected rows) - avg|^2 (search_core.h: row sums in index order, then their sum in index order)
+  // |mean(selected rows) - avg|^2 (search_core.h: row sums in index order, then the butterfly order over 64 slots)
   double objective(const std::vector<int>& sel_sorted, double t) const {
     int kb = 0;
-    double quad = 0.0, lin = 0.0;
+    double rows[BM_MAX_ROWS] = {0.0}, ws[BM_MAX_ROWS] = {0.0};
     for (int i : sel_sorted) {
       if (i >= h) {
         ++kb;
         continue;
       }
-      lin += w[i];
+      ws[i] = w[i];
       double row = 0.0;
       for (int j : sel_sorted)
         if (j < h) row += uu[(size_t)i * h + j];
-      quad += row;
+      rows[i] = row;
     }
-    return attack_objective_value(quad, lin, kb, t, c, (int)sel_sorted.size());
+    return attack_objective_value(butterfly_order_sum(rows), butterfly_order_sum(ws), kb, t, c, (int)sel_sorted.size());
   }
 };
 

@@ -86,10 +86,24 @@ __host__ __device__ inline double attack_candidate_sq(double a_i, double w_i, do
   return (q < 0.0) ? 0.0 : q;
 }
 // |mean(selected rows) - avg|^2 = |sum_{i in S} u_i + kb t att|^2 / count^2 with S the selected honest rows and kb
-// the selected Byzantine copies: quad = sum_{i in S} (sum_{j in S} <u_i, u_j>) — every inner sum and the outer one in
-// index order, so that the value depends on the selected SET only (two candidates that select the same honest rows
-// and no Byzantine one compare equal, as they do in the reference where the rule then returns the same vector) —
-// and lin = sum_{i in S} w_i in index order.
+// the selected Byzantine copies: quad = sum_{i in S} row_i, row_i = sum_{j in S} <u_i, u_j>, lin = sum_{i in S} w_i, in
+// a FIXED order so that the value depends on the selected SET only (two candidates that select the same honest rows
+// and no Byzantine one compare equal, as they do in the reference where the rule then returns the same vector): the
+// inner sums in index order; the outer ones over 64 slots (row i in slot i, 0.0 in the slots of unselected rows) in the
+// order a wave can follow with all its lanes at once — butterfly_order_sum below (a sequential outer sum costs the
+// device a chain of ~40 dependent fp64 additions of 13 ns each per candidate, profiles/r06_device_search.txt).
+// slot[i] <- slot[i] + slot[i ^ 1], then ^ 2, ^ 4, ..., ^ 32 (all 64 slots at every level): slot[0] at the end.  The device
+// form is butterfly_sum (search_device.hip).
+inline double butterfly_order_sum(const double (&slots)[BM_MAX_ROWS]) {
+  double cur[BM_MAX_ROWS], nxt[BM_MAX_ROWS];
+  for (int i = 0; i < BM_MAX_ROWS; ++i) cur[i] = slots[i];
+  for (int s = 1; s < BM_MAX_ROWS; s <<= 1) {
+    for (int i = 0; i < BM_MAX_ROWS; ++i) nxt[i] = cur[i] + cur[i ^ s];
+    for (int i = 0; i < BM_MAX_ROWS; ++i) cur[i] = nxt[i];
+  }
+  return cur[0];
+}
+
 __host__ __device__ inline double attack_objective_value(double quad, double lin, int kb, double t, double c, int count) {
   const double cnt = (double)count;
   return (quad + 2.0 * kb * t * lin + (double)kb * kb * t * t * c) / (cnt * cnt);

@@ -125,6 +125,18 @@ case $name in
     grep -v amdgpu.ids $out/prof_brute.log | tail -6 | cut -c1-300
     find $out/prof_brute -name "*kernel_stats.csv" | head -1 | xargs -r head -12 | cut -c1-200
     ;;
+  costs)   # library-free: the primitives of a one-workgroup kernel
+    P=scripts/probes/one_workgroup_costs
+    [ -x $P ] || hipcc --offload-arch=gfx950 -O2 -o $P $P.hip
+    timeout 120 $P 4096 > $out/one_workgroup_costs.txt 2>&1; cat $out/one_workgroup_costs.txt
+    ;;
+  stepsearch)   # a whole step with the search on the device / on the host, two vector lengths; then the whole GPU suite
+    for D in 11173962 36546980; do D=$D timeout 600 python scripts/step_search_probe.py 2>&1 | grep -v amdgpu.ids; done > $out/step_search.txt; cat $out/step_search.txt
+    ( time timeout 2400 python -m pytest tests -m gpu -x -q ) > $out/pytest_gpu.log 2>&1; tail -5 $out/pytest_gpu.log
+    ;;
+  searchprobe)   # the search kernel alone: warm / cold, 1-64 evaluations
+    timeout 300 python scripts/search_kernel_probe.py 2>&1 | grep -v amdgpu.ids > $out/search_kernel_probe.txt; cat $out/search_kernel_probe.txt
+    ;;
   pair)   # the failing pair of files as the suite runs them, N times
     for i in $(seq 1 ${PAIR_RUNS:-3}); do
       BM_TEST_POISON=0 timeout 500 python -m pytest tests/test_gpu_full_size_o1.py tests/test_gpu_zz_multirank.py -m gpu -q > $out/pair_$i.log 2>&1
