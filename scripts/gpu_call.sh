@@ -87,7 +87,7 @@ case $name in
     done
     ;;
   census)   # every rule of the library under GPU sharing, three launches each on unchanged rows (scripts/stale_read_hunt.py)
-    timeout 1500 python scripts/stale_read_hunt.py --procs 4 --iters ${HUNT_ITERS:-250} --hold-gb 0 --kinds gram,mean,pass2,median,trmean,phocas,meamed,aksel,cge,brute,krum,bulyan,stats > $out/census.jsonl 2> $out/census.err
+    timeout 1500 python scripts/stale_read_hunt.py --procs 4 --iters ${HUNT_ITERS:-250} --hold-gb 0 --kinds ${CENSUS_KINDS:-gram,mean,pass2,median,trmean,phocas,meamed,aksel,cge,brute,krum,bulyan,stats,search} > $out/census.jsonl 2> $out/census.err
     tail -1 $out/census.jsonl | cut -c1-2500
     ;;
   updatestep)   # where a step with the momentum at the update spends its time (kernel trace)

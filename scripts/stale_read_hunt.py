@@ -139,6 +139,11 @@ def child(args):
       if kind in ("aksel", "cge", "brute", "krum", "bulyan"):   # whole rules, distance pass and ranking included
         gars.invalidate_rank_cache()
         return getattr(bm, kind)(rows, F)
+      if kind == "search":   # the factor search on the device: distance pass over honests + [avg, avg + att], then the 16 candidates
+        avg_, _, att = bm.stats.stack_stats_async(rows[:h], scale=1.0, attack="empire", direction=True)
+        unit = torch.empty_like(avg_)
+        bm.stats.multi_fma3([unit], [avg_], [att], 1.0, 1.0)
+        return bm.stats.attack_search_device(gars.pairwise_sqdist(rows[:h] + [avg_, unit]), h, F, F, "krum", evals=16)
       if kind == "stats":
         avg, norm, dev_, mx = bm.compute_avg_dev_max(rows[:h])
         return torch.cat([avg, torch.tensor([norm, dev_, mx], device=dev)])
