@@ -42,7 +42,7 @@ namespace bm {
 constexpr int kSearchBlock = 1024;
 constexpr int kSearchWaves = kSearchBlock / 64;
 constexpr int kRowWaves = kSearchWaves - 1;
-constexpr int kRowsPerWave = (BM_MAX_ROWS - 2 + kRowWaves - 1) / kRowWaves;  // h <= 62 (n <= 64 only bounds h + k; h + 2 <= 64: the matrix)
+constexpr int kRowsPerWave = (BM_MAX_ROWS + kRowWaves - 1) / kRowWaves;       // 5: every h <= n <= 64 (the step itself stops at h = 62: its distance pass takes 64 rows)
 constexpr int kRankChunk = BM_MAX_ROWS / kSearchWaves;                       // rows whose scores one wave compares with everybody's
 
 __host__ __device__ inline int search_ld(int h) { return h | 1; }  // odd row length: lane i walks row i without bank conflicts

@@ -70,7 +70,7 @@ SHAPES = [
   (20, 5, 5, 1, 12),         # plain Krum
   (39, 12, 12, None, 16),    # C3
   (39, 12, 12, 51, 16),      # every row selected
-  (62, 2, 2, None, 16),      # the most honest rows the tables hold (64 KB of LDS: the opt-in)
+  (62, 2, 2, None, 16),      # the most honest rows a distance pass serves (h + 2 = 64)
   (33, 31, 15, None, 16),    # as many copies as the row count allows
   (14, 0, 3, None, 8),       # no Byzantine row at all
   (1, 0, 0, 1, 4),           # one row
@@ -94,7 +94,7 @@ def test_device_search_equals_host_search_on_adversarial_matrices(bm):
   +inf / NaN entries (krum.py:46-47: a non-finite distance counts as +inf), a huge |att|^2 and a zero one."""
   gen = torch.Generator().manual_seed(99)
   cases = 0
-  for h, k, f in ((7, 2, 2), (20, 5, 5), (39, 12, 12), (50, 14, 14)):
+  for h, k, f in ((7, 2, 2), (20, 5, 5), (39, 12, 12), (50, 14, 14), (63, 1, 1), (64, 0, 3)):  # (the last two: more honest rows than a distance pass can serve, legal for the search)
     e = h + 2
     for trial in range(12):
       a = torch.randint(0, 6, (e, e), generator=gen).double()
@@ -115,7 +115,7 @@ def test_device_search_equals_host_search_on_adversarial_matrices(bm):
         got, want = _both(bm, dev, h, k, f, rule, 16, trial % 2 == 1, None)
         _same_bits(got, want, (h, k, f, trial, rule))
         cases += 1
-  assert cases == 96
+  assert cases == 144
 
 
 def test_factor_applied_from_device_memory_has_the_bits_of_the_host_factor(bm):
