@@ -61,20 +61,24 @@ struct AttackGeometry {
     }
   }
 
-  // |mean(selected rows) - avg|^2 (search_core.h: row sums in index order, then the butterfly order over 64 slots)
+  // |mean(selected rows) - avg|^2 (search_core.h: row sums over the two halves of the row's span in index order, every
+  // column adding its value or 0.0; then the butterfly order over 64 slots)
   double objective(const std::vector<int>& sel_sorted, double t) const {
     int kb = 0;
-    double rows[BM_MAX_ROWS] = {0.0}, ws[BM_MAX_ROWS] = {0.0};
+    bool on[BM_MAX_ROWS] = {false};
     for (int i : sel_sorted) {
-      if (i >= h) {
-        ++kb;
-        continue;
-      }
+      if (i >= h) ++kb;
+      else on[i] = true;
+    }
+    double rows[BM_MAX_ROWS] = {0.0}, ws[BM_MAX_ROWS] = {0.0};
+    const int span = attack_row_span(h);
+    for (int i = 0; i < h; ++i) {
+      if (!on[i]) continue;
       ws[i] = w[i];
-      double row = 0.0;
-      for (int j : sel_sorted)
-        if (j < h) row += uu[(size_t)i * h + j];
-      rows[i] = row;
+      double lo = 0.0, hi = 0.0;
+      for (int j = 0; j < span / 2; ++j) lo += (j < h && on[j]) ? uu[(size_t)i * h + j] : 0.0;
+      for (int j = span / 2; j < span; ++j) hi += (j < h && on[j]) ? uu[(size_t)i * h + j] : 0.0;
+      rows[i] = lo + hi;
     }
     return attack_objective_value(butterfly_order_sum(rows), butterfly_order_sum(ws), kb, t, c, (int)sel_sorted.size());
   }

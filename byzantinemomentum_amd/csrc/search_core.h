@@ -89,9 +89,12 @@ __host__ __device__ inline double attack_candidate_sq(double a_i, double w_i, do
 // the selected Byzantine copies: quad = sum_{i in S} row_i, row_i = sum_{j in S} <u_i, u_j>, lin = sum_{i in S} w_i, in
 // a FIXED order so that the value depends on the selected SET only (two candidates that select the same honest rows
 // and no Byzantine one compare equal, as they do in the reference where the rule then returns the same vector): the
-// inner sums in index order; the outer ones over 64 slots (row i in slot i, 0.0 in the slots of unselected rows) in the
+// inner sums as (first half of the columns 0 .. attack_row_span(h) - 1 in index order) + (second half in index order),
+// a column adding its value when it is selected and 0.0 when it is not or lies beyond h (the device reads a row in
+// groups and adds without a branch, two chains in flight); the outer ones over 64 slots (row i in slot i, 0.0 in the slots of unselected rows) in the
 // order a wave can follow with all its lanes at once — butterfly_order_sum below (a sequential outer sum costs the
 // device a chain of ~40 dependent fp64 additions of 13 ns each per candidate, profiles/r06_device_search.txt).
+__host__ __device__ inline int attack_row_span(int h) { return (h + 7) & ~7; }
 // slot[i] <- slot[i] + slot[i ^ 1], then ^ 2, ^ 4, ..., ^ 32 (all 64 slots at every level): slot[0] at the end.  The device
 // form is butterfly_sum (search_device.hip).
 inline double butterfly_order_sum(const double (&slots)[BM_MAX_ROWS]) {

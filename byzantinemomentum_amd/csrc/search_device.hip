@@ -12,44 +12,42 @@
 //
 // Per candidate t the n x n distances of honests + [avg + t att] * k differ from those among the honest rows only in
 // the Byzantine row / column, so the ranking of krum.py:44-62 is not recomputed from scratch:
-//   * once: <u_i, u_j>, and every honest row's distances to the other honest rows in ascending order — one bitonic
-//     network per row, the row then STAYS in the registers of its wave, one value per lane;
-//   * per candidate: the wave of honest row i forms dq_i = |h_i - byz(t)|, counts with one ballot how many of the row's
-//     sorted distances lie below it, lays the merged sequence (those, k copies of dq_i, the rest) out across its lanes
-//     and adds the `take` smallest in ascending order through v_readlane (the additions of rank_order() on the host:
-//     equal values in either order give the same sums) — fifteen waves, up to five rows each, the chains of a wave
-//     interleaved; the sixteenth wave does the Byzantine row meanwhile (all k are the same row: k - 1 zeros, then the
-//     dq in ascending order); the stable argsort of the n scores is counted by all sixteen waves, four rows each; wave 0
-//     turns the selected set (a ballot) into the objective (row sums in index order, then their sum over the lanes in
-//     the butterfly order of search_core.h).
-//   Cost (profiles/r06_device_search.txt): 160 us for the 16 candidates of C3 (n = 51), ~10 us per candidate — what the
-//   host form spends on its arithmetic (0.16 ms) without its copy and its stream synchronisation.  The reference's
-//   semantics make every score a SEQUENTIAL sum (38 dependent fp64 additions per row and candidate) and a candidate is
-//   ~2 000 dependent instructions end to end; a loop iteration around one dependent fp64 addition is 32 cycles (13 ns) on
-//   this chip, 64 when a v_readlane pair feeds it (scripts/probes/one_workgroup_costs.hip), so a wave cannot beat a
-//   5 GHz core on latency here.  Earlier forms: one wave working row-per-lane from tables in LDS 216 us (conditional
-//   loads: a branch and a full LDS latency per element), 180 us with the loads batched; sixteen waves with the sorted
-//   rows in registers 175 us; with the dq ranked by all waves and the objective's outer sums in butterfly order 160 us.
+//   * once: <u_i, u_j>, and every honest row's distances to the other honest rows in ascending order (a bitonic
+//     network per row, sixteen waves);
+//   * per candidate: lane i of wave 0 forms dq_i = |h_i - byz(t)|, finds by binary search how many of its row's sorted
+//     distances lie below it and adds the `take` smallest of the merged sequence (those, k copies of dq_i, the rest) in
+//     ascending order (the additions of rank_order() on the host: equal values in either order give the same sums);
+//     wave 1 does the Byzantine row meanwhile (all k are the same row: k - 1 zeros, then the dq in ascending order, their
+//     stable rank counted by all sixteen waves); the stable argsort of the n scores is counted by all sixteen waves, four
+//     rows each; wave 0 turns the selected set (a ballot) into the objective (row sums in index order, then their sum
+//     over the lanes in the butterfly order of search_core.h).
+//   Cost and history: profiles/r06_device_search.txt (the reference's semantics make every score a SEQUENTIAL sum and a
+//   loop iteration around one dependent fp64 addition is 32 cycles on this chip, 64 when a v_readlane pair feeds it:
+//   scripts/probes/one_workgroup_costs.hip).
+#include <cstdlib>
+
 #include "bm_common.h"
 #include "rank_body.h"
 #include "search_core.h"
 
 namespace bm {
 
-// One workgroup of 16 waves.  Waves 0 .. 14 own the honest rows (row i on wave i % 15, the row's sorted distances one per
-// lane, in registers for the whole search), wave 15 owns the Byzantine row; wave 0 also turns the scores into the
-// objective.  Three workgroup barriers per candidate.
+// One workgroup of 16 waves.  All of them share the set-up (a wave sorts up to five honest rows) and the two stable
+// ranks of a candidate (four rows' worth of comparisons each); wave 0 does the honest rows' scores (a row per lane) and
+// the objective, wave 1 the Byzantine row meanwhile.  Three or four workgroup barriers per candidate.
 constexpr int kSearchBlock = 1024;
 constexpr int kSearchWaves = kSearchBlock / 64;
-constexpr int kRowWaves = kSearchWaves - 1;
-constexpr int kRowsPerWave = (BM_MAX_ROWS + kRowWaves - 1) / kRowWaves;       // 5: every h <= n <= 64 (the step itself stops at h = 62: its distance pass takes 64 rows)
-constexpr int kRankChunk = BM_MAX_ROWS / kSearchWaves;                       // rows whose scores one wave compares with everybody's
+constexpr int kSortRowsPerWave = BM_MAX_ROWS / kSearchWaves;  // 4: row i is sorted by wave i % 16
+constexpr int kRankChunk = BM_MAX_ROWS / kSearchWaves;        // rows whose values one wave compares with everybody's
+constexpr int kByzWave = 1;
 
 __host__ __device__ inline int search_ld(int h) { return h | 1; }  // odd row length: lane i walks row i without bank conflicts
-// LDS: UU[h][ld] (<u_i, u_j>), SC[64] (scores), Q[64] (sorted dq), Y[2] (objective), PART / PARTQ[16][64] (partial ranks
-// of the scores / of the dq, int)
+__host__ __device__ inline int search_ldu(int h) { return attack_row_span(h) + 1; }  // UU rows: read in groups of eight, odd as well
+// LDS: UU[h][ldu] (<u_i, u_j>), HS[h][ld] (row i's distances to the other honest rows, ascending), SC[64] (scores), Q[64]
+// (sorted dq), Y[2] (objective), PART / PARTQ[16][64] (partial ranks of the scores / of the dq, int)
 __host__ __device__ inline size_t search_lds_bytes(int h) {
-  return (size_t)(h * search_ld(h) + 2 * BM_MAX_ROWS + 2) * sizeof(double) + (size_t)2 * kSearchWaves * BM_MAX_ROWS * sizeof(int);
+  return (size_t)(h * search_ldu(h) + h * search_ld(h) + 2 * BM_MAX_ROWS + 2) * sizeof(double) +
+         (size_t)2 * kSearchWaves * BM_MAX_ROWS * sizeof(int);
 }
 
 __device__ __forceinline__ double lane_value(double v, int src) {  // lane `src` (wave-uniform) of v, through v_readlane
@@ -74,33 +72,32 @@ __device__ __forceinline__ int rank_share(double v, int lane, int first, int cou
 
 // The sum of one value per lane over all 64 lanes in a FIXED order every lane can follow at once: v <- v + (v of lane
 // ^ 1), then ^ 2, ^ 4, ... ^ 32 (fp64 addition commutes, so both partners of an exchange form the same sum and all lanes
-// end with the same bits).  The host form adds in the same order (linesearch.cpp, butterfly_sum).
+// end with the same bits).  The host form adds in the same order (search_core.h, butterfly_order_sum).
 __device__ __forceinline__ double butterfly_sum(double v) {
 #pragma unroll
   for (int s = 1; s < 64; s <<= 1) v = v + __shfl_xor(v, s, 64);
   return v;
 }
 
-// s[r] = ((0 + val[r]@lane 0) + val[r]@lane 1) + ... over the first `take` lanes, for the NR rows of a wave together
-// (NR independent chains of fp64 additions: the chains hide one another's latency).
-template <int NR>
-__device__ __forceinline__ void fold_lanes(const double (&val)[kRowsPerWave], int take, double (&s)[kRowsPerWave]) {
-#pragma unroll
-  for (int r = 0; r < NR; ++r) s[r] = 0.0;
-  for (int u = 0; u < take; ++u) {
-#pragma unroll
-    for (int r = 0; r < NR; ++r) s[r] += lane_value(val[r], u);
-  }
-}
-
+// TRACE (measurement only, BM_SEARCH_TRACE=1 in the environment at the call): waves 0 and 1 also write the shader clock
+// at the phase boundaries of every candidate behind the results — out[1 + 2 evals + (2 e + wave) * kTraceSlots + slot],
+// cycles since the kernel started (scripts/search_kernel_probe.py prints them).
+constexpr int kTraceSlots = 12;
+template <bool TRACE>
 __global__ __launch_bounds__(kSearchBlock) void attack_search_kernel(const double* __restrict__ ext, int h, int k, int f,
                                                                      int rule, int m, int evals, int negative,
                                                                      double* __restrict__ out) {
+  const unsigned long long clock0 = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
   extern __shared__ double search_smem[];
-  const int n = h + k, e = h + 2, tid = threadIdx.x, ld = search_ld(h);
+  const int n = h + k, e = h + 2, tid = threadIdx.x, ld = search_ld(h), ldu = search_ldu(h);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  auto stamp = [&](int ev, int slot) {
+    if (TRACE && lane == 0 && wave <= kByzWave)
+      out[1 + 2 * evals + (2 * ev + wave) * kTraceSlots + slot] = (double)(__builtin_amdgcn_s_memtime() - clock0);
+  };
   double* const UU = search_smem;
-  double* const SC = UU + h * ld;
+  double* const HS = UU + h * ldu;
+  double* const SC = HS + h * ld;
   double* const Q = SC + BM_MAX_ROWS;
   double* const Y = Q + BM_MAX_ROWS;
   int* const PART = reinterpret_cast<int*>(Y + 2);
@@ -109,52 +106,53 @@ __global__ __launch_bounds__(kSearchBlock) void attack_search_kernel(const doubl
   const double kInf = __builtin_inf();
   const bool krum = rule == BM_RULE_KRUM;
 
-  // ---- once: <u_i, u_j> (everybody); on the row waves every honest row's distances to the other honest rows in
-  // ascending order, one per lane (a 64-lane bitonic network per row, the rows of a wave going through it together),
-  // and the same values k lanes further up (the part of the merged sequence behind the k copies of the candidate)
+  // ---- once: <u_i, u_j> (everybody), and every honest row's distances to the other honest rows in ascending order (a
+  // 64-lane bitonic network per row, the four rows of a wave going through it together so that their exchanges overlap)
   for (int p = tid; p < h * h; p += kSearchBlock) {
     const int i = p / h, j = p - i * h;
-    UU[i * ld + j] = attack_uu(ext[i * e + h], ext[j * e + h], ext[i * e + j], i == j);
+    UU[i * ldu + j] = attack_uu(ext[i * e + h], ext[j * e + h], ext[i * e + j], i == j);
   }
-  double sorted[kRowsPerWave], shifted[kRowsPerWave], row_a[kRowsPerWave], row_w[kRowsPerWave];
-  int my_rows = 0;
+  if (krum) {
+    double sorted[kSortRowsPerWave];
 #pragma unroll
-  for (int r = 0; r < kRowsPerWave; ++r) {
-    const int i = wave + r * kRowWaves;
-    const bool mine = wave < kRowWaves && i < h;  // (wave-uniform)
-    my_rows += mine ? 1 : 0;
-    sorted[r] = (mine && lane < h && lane != i) ? rank_distance(ext[i * e + lane]) : kInf;
-    row_a[r] = mine ? ext[i * e + h] : 0.0;
-    row_w[r] = mine ? attack_w(row_a[r], c, ext[i * e + h + 1]) : 0.0;
-  }
-  if (wave < kRowWaves && krum) {
+    for (int r = 0; r < kSortRowsPerWave; ++r) {
+      const int i = wave + r * kSearchWaves;
+      sorted[r] = (i < h && lane < h && lane != i) ? rank_distance(ext[i * e + lane]) : kInf;
+    }
 #pragma unroll
     for (int kk = 2; kk <= 64; kk <<= 1) {
 #pragma unroll
       for (int j = kk >> 1; j > 0; j >>= 1) {
         const bool keep_min = ((lane & kk) == 0) == ((lane & j) == 0);
 #pragma unroll
-        for (int r = 0; r < kRowsPerWave; ++r) {
+        for (int r = 0; r < kSortRowsPerWave; ++r) {
           const double o = __shfl_xor(sorted[r], j, 64);
           sorted[r] = keep_min ? __builtin_fmin(sorted[r], o) : __builtin_fmax(sorted[r], o);
         }
       }
     }
-  }
 #pragma unroll
-  for (int r = 0; r < kRowsPerWave; ++r) shifted[r] = __shfl(sorted[r], lane >= k ? lane - k : 0, 64);
-  // wave 15: lane j is honest row j as the Byzantine row sees it; wave 0: lane i is honest row i in the objective
+    for (int r = 0; r < kSortRowsPerWave; ++r) {
+      const int i = wave + r * kSearchWaves;
+      if (i < h && lane < h - 1) HS[i * ld + lane] = sorted[r];
+    }
+  }
+  // lane i < h is honest row i (its dq in every wave, its score and its part of the objective in wave 0)
   const bool honest = lane < h;
   const double a = honest ? ext[lane * e + h] : 0.0;
   const double w = honest ? attack_w(a, c, ext[lane * e + h + 1]) : 0.0;
-  const double* const uu = UU + (honest ? lane : 0) * ld;
+  const double* const uu = UU + (honest ? lane : 0) * ldu;
+  const double* const hs = HS + (honest ? lane : 0) * ld;
   int take = n - f - 1;  // krum.py:59-60
   take = take > n - 1 ? n - 1 : take;
   take = take < 0 ? 0 : take;
   const int count = krum ? m : n;
+  const int hm1 = h - 1, last = hm1 > 0 ? hm1 - 1 : 0, span = attack_row_span(h);
+  const unsigned long long honest_rows = (h >= 64) ? ~0ull : ((1ull << h) - 1ull);
   unsigned long long selected = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);  // Average: every row, at every candidate
   double row = 0.0;
   __syncthreads();
+  stamp(0, 11);
 
   bm_search cur;
   cursor_begin(&cur, 0.0, 1.0, 0.8);  // the attack's call: tools.line_maximize(eval_factor, evals=evals)
@@ -162,54 +160,68 @@ __global__ __launch_bounds__(kSearchBlock) void attack_search_kernel(const doubl
     cursor_propose(&cur);
     const double x = cur.probe;
     const double t = negative ? -x : x;  // identical.py:70-71
+    stamp(ev, 0);
     if (krum) {
-      // the Byzantine row needs the dq_j = |h_j - byz(t)| in ascending order: every wave forms them (lane j: row j) and
-      // counts its four rows' share of their stable rank; the sixteenth wave adds the shares after the barrier
-      const double dq_lane = honest ? rank_distance(attack_candidate_sq(a, w, c, t)) : kInf;
+      // dq_j = |h_j - byz(t)| in lane j of every wave.  The Byzantine row needs them in ascending order: every wave counts
+      // its four rows' share of their stable rank, wave 1 adds the shares after the barrier.
+      const double dq = honest ? rank_distance(attack_candidate_sq(a, w, c, t)) : kInf;
       if (k > 0) {
-        PARTQ[wave * BM_MAX_ROWS + lane] = rank_share(dq_lane, lane, wave * kRankChunk, h);
+        PARTQ[wave * BM_MAX_ROWS + lane] = rank_share(dq, lane, wave * kRankChunk, h);
         __syncthreads();
       }
-      if (wave < kRowWaves) {
-        // honest row i: its h - 1 sorted honest distances merged with k copies of dq = |h_i - byz(t)| — `below` of them
-        // come first — as one value per lane, then the `take` smallest added in ascending order
-        double val[kRowsPerWave], s[kRowsPerWave];
+      stamp(ev, 1);
+      if (wave == 0) {
+        // honest row i (lane i): its h - 1 sorted honest distances merged with k copies of dq — `below` of them come
+        // first (a binary search of the row: six dependent LDS reads) — and the `take` smallest added in ascending order
+        // (loads in groups of eight at clamped indices, every one unconditional: they leave together and the additions
+        // follow; a conditional load costs a branch and a full LDS latency per element)
+        int below = 0, len = hm1;
 #pragma unroll
-        for (int r = 0; r < kRowsPerWave; ++r) {
-          const double dq = rank_distance(attack_candidate_sq(row_a[r], row_w[r], c, t));
-          const int below = __builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < h - 1 && sorted[r] < dq));
-          val[r] = (lane < below) ? sorted[r] : ((lane < below + k) ? dq : shifted[r]);
+        for (int it = 0; it < 6; ++it) {  // (h - 1 <= 63 values)
+          const int half = len >> 1, mid = below + half;
+          const double v = hs[mid < hm1 ? mid : last];
+          const bool right = len > 0 && v < dq;
+          below = right ? mid + 1 : below;
+          len = right ? len - half - 1 : half;
         }
-        switch (my_rows) {
-          case 1: fold_lanes<1>(val, take, s); break;
-          case 2: fold_lanes<2>(val, take, s); break;
-          case 3: fold_lanes<3>(val, take, s); break;
-          case 4: fold_lanes<4>(val, take, s); break;
-          case 5: fold_lanes<5>(val, take, s); break;
-          default: break;
-        }
-        if (lane == 0) {
+        stamp(ev, 2);
+        double score = 0.0;
+        for (int u0 = 0; u0 < take; u0 += 8) {
+          double g[8];
+          bool from_row[8];
 #pragma unroll
-          for (int r = 0; r < kRowsPerWave; ++r)
-            if (r < my_rows) SC[wave + r * kRowWaves] = s[r];
+          for (int q = 0; q < 8; ++q) {
+            const int u = u0 + q;
+            from_row[q] = (u < below) || (u >= below + k);
+            int idx = (u < below) ? u : u - k;  // 0 <= idx < h - 1 whenever it is used: u < take <= h + k - 1
+            idx = (from_row[q] && u < take) ? idx : 0;
+            g[q] = hs[idx];
+          }
+#pragma unroll
+          for (int q = 0; q < 8; ++q)  // (beyond `take` the addend is 0.0: the distances are >= +0, so x + 0.0 is x bit for
+            score += (u0 + q < take) ? (from_row[q] ? g[q] : dq) : 0.0;  // bit, and the select stays off the chain of additions)
         }
-      } else if (k > 0) {
+        if (honest) SC[lane] = score;
+      } else if (wave == kByzWave && k > 0) {
         // the Byzantine row (all k are the same row): k - 1 zeros (its copies), then the dq in ascending order
         int place = 0;
 #pragma unroll
         for (int q = 0; q < kSearchWaves; ++q) place += PARTQ[q * BM_MAX_ROWS + lane];
-        if (honest) Q[place] = dq_lane;
+        if (honest) Q[place] = dq;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const double ascending = honest ? Q[lane] : 0.0;
+        stamp(ev, 2);
         const int zeros = (k - 1 < take) ? k - 1 : take;
         const int rest = take - zeros;
         double sb = 0.0;
-        for (int u = 0; u < rest; ++u) sb += lane_value(ascending, u);
+#pragma unroll 8
+        for (int u = 0; u < rest; ++u) sb += Q[u];  // (every lane the same sum: broadcast reads)
         if (lane < k) SC[h + lane] = sb;
       }
+      stamp(ev, 3);
       __syncthreads();
+      stamp(ev, 4);
       // stable argsort of the n scores (Python's sort, krum.py:62): wave c counts, for every row, how many of the rows
       // 4c .. 4c+3 come before it; wave 0 adds the sixteen counts
       if (lane < n) {
@@ -224,6 +236,7 @@ __global__ __launch_bounds__(kSearchBlock) void attack_search_kernel(const doubl
         PART[wave * BM_MAX_ROWS + lane] = before;
       }
       __syncthreads();
+      stamp(ev, 5);
     }
     if (wave == 0) {
       if (krum) {
@@ -232,20 +245,33 @@ __global__ __launch_bounds__(kSearchBlock) void attack_search_kernel(const doubl
         for (int q = 0; q < kSearchWaves; ++q) rank += PART[q * BM_MAX_ROWS + (lane < n ? lane : 0)];
         selected = __builtin_amdgcn_ballot_w64(lane < n && rank < m);  // krum.py:78-80: the m best scores
       }
+      stamp(ev, 6);
       if (krum || ev == 0) {
-        // row sums of <u_i, u_j> over the selected honest j, in index order (loads in groups of eight at clamped
-        // indices, every one unconditional: they leave together and the arithmetic follows)
-        row = 0.0;
-        for (int j0 = 0; j0 < h; j0 += 8) {
-          double g[8];
+        // row sums of <u_i, u_j> over the selected honest j in index order, as attack_row_sum (search_core.h) forms them:
+        // every column of the row's span adds its value or 0.0 (the loads of a group of eight leave together)
+        // — in two halves of the span, two chains of additions in flight
+        const unsigned long long on = selected & honest_rows;
+        const int half = span >> 1;  // (a multiple of four)
+        double lo = 0.0, hi = 0.0;
+        for (int j0 = 0; j0 < half; j0 += 4) {
+          double g[4], gh[4];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) g[q] = uu[(j0 + q < h) ? j0 + q : 0];
+          for (int q = 0; q < 4; ++q) {
+            g[q] = uu[j0 + q];
+            gh[q] = uu[half + j0 + q];
+          }
 #pragma unroll
-          for (int q = 0; q < 8; ++q) row = (j0 + q < h && ((selected >> (j0 + q)) & 1ull)) ? row + g[q] : row;
+          for (int q = 0; q < 4; ++q) {
+            lo += ((on >> (j0 + q)) & 1ull) ? g[q] : 0.0;
+            hi += ((on >> (half + j0 + q)) & 1ull) ? gh[q] : 0.0;
+          }
         }
+        row = lo + hi;
       }
-      const bool on = honest && ((selected >> lane) & 1ull);
-      const double quad = butterfly_sum(on ? row : 0.0), lin = butterfly_sum(on ? w : 0.0);
+      stamp(ev, 7);
+      const bool mine = honest && ((selected >> lane) & 1ull);
+      const double quad = butterfly_sum(mine ? row : 0.0), lin = butterfly_sum(mine ? w : 0.0);
+      stamp(ev, 8);
       const int kb = __builtin_popcountll(h >= 64 ? 0ull : (selected >> h));
       const double y = attack_objective_value(quad, lin, kb, t, c, count);
       if (lane == 0) {
@@ -253,9 +279,11 @@ __global__ __launch_bounds__(kSearchBlock) void attack_search_kernel(const doubl
         out[2 + 2 * ev] = y;
         Y[0] = y;
       }
+      stamp(ev, 9);
     }
     __syncthreads();
     cursor_report(&cur, Y[0]);
+    stamp(ev, 10);
   }
   if (tid == 0) out[0] = cur.best_x;
 }
@@ -273,11 +301,14 @@ extern "C" int bm_attack_line_search_device(const double* ext, int h, int k, int
   } else if (rule != BM_RULE_AVERAGE) {
     return BM_EINVAL;  // Brute: the host form (bm_attack_line_search)
   }
-  const size_t lds = search_lds_bytes(h);  // (at most 62 * 63 * 8 + 5 KB = 36 KB)
-  const int rc = lds_opt_in(reinterpret_cast<const void*>(attack_search_kernel), lds, 0);
+  const size_t lds = search_lds_bytes(h);  // (39 honest rows: 35 KB; 64: 80 KB, behind the opt-in)
+  const char* trace_env = getenv("BM_SEARCH_TRACE");
+  const bool trace = trace_env != nullptr && trace_env[0] == '1';  // (the caller then holds 2 * kTraceSlots more doubles per candidate)
+  auto kernel = trace ? attack_search_kernel<true> : attack_search_kernel<false>;
+  const int rc = lds_opt_in(reinterpret_cast<const void*>(kernel), lds, 0);
   if (rc != 0) return rc;
-  hipLaunchKernelGGL(attack_search_kernel, dim3(1), dim3(kSearchBlock), lds, static_cast<hipStream_t>(stream), ext, h,
-                     k, f, rule, m, evals, negative ? 1 : 0, out);
+  hipLaunchKernelGGL(kernel, dim3(1), dim3(kSearchBlock), lds, static_cast<hipStream_t>(stream), ext, h, k, f, rule, m, evals,
+                     negative ? 1 : 0, out);
   BM_LAUNCH_CHECK();
   return 0;
 }

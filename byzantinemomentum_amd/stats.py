@@ -7,6 +7,7 @@ products; results stay on the device until the caller asks for Python floats (on
 """
 
 import ctypes
+import os
 import math
 
 import torch
@@ -335,7 +336,10 @@ def attack_search_device(ext, h, k, f, rule, evals=16, negative=False, m=None):
   if not isinstance(evals, int) or evals < 1:
     _lib.check(_lib.EINVAL, "attack_search_device (evals must be a positive integer)")
   lib = _lib.load()
-  out = torch.empty(1 + 2 * evals, dtype=torch.float64, device=ext.device)
+  # (BM_SEARCH_TRACE=1, measurement only: the kernel appends 24 phase timestamps per candidate behind the results)
+  extra = 24 * evals if os.environ.get("BM_SEARCH_TRACE", "") == "1" else 0
+  out = torch.zeros(1 + 2 * evals + extra, dtype=torch.float64, device=ext.device) if extra else \
+      torch.empty(1 + 2 * evals, dtype=torch.float64, device=ext.device)
   with torch.cuda.device(ext.device):
     _lib.check(lib.bm_attack_line_search_device(_ptr(ext), h, k, f, _lib.RULE_IDS[rule], m or 0, evals,
                                                 1 if negative else 0, _ptr(out), gars._stream(ext.device)),

@@ -134,6 +134,11 @@ case $name in
     for D in 11173962 36546980; do D=$D timeout 600 python scripts/step_search_probe.py 2>&1 | grep -v amdgpu.ids; done > $out/step_search.txt; cat $out/step_search.txt
     ( time timeout 2400 python -m pytest tests -m gpu -x -q ) > $out/pytest_gpu.log 2>&1; tail -5 $out/pytest_gpu.log
     ;;
+  searchv5)   # parity of the device search, then the kernel alone with its phase trace
+    timeout 900 python -m pytest tests/test_gpu_search_device.py -m gpu -x -q > $out/pytest_search_device.log 2>&1; tail -5 $out/pytest_search_device.log
+    timeout 300 python scripts/search_kernel_probe.py 2>&1 | grep -v amdgpu.ids > $out/search_kernel_probe.txt; cat $out/search_kernel_probe.txt
+    timeout 600 python scripts/search_forms_probe.py 2>&1 | grep -v amdgpu.ids > $out/search_forms.txt; grep "^rep" $out/search_forms.txt | cut -c1-600
+    ;;
   searchprobe)   # the search kernel alone: warm / cold, 1-64 evaluations
     timeout 300 python scripts/search_kernel_probe.py 2>&1 | grep -v amdgpu.ids > $out/search_kernel_probe.txt; cat $out/search_kernel_probe.txt
     ;;

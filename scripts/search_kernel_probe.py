@@ -42,3 +42,21 @@ for rule_evals in (16, 1, 4, 16, 64):
   for cold in (False, True):
     each = timed(rule_evals, cold)
     print(f"evals={rule_evals:3d} {'behind a 1 GB fill' if cold else 'back to back      '}: " + " ".join(f"{v:7.1f}" for v in each) + " us", flush=True)
+
+# Phase timestamps of one traced launch (BM_SEARCH_TRACE=1: csrc/search_device.hip, attack_search_kernel<true>)
+os.environ["BM_SEARCH_TRACE"] = "1"
+evals = 16
+for _ in range(2):
+  out = bm.stats.attack_search_device(sq, h, k, f, "krum", evals=evals)
+torch.cuda.synchronize()
+tr = out[1 + 2 * evals:].view(evals, 2, 12).cpu()
+names = ["propose", "dq+share+B0", "bin. search", "fold", "B1", "partials+B2", "rank sum", "row sums", "butterfly", "objective", "B3+report"]
+print("wave 0: cycles since the previous stamp (2.4 GHz), per candidate; last column = the candidate's total")
+print("        " + " ".join(f"{n[:11]:>11s}" for n in names[1:]) + "       total |  wave 1 (Byzantine row) done")
+for e in range(evals):
+  w0 = tr[e, 0, :11].tolist()
+  deltas = [w0[i] - w0[i - 1] for i in range(1, 11)]
+  w15 = tr[e, 1, 3].item() - w0[0]
+  print(f"  e={e:2d}  " + " ".join(f"{v:11.0f}" for v in deltas) + f" {w0[10] - w0[0]:11.0f} | {w15:11.0f}")
+print(f"first candidate starts {tr[0, 0, 0].item():.0f} cycles into the kernel (the set-up)")
+os.environ["BM_SEARCH_TRACE"] = "0"
