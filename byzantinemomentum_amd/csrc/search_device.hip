@@ -41,12 +41,13 @@ constexpr int kSortRowsPerWave = BM_MAX_ROWS / kSearchWaves;  // 4: row i is sor
 constexpr int kRankChunk = BM_MAX_ROWS / kSearchWaves;        // rows whose values one wave compares with everybody's
 constexpr int kByzWave = 1;
 
-__host__ __device__ inline int search_ld(int h) { return h | 1; }  // odd row length: lane i walks row i without bank conflicts
-__host__ __device__ inline int search_ldu(int h) { return attack_row_span(h) + 1; }  // UU rows: read in groups of eight, odd as well
-// LDS: UU[h][ldu] (<u_i, u_j>), HS[h][ld] (row i's distances to the other honest rows, ascending), SC[64] (scores), Q[64]
+// Row length of UU and HS: the rows are read in groups of eight (span = h rounded up), and odd, so that lane i walking row i
+// meets no bank conflict.
+__host__ __device__ inline int search_ld(int h) { return attack_row_span(h) + 1; }
+// LDS: UU[h][ld] (<u_i, u_j>), HS[h][ld] (row i's distances to the other honest rows, ascending), SC[64] (scores), Q[64]
 // (sorted dq), Y[2] (objective), PART / PARTQ[16][64] (partial ranks of the scores / of the dq, int)
 __host__ __device__ inline size_t search_lds_bytes(int h) {
-  return (size_t)(h * search_ldu(h) + h * search_ld(h) + 2 * BM_MAX_ROWS + 2) * sizeof(double) +
+  return (size_t)(2 * h * search_ld(h) + 2 * BM_MAX_ROWS + 2) * sizeof(double) +
          (size_t)2 * kSearchWaves * BM_MAX_ROWS * sizeof(int);
 }
 
@@ -70,6 +71,23 @@ __device__ __forceinline__ int rank_share(double v, int lane, int first, int cou
   return before;
 }
 
+// The largest v (0 <= v <= 63) over the lanes of the wave, as a wave-uniform number: `limit` at once when some lane has
+// reached it (the common case of the stretches below), else bit by bit with six ballots.
+__device__ __forceinline__ int longest(int v, int limit) {
+  if (__builtin_amdgcn_ballot_w64(v >= limit) != 0ull) return limit;
+  unsigned long long among = ~0ull;
+  int most = 0;
+#pragma unroll
+  for (int bit = 5; bit >= 0; --bit) {
+    const unsigned long long with = __builtin_amdgcn_ballot_w64(((v >> bit) & 1) != 0) & among;
+    if (with != 0ull) {
+      among = with;
+      most |= 1 << bit;
+    }
+  }
+  return most;
+}
+
 // The sum of one value per lane over all 64 lanes in a FIXED order every lane can follow at once: v <- v + (v of lane
 // ^ 1), then ^ 2, ^ 4, ... ^ 32 (fp64 addition commutes, so both partners of an exchange form the same sum and all lanes
 // end with the same bits).  The host form adds in the same order (search_core.h, butterfly_order_sum).
@@ -89,14 +107,14 @@ __global__ __launch_bounds__(kSearchBlock) void attack_search_kernel(const doubl
                                                                      double* __restrict__ out) {
   const unsigned long long clock0 = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
   extern __shared__ double search_smem[];
-  const int n = h + k, e = h + 2, tid = threadIdx.x, ld = search_ld(h), ldu = search_ldu(h);
+  const int n = h + k, e = h + 2, tid = threadIdx.x, ld = search_ld(h);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   auto stamp = [&](int ev, int slot) {
     if (TRACE && lane == 0 && wave <= kByzWave)
       out[1 + 2 * evals + (2 * ev + wave) * kTraceSlots + slot] = (double)(__builtin_amdgcn_s_memtime() - clock0);
   };
   double* const UU = search_smem;
-  double* const HS = UU + h * ldu;
+  double* const HS = UU + h * ld;
   double* const SC = HS + h * ld;
   double* const Q = SC + BM_MAX_ROWS;
   double* const Y = Q + BM_MAX_ROWS;
@@ -110,7 +128,7 @@ __global__ __launch_bounds__(kSearchBlock) void attack_search_kernel(const doubl
   // 64-lane bitonic network per row, the four rows of a wave going through it together so that their exchanges overlap)
   for (int p = tid; p < h * h; p += kSearchBlock) {
     const int i = p / h, j = p - i * h;
-    UU[i * ldu + j] = attack_uu(ext[i * e + h], ext[j * e + h], ext[i * e + j], i == j);
+    UU[i * ld + j] = attack_uu(ext[i * e + h], ext[j * e + h], ext[i * e + j], i == j);
   }
   if (krum) {
     double sorted[kSortRowsPerWave];
@@ -141,7 +159,7 @@ __global__ __launch_bounds__(kSearchBlock) void attack_search_kernel(const doubl
   const bool honest = lane < h;
   const double a = honest ? ext[lane * e + h] : 0.0;
   const double w = honest ? attack_w(a, c, ext[lane * e + h + 1]) : 0.0;
-  const double* const uu = UU + (honest ? lane : 0) * ldu;
+  const double* const uu = UU + (honest ? lane : 0) * ld;
   const double* const hs = HS + (honest ? lane : 0) * ld;
   int take = n - f - 1;  // krum.py:59-60
   take = take > n - 1 ? n - 1 : take;
@@ -185,21 +203,33 @@ __global__ __launch_bounds__(kSearchBlock) void attack_search_kernel(const doubl
           len = right ? len - half - 1 : half;
         }
         stamp(ev, 2);
+        // the merged sequence in its three stretches: b1 values of the row, c2 copies of dq, c3 more values of the row
+        // from index b1 on (c3 > 0 only when b1 == below).  Every lane walks every stretch up to the longest one in the
+        // wave and adds 0.0 beyond its own length: the distances are >= +0, so x + 0.0 is x bit for bit, and an element
+        // costs a read at an immediate offset, a compare, a select and the addition (the one-loop form with its index
+        // arithmetic per element: ~18 instructions, 4 000 cycles for 38 elements on a wave that issues one every 5-6).
+        const int b1 = below < take ? below : take;
+        const int c2 = (take - b1 < k) ? take - b1 : k;
+        const int c3 = take - b1 - c2;
+        const int most1 = longest(b1, take), most3 = longest(c3, take);
         double score = 0.0;
-        for (int u0 = 0; u0 < take; u0 += 8) {
+        for (int u0 = 0; u0 < most1; u0 += 8) {
           double g[8];
-          bool from_row[8];
 #pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            const int u = u0 + q;
-            from_row[q] = (u < below) || (u >= below + k);
-            int idx = (u < below) ? u : u - k;  // 0 <= idx < h - 1 whenever it is used: u < take <= h + k - 1
-            idx = (from_row[q] && u < take) ? idx : 0;
-            g[q] = hs[idx];
-          }
+          for (int q = 0; q < 8; ++q) g[q] = hs[u0 + q];
 #pragma unroll
-          for (int q = 0; q < 8; ++q)  // (beyond `take` the addend is 0.0: the distances are >= +0, so x + 0.0 is x bit for
-            score += (u0 + q < take) ? (from_row[q] ? g[q] : dq) : 0.0;  // bit, and the select stays off the chain of additions)
+          for (int q = 0; q < 8; ++q) score += (u0 + q < b1) ? g[q] : 0.0;
+        }
+        if (__builtin_amdgcn_ballot_w64(c2 > 0) != 0ull) {
+          for (int u = 0; u < k; ++u) score += (u < c2) ? dq : 0.0;
+        }
+        const double* const hs3 = hs + b1;
+        for (int u0 = 0; u0 < most3; u0 += 8) {  // (a group may run past the row's end: into the next row or the tables behind, unused)
+          double g[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) g[q] = hs3[u0 + q];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) score += (u0 + q < c3) ? g[q] : 0.0;
         }
         if (honest) SC[lane] = score;
       } else if (wave == kByzWave && k > 0) {
@@ -301,7 +331,7 @@ extern "C" int bm_attack_line_search_device(const double* ext, int h, int k, int
   } else if (rule != BM_RULE_AVERAGE) {
     return BM_EINVAL;  // Brute: the host form (bm_attack_line_search)
   }
-  const size_t lds = search_lds_bytes(h);  // (39 honest rows: 35 KB; 64: 80 KB, behind the opt-in)
+  const size_t lds = search_lds_bytes(h);  // (39 honest rows: 35 KB; 64: 75 KB, behind the opt-in)
   const char* trace_env = getenv("BM_SEARCH_TRACE");
   const bool trace = trace_env != nullptr && trace_env[0] == '1';  // (the caller then holds 2 * kTraceSlots more doubles per candidate)
   auto kernel = trace ? attack_search_kernel<true> : attack_search_kernel<false>;

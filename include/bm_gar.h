@@ -430,7 +430,9 @@ int bm_attack_line_search(const double* ext, int h, int k, int f, int rule, int 
  * is the host form's): ext is the DEVICE matrix where bm_pairwise_sqdist left it, one workgroup evaluates the `evals`
  * candidates (csrc/search_device.hip) and writes out[0] = the factor, out[1 + 2e], out[2 + 2e] = abscissa and objective
  * of evaluation e (out: DEVICE, 1 + 2 * evals doubles).  Same candidates and the same bits as the host form; no copy,
- * no synchronisation — the factor is consumed where it is by bm_multi_fma3_bdev. */
+ * no synchronisation — the factor is consumed where it is by bm_multi_fma3_bdev.  (MEASUREMENT ONLY: with
+ * BM_SEARCH_TRACE=1 in the environment the kernel also writes 24 phase timestamps per evaluation behind the results and
+ * `out` must hold 1 + 26 * evals doubles; scripts/search_kernel_probe.py.) */
 int bm_attack_line_search_device(const double* ext, int h, int k, int f, int rule, int m, int evals, int negative,
                                  double* out, void* stream);
 /* The ranking bm_krum_rank(mode, m) would give for honests + [avg + t*att] * k, from the same scalars (order_out: n
