@@ -139,6 +139,19 @@ case $name in
     timeout 300 python scripts/search_kernel_probe.py 2>&1 | grep -v amdgpu.ids > $out/search_kernel_probe.txt; cat $out/search_kernel_probe.txt
     timeout 600 python scripts/search_forms_probe.py 2>&1 | grep -v amdgpu.ids > $out/search_forms.txt; grep "^rep" $out/search_forms.txt | cut -c1-600
     ;;
+  gcprobe)   # are the bench's 40-130 ms stalls the Python garbage collector?
+    timeout 600 python scripts/gc_pause_probe.py 2>&1 | grep -v amdgpu.ids > $out/gc_pause_probe.txt; cat $out/gc_pause_probe.txt | cut -c1-900
+    ;;
+  stallprobe)   # the one slow search in ten of the bench's first series: where does it wait?
+    timeout 600 python scripts/search_stall_probe.py 2>&1 | grep -v amdgpu.ids > $out/search_stall_probe.txt; cat $out/search_stall_probe.txt | cut -c1-700
+    timeout 600 python bench.py --no-cpu-baseline --no-traffic > $out/bench_quick.json 2> $out/bench_quick.err; python -c "import json; b=json.load(open('$out/bench_quick.json')); a=b['per_gar']['attack_search_c3_krum']; print('bench without the PMC children and the CPU baselines:', a['scalar_form_each_ms'], a['host_scalar_form_each_ms'])"
+    ;;
+  stallbench)   # which leg of the default bench run brings the slow search: the CPU baselines or the PMC children?
+    for flag in --no-traffic --no-cpu-baseline; do
+      timeout 900 python bench.py $flag > $out/bench$flag.json 2> $out/bench$flag.err
+      python -c "import json; b=json.load(open('$out/bench$flag.json')); a=b['per_gar']['attack_search_c3_krum']; print('bench $flag:', a['scalar_form_each_ms'], a['host_scalar_form_each_ms'])"
+    done
+    ;;
   searchprobe)   # the search kernel alone: warm / cold, 1-64 evaluations
     timeout 300 python scripts/search_kernel_probe.py 2>&1 | grep -v amdgpu.ids > $out/search_kernel_probe.txt; cat $out/search_kernel_probe.txt
     ;;
