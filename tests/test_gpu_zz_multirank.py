@@ -259,6 +259,29 @@ def _rank_body(rank, world, rendezvous, d, queue):
           g = got[key]
           assert (math.isnan(g) and math.isnan(val)) or abs(g - val) <= 1e-6 * max(abs(val), 1e-6), (gar, it, key, g, val)
         report[(gar, it)] = tuple(sorted((k, v) for k, v in got.items() if not math.isnan(v)))
+    # the same step with the attack's factor search (attacks/identical.py:67-77, the reference's default factor=-16): the
+    # distance pass over honests + [avg, avg + att] is all-reduced, then every rank searches on the device from the same
+    # (h+2)^2 scalars — the same candidates as the single-rank step, the same factor on every shard
+    if d <= 500000:
+      sharded = AggregationStep(N, F, F, gar="krum", momentum=0.9, dampening=0.9, nb_past=2, attack_evals=8, aggregator=agg)
+      single = AggregationStep(N, F, F, gar="krum", momentum=0.9, dampening=0.9, nb_past=2, attack_evals=8,
+                               aggregator=ShardedAggregator(local_only=True))
+      gen = torch.Generator().manual_seed(6)
+      origin = torch.randn(d, generator=gen)
+      for it in range(3):
+        base = 0.2 * torch.randn(d, generator=gen)
+        sampled = [base + (0.5 + 0.05 * i) * torch.randn(d, generator=gen) for i in range(N - F)]
+        got_def = sharded.run([g[lo:hi].to(DEV) for g in sampled], origin[lo:hi].to(DEV), origin[lo:hi].to(DEV))
+        want_def = single.run([g.to(DEV) for g in sampled], origin.to(DEV), origin.to(DEV))
+        assert isinstance(sharded._factor_now, torch.Tensor), "the sharded step must search on the device as well"
+        (got_f, got_tr), (want_f, want_tr) = (sharded.last_factor, sharded.last_search), (single.last_factor, single.last_search)
+        assert [x for x, _ in got_tr] == [x for x, _ in want_tr] and got_f == want_f, (it, got_tr, want_tr)
+        for (_, y), (_, yo) in zip(got_tr, want_tr):
+          assert abs(y - yo) <= 1e-6 * max(abs(yo), 1e-12), (it, y, yo)
+        scale = max(float(want_def.abs().max()), 1e-30)
+        if hi > lo:  # (an empty shard takes part in the exchange and the search, and has nothing to compare)
+          assert float((got_def - want_def[lo:hi]).abs().max()) <= 2e-6 * scale, it
+        report[("krum-search", it)] = (got_f, tuple(x for x, _ in got_tr))
     torch.cuda.synchronize()
     queue.put((rank, report))
     dist.barrier()
