@@ -877,6 +877,8 @@ def attack_search(bm, honests, n, f, d, evals=16, gar="krum"):
   pass over h+2 rows, then the sixteen candidates from its (h+2)^2 scalars: ON THE DEVICE by default,
   `scalar_form_ms`, the factor never leaves the GPU; on the host after a copy, `host_scalar_form_ms`, what rounds 2-5
   measured) and the reference's form (the rule on the vectors once per evaluation).
+  Against the other rules "auto" keeps the exploration's cursor in device memory (bm_search_device_next: the sixteen
+  evaluations are queued without a synchronisation; `host_scalar_form_ms` = the same evaluations driven from the host).
   Against the median (C2 shape): every candidate as the middle of (candidate, lo, hi), lo / hi being two order
   statistics of the honest rows formed once per search (the key stays `scalar_form_ms`), and the reference's form.
   Against Bulyan (C4 shape): every candidate ranked on the host from one distance pass, pass 2 alone on the vectors.
@@ -885,7 +887,7 @@ def attack_search(bm, honests, n, f, d, evals=16, gar="krum"):
   from byzantinemomentum_amd.step import AggregationStep
   avg, _, direction = bm.stats.stack_stats_async(honests, scale=1.0, attack="empire", direction=True)
   res = {"config": f"empire against {gar}, n={n}, f={f}, d={d}, {evals} evaluations, one GPU"}
-  modes = (("auto", 10), ("host", 10), ("generic", 3)) if gar in bm.stats.DEVICE_SEARCH_RULES else (("auto", 10), ("generic", 3))
+  modes = (("auto", 10), ("generic", 3)) if gar == "bulyan" else (("auto", 10), ("host", 10), ("generic", 3))  # (Bulyan: "auto" IS the host's cursor)
   for mode, reps in modes:
     runner = AggregationStep(n, f, f, gar=gar, attack_evals=evals, line_search=mode, nb_past=0)
     runner._search_factor(honests, avg, direction)

@@ -318,7 +318,43 @@ __global__ __launch_bounds__(kSearchBlock) void attack_search_kernel(const doubl
   if (tid == 0) out[0] = cur.best_x;
 }
 
+// The cursor of the exploration kept in DEVICE memory, for the searches whose candidates are evaluated by d-sized kernels
+// (median, trimmed mean, phocas, meamed, any rule): one lane takes the objective the last evaluation left on the device,
+// moves the cursor and leaves the next candidate's factor on the device, where the evaluation kernels read it
+// (bm_multi_fma3_bdev, bm_colwise_eval_tdev).  The host queues all the evaluations of a search without waiting for any.
+__global__ void search_cursor_kernel(bm_search* __restrict__ state, const double* __restrict__ y, int negative, int last,
+                                     double start, double delta, double ratio, double* __restrict__ t_out,
+                                     double* __restrict__ out) {
+  bm_search cur;
+  if (y == nullptr) {
+    cursor_begin(&cur, start, delta, ratio);
+  } else {
+    cur = *state;
+    out[2 + 2 * cur.evaluations] = y[0];
+    cursor_report(&cur, y[0]);
+  }
+  if (last) {
+    out[0] = cur.best_x;
+  } else {
+    cursor_propose(&cur);
+    out[1 + 2 * cur.evaluations] = cur.probe;
+    t_out[0] = negative ? -cur.probe : cur.probe;  // identical.py:70-71
+  }
+  *state = cur;
+}
+
 }  // namespace bm
+
+extern "C" int bm_search_device_next(void* state, const double* y, int negative, int last, double start, double delta,
+                                     double ratio, double* t_out, double* out, void* stream) {
+  using namespace bm;
+  if (state == nullptr || out == nullptr || (!last && t_out == nullptr) || (last && y == nullptr)) return BM_EINVAL;
+  if (y == nullptr && (!(start >= 0.0) || !(delta > 0.0) || !(ratio > 0.5 && ratio < 1.0))) return BM_EINVAL;
+  hipLaunchKernelGGL(search_cursor_kernel, dim3(1), dim3(1), 0, static_cast<hipStream_t>(stream),
+                     static_cast<bm_search*>(state), y, negative ? 1 : 0, last ? 1 : 0, start, delta, ratio, t_out, out);
+  BM_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" int bm_attack_line_search_device(const double* ext, int h, int k, int f, int rule, int m, int evals,
                                             int negative, double* out, void* stream) {

@@ -25,8 +25,12 @@ constexpr int kEvalMaxBlocks = 2048;
 
 template <int N, int OP, int VEC>
 __global__ __launch_bounds__(kColBlock) void colwise_eval_kernel(RowTable rows, int h, const float* __restrict__ avg,
-                                                                 const float* __restrict__ dir, float t, int64_t nvec,
+                                                                 const float* __restrict__ dir, float t_host,
+                                                                 const double* __restrict__ t_dev, int64_t nvec,
                                                                  int f, float inv_keep, double* __restrict__ partial) {
+  // the candidate's factor: the caller's number, or the one the device cursor left in device memory (bm_colwise_eval_tdev;
+  // rounded to fp32 as the host's conversion of the same number would be)
+  const float t = t_dev != nullptr ? (float)t_dev[0] : t_host;
   __shared__ double red[kColBlock / 64];
   float* const lds = nullptr;  // (column_rule needs no LDS)
   float acc = 0.0f;
@@ -83,7 +87,7 @@ __global__ __launch_bounds__(kEvalFinishThreads) void eval_finish_kernel(const d
 
 template <int N, int OP>
 static int launch_eval(const float* const* rows, int h, int64_t d, int f, const float* avg, const float* dir, float t,
-                       double* out, double* partial, hipStream_t s) {
+                       const double* t_dev, double* out, double* partial, hipStream_t s) {
   constexpr int kMaxVec = (N <= 28) ? 4 : 2;
   const int keep = (OP == BM_OP_TRMEAN) ? (N - 2 * f) : (N - f);
   const float inv_keep = 1.0f / (float)(keep > 0 ? keep : 1);
@@ -100,7 +104,7 @@ static int launch_eval(const float* const* rows, int h, int64_t d, int f, const 
     const int64_t nvec = d / vec;
     const int grid = stream_grid(nvec, kColBlock, kEvalMaxBlocks);
     auto kern = vec == 4 ? colwise_eval_kernel<N, OP, (kMaxVec >= 4 ? 4 : 2)> : colwise_eval_kernel<N, OP, 2>;
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(kColBlock), 0, s, tab, h, avg, dir, t, nvec, f, inv_keep, partial);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kColBlock), 0, s, tab, h, avg, dir, t, t_dev, nvec, f, inv_keep, partial);
     BM_LAUNCH_CHECK();
     nparts = grid;
     body = nvec * vec;
@@ -111,7 +115,7 @@ static int launch_eval(const float* const* rows, int h, int64_t d, int f, const 
     const int64_t rest = d - body;
     const int grid = (body == 0) ? stream_grid(rest, kColBlock, kEvalMaxBlocks) : 1;
     hipLaunchKernelGGL((colwise_eval_kernel<N, OP, 1>), dim3(grid), dim3(kColBlock), 0, s, tail, h, avg + body, dir + body,
-                       t, rest, f, inv_keep, partial + nparts);
+                       t, t_dev, rest, f, inv_keep, partial + nparts);
     BM_LAUNCH_CHECK();
     nparts += grid;
   }
@@ -123,11 +127,11 @@ static int launch_eval(const float* const* rows, int h, int64_t d, int f, const 
 
 template <int N>
 static int launch_eval_op(int op, const float* const* rows, int h, int64_t d, int f, const float* avg, const float* dir,
-                          float t, double* out, double* partial, hipStream_t s) {
+                          float t, const double* t_dev, double* out, double* partial, hipStream_t s) {
   switch (op) {
-    case BM_OP_TRMEAN: return launch_eval<N, BM_OP_TRMEAN>(rows, h, d, f, avg, dir, t, out, partial, s);
-    case BM_OP_PHOCAS: return launch_eval<N, BM_OP_PHOCAS>(rows, h, d, f, avg, dir, t, out, partial, s);
-    case BM_OP_MEAMED: return launch_eval<N, BM_OP_MEAMED>(rows, h, d, f, avg, dir, t, out, partial, s);
+    case BM_OP_TRMEAN: return launch_eval<N, BM_OP_TRMEAN>(rows, h, d, f, avg, dir, t, t_dev, out, partial, s);
+    case BM_OP_PHOCAS: return launch_eval<N, BM_OP_PHOCAS>(rows, h, d, f, avg, dir, t, t_dev, out, partial, s);
+    case BM_OP_MEAMED: return launch_eval<N, BM_OP_MEAMED>(rows, h, d, f, avg, dir, t, t_dev, out, partial, s);
     default: return BM_EINVAL;
   }
 }
@@ -140,8 +144,8 @@ extern "C" int bm_colwise_eval_supported(int op, int n) {
 
 extern "C" int64_t bm_colwise_eval_workspace_bytes(void) { return (int64_t)(2 * bm::kEvalMaxBlocks) * (int64_t)sizeof(double); }
 
-extern "C" int bm_colwise_eval(int op, const float* const* honests, int h, int copies, int64_t d, int f,
-                               const float* avg, const float* dir, float t, double* out, void* ws, void* stream) {
+static int colwise_eval_call(int op, const float* const* honests, int h, int copies, int64_t d, int f, const float* avg,
+                             const float* dir, float t, const double* t_dev, double* out, void* ws, void* stream) {
   using namespace bm;
   const int n = h + copies;
   if (honests == nullptr || out == nullptr || ws == nullptr || h < 1 || copies < 1 || n > BM_MAX_ROWS || d < 0 || f < 0 ||
@@ -150,8 +154,20 @@ extern "C" int bm_colwise_eval(int op, const float* const* honests, int h, int c
   hipStream_t s = static_cast<hipStream_t>(stream);
   double* partial = static_cast<double*>(ws);
   switch (n) {
-    case 11: return launch_eval_op<11>(op, honests, h, d, f, avg, dir, t, out, partial, s);
-    case 25: return launch_eval_op<25>(op, honests, h, d, f, avg, dir, t, out, partial, s);
-    default: return launch_eval_op<51>(op, honests, h, d, f, avg, dir, t, out, partial, s);
+    case 11: return launch_eval_op<11>(op, honests, h, d, f, avg, dir, t, t_dev, out, partial, s);
+    case 25: return launch_eval_op<25>(op, honests, h, d, f, avg, dir, t, t_dev, out, partial, s);
+    default: return launch_eval_op<51>(op, honests, h, d, f, avg, dir, t, t_dev, out, partial, s);
   }
+}
+
+extern "C" int bm_colwise_eval(int op, const float* const* honests, int h, int copies, int64_t d, int f,
+                               const float* avg, const float* dir, float t, double* out, void* ws, void* stream) {
+  return colwise_eval_call(op, honests, h, copies, d, f, avg, dir, t, nullptr, out, ws, stream);
+}
+
+extern "C" int bm_colwise_eval_tdev(int op, const float* const* honests, int h, int copies, int64_t d, int f,
+                                    const float* avg, const float* dir, const double* t_dev, double* out, void* ws,
+                                    void* stream) {
+  if (t_dev == nullptr) return BM_EINVAL;
+  return colwise_eval_call(op, honests, h, copies, d, f, avg, dir, 0.0f, t_dev, out, ws, stream);
 }

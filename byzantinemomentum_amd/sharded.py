@@ -199,6 +199,10 @@ class HipBackend:
   def attack_search_device(self, *args, **kwargs):
     return self.stats.attack_search_device(*args, **kwargs)
 
+  def device_search(self, device, evals, negative=False):
+    """The exploration's cursor in device memory (stats.DeviceSearch): the host queues every evaluation of a search."""
+    return self.stats.DeviceSearch(device, evals, negative)
+
   def multi_scale(self, ys, factors):
     return self.stats.multi_scale(ys, factors)
 

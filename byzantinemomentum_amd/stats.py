@@ -98,7 +98,8 @@ def colwise_eval_supported(rule, n):
 
 def colwise_eval(rule, honests, copies, f, h_avg, direction, t):
   """| RULE(honests + [h_avg + t * direction] * copies) - h_avg |^2 as a device fp64[1] tensor, the candidate and the
-  rule's output formed in registers only (bm_colwise_eval): one candidate of attacks/identical.py:67-77. No sync."""
+  rule's output formed in registers only (bm_colwise_eval): one candidate of attacks/identical.py:67-77. No sync.
+  t: a number, or the DEVICE float64 tensor a DeviceSearch left its candidate in (bm_colwise_eval_tdev)."""
   honests = list(honests)
   h, d, device = gars._validate(honests)
   gars._validate([h_avg, direction] + honests[:1])
@@ -106,10 +107,59 @@ def colwise_eval(rule, honests, copies, f, h_avg, direction, t):
   out = torch.empty(1, dtype=torch.float64, device=device)
   ws = gars._Scratch.get(device, "ws_eval", nbytes=int(lib.bm_colwise_eval_workspace_bytes()))
   with torch.cuda.device(device):
-    _lib.check(lib.bm_colwise_eval(_EVAL_OPS[rule], _lib.pointer_table(honests), h, copies, d, f, _ptr(h_avg),
-                                   _ptr(direction), float(t), _ptr(out), _ptr(ws), gars._stream(device)),
-               "bm_colwise_eval")
+    if isinstance(t, torch.Tensor):
+      if not (t.is_cuda and t.device == device and t.dtype == torch.float64 and t.numel() >= 1 and t.is_contiguous()):
+        raise gars.GarInputError("colwise_eval: a tensor t must be a contiguous float64 tensor on the vectors' device")
+      _lib.check(lib.bm_colwise_eval_tdev(_EVAL_OPS[rule], _lib.pointer_table(honests), h, copies, d, f, _ptr(h_avg),
+                                          _ptr(direction), _ptr(t), _ptr(out), _ptr(ws), gars._stream(device)),
+                 "bm_colwise_eval_tdev")
+    else:
+      _lib.check(lib.bm_colwise_eval(_EVAL_OPS[rule], _lib.pointer_table(honests), h, copies, d, f, _ptr(h_avg),
+                                     _ptr(direction), float(t), _ptr(out), _ptr(ws), gars._stream(device)),
+                 "bm_colwise_eval")
   return out
+
+
+class DeviceSearch:
+  """The cursor of tools.line_maximize (tools/misc.py:468-514) kept in device memory (bm_search_device_next): `next(y)`
+  takes the objective the last evaluation left on the device (None the first time) and returns the DEVICE float64[1]
+  tensor holding the next candidate's signed factor — hand it to multi_fma3 / colwise_eval as b / t —, `finish(y)`
+  returns the float64 device tensor [factor, x0, y0, x1, y1, ...] of attack_search_device.  Nothing is awaited: the
+  host queues the whole search."""
+
+  def __init__(self, device, evals, negative=False, start=0., delta=1., ratio=0.8):
+    if not isinstance(evals, int) or evals < 1:
+      _lib.check(_lib.EINVAL, "DeviceSearch (evals must be a positive integer)")
+    self.device, self.evals, self.negative, self.shape = device, evals, bool(negative), (start, delta, ratio)
+    self.state = torch.zeros(8, dtype=torch.float64, device=device)   # sizeof(bm_search) = 56 bytes
+    self.t = torch.zeros(1, dtype=torch.float64, device=device)
+    self.out = torch.zeros(1 + 2 * evals, dtype=torch.float64, device=device)
+    self.proposed = 0
+    self._keep = None
+
+  def _call(self, y, last):
+    if y is not None and not (isinstance(y, torch.Tensor) and y.is_cuda and y.device == self.device
+                              and y.dtype == torch.float64 and y.numel() >= 1):
+      raise gars.GarInputError("DeviceSearch: the objective must be a float64 tensor on the search's device")
+    lib = _lib.load()
+    self._keep = y  # (alive until the kernel that reads it has been queued behind its producer)
+    with torch.cuda.device(self.device):
+      _lib.check(lib.bm_search_device_next(_ptr(self.state), _ptr(y) if y is not None else None, 1 if self.negative else 0,
+                                           1 if last else 0, *self.shape, _ptr(self.t) if not last else None,
+                                           _ptr(self.out), gars._stream(self.device)), "bm_search_device_next")
+
+  def next(self, y=None):
+    if self.proposed >= self.evals or (y is None) != (self.proposed == 0):
+      raise RuntimeError("DeviceSearch.next: one objective per candidate, `evals` candidates")
+    self._call(y, False)
+    self.proposed += 1
+    return self.t
+
+  def finish(self, y):
+    if self.proposed != self.evals:
+      raise RuntimeError("DeviceSearch.finish: the search has candidates left")
+    self._call(y, True)
+    return self.out
 
 
 def study_stats(s_avg, h_avg, defense, byz, f_real, past_newest=None, curv=None, past_oldest=None, curv_mode=0, mu=0.0,

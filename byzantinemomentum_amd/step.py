@@ -52,9 +52,11 @@ class AggregationStep:
     default is -16): the factor is searched each step with tools.line_maximize's exploration
     (identical.py:67-77), `attack_negative` being the attack's `negative` argument during the search.
     line_search: "auto" evaluates the search from scalars when the rule allows it (krum, brute, average) — on the
-    device for krum / average (bm_attack_line_search_device: the step then has no synchronisation but `floats()`),
-    "host" the same scalars copied to the host (bm_attack_line_search, what "auto" does for brute), "generic" always
-    runs the rule on the device once per evaluation like the reference does."""
+    device for krum / average (bm_attack_line_search_device) — and otherwise keeps the exploration's cursor in device
+    memory (bm_search_device_next: median, trmean, phocas, meamed, aksel, cge ...): the step then has no synchronisation
+    but `floats()`; Bulyan (its candidates are ranked on the host) and Brute keep the host's cursor.  "host": the same
+    forms with scalars and cursor on the host (one synchronisation per evaluation).  "generic" always runs the rule on
+    the device once per evaluation like the reference does, the cursor on the host."""
     if gar not in _RULES:
       raise ValueError(f"unknown aggregation rule {gar!r}")
     if momentum_at not in ("worker", "server", "update"):
@@ -200,6 +202,7 @@ class AggregationStep:
 
     rule = lambda cand, t: self._aggregate(list(honests) + [cand] * k)  # noqa: E731
     n = h + k
+    host_ranked = self.gar == "brute"  # (its checked call reads a status: a synchronisation per evaluation anyway)
     if self.line_search in ("auto", "host") and self.gar == "bulyan" and k >= 1 and h + 2 <= 64 and hasattr(ops, "bulyan_pass2") \
        and not (set(self.gar_args) - {"m"}):
       # Bulyan's second pass needs the vectors, its ranking does not: the distances among honests + [avg + t*dir] * k
@@ -209,6 +212,8 @@ class AggregationStep:
       unit = torch.empty_like(h_avg)
       ops.multi_fma3([unit], [h_avg], [direction], 1.0, 1.0)
       ext = self._fetch(agg.global_sqdist(list(honests) + [h_avg, unit]))
+
+      host_ranked = True
 
       def rule(cand, t):  # noqa: F811
         order = linesearch.attack_ranking(ext, h, k, self.f_decl, "bulyan", t, m)
@@ -228,20 +233,34 @@ class AggregationStep:
     fused_eval = (self.line_search in ("auto", "host") and k >= 1 and not self.gar_args and hasattr(ops, "colwise_eval")
                   and ops.colwise_eval_supported(self.gar, n))
 
-    def scape(x):
-      t = -x if self.attack_negative else x
+    def evaluate(t):
+      """The objective of candidate t as a device fp64[1] tensor; t a number or the device cursor's tensor."""
       if fused_eval:
         # trmean / phocas / meamed: candidate, rule and objective in ONE pass over the honest rows, nothing written
         # (bm_colwise_eval: h + 2 row passes instead of h + 5 read and 2 written); the same value at every column
         sq = ops.colwise_eval(self.gar, honests, k, self.f_decl, h_avg, direction, t)
-        agg.all_reduce_sum(sq)
-        return sq.item()
-      cand = torch.empty_like(h_avg)
-      ops.multi_fma3([cand], [h_avg], [direction], 1.0, t)
-      out = rule(cand, t)
-      sq = ops.pairwise_sqdist([out, h_avg])[0, 1].reshape(1)  # aggregated.sub_(grad_avg); dot with itself
+      else:
+        cand = torch.empty_like(h_avg)
+        ops.multi_fma3([cand], [h_avg], [direction], 1.0, t)
+        out = rule(cand, t)
+        sq = ops.pairwise_sqdist([out, h_avg])[0, 1].reshape(1)  # aggregated.sub_(grad_avg); dot with itself
       agg.all_reduce_sum(sq)
-      return sq.item()
+      return sq
+
+    if self.line_search == "auto" and not host_ranked and hasattr(ops, "device_search") and h_avg.is_cuda:
+      # the cursor of the exploration in device memory: every evaluation reads its factor there and leaves its objective
+      # there — the host queues the whole search and waits for none of it (Bulyan's candidates are ranked on the host
+      # from t, and Brute's checked call synchronises by itself: those keep the host's cursor)
+      cursor = ops.device_search(h_avg.device, self.attack_evals, self.attack_negative)
+      y = None
+      for _ in range(self.attack_evals):
+        y = evaluate(cursor.next(y))
+      found = cursor.finish(y)
+      self.last_search = found
+      return found
+
+    def scape(x):
+      return evaluate(-x if self.attack_negative else x).item()
 
     factor, self.last_search = linesearch.line_maximize(scape, evals=self.attack_evals)
     return factor

@@ -390,6 +390,10 @@ int bm_colwise_eval_supported(int op, int n);
 int64_t bm_colwise_eval_workspace_bytes(void);
 int bm_colwise_eval(int op, const float* const* honests, int h, int copies, int64_t d, int f, const float* avg,
                     const float* dir, float t, double* out, void* ws, void* stream);
+/* The same with t read from DEVICE memory (one double, rounded to fp32 like the host's conversion of the same number):
+ * the factor bm_search_device_next left there. */
+int bm_colwise_eval_tdev(int op, const float* const* honests, int h, int copies, int64_t d, int f, const float* avg,
+                         const float* dir, const double* t_dev, double* out, void* ws, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * The factor search of the "identical" attacks (attacks/identical.py:67-77, the reference's default
@@ -435,6 +439,17 @@ int bm_attack_line_search(const double* ext, int h, int k, int f, int rule, int 
  * `out` must hold 1 + 26 * evals doubles; scripts/search_kernel_probe.py.) */
 int bm_attack_line_search_device(const double* ext, int h, int k, int f, int rule, int m, int evals, int negative,
                                  double* out, void* stream);
+/* The cursor of bm_search_* kept in DEVICE memory, for the searches whose candidates are evaluated by d-sized kernels
+ * (median, trimmed mean, phocas, meamed, any rule): the host queues
+ *     bm_search_device_next(state, NULL, negative, 0, start, delta, ratio, t, out)      first candidate
+ *     repeat: <evaluation kernels that read t[0]: bm_multi_fma3_bdev, bm_colwise_eval_tdev, the rule, and leave the
+ *              objective y[0] on the device>;  bm_search_device_next(state, y, negative, 0, ..., t, out)
+ *     bm_search_device_next(state, y_last, negative, 1, ..., NULL, out)                  the factor
+ * without waiting for any of them: `state` DEVICE memory of sizeof(bm_search), t DEVICE double (the candidate's signed
+ * factor, identical.py:70-71), out DEVICE 1 + 2 * evals doubles laid out like bm_attack_line_search_device's.  Same
+ * candidates as the host cursor (one definition, csrc/search_core.h).  start / delta / ratio are read on the first call. */
+int bm_search_device_next(void* state, const double* y, int negative, int last, double start, double delta, double ratio,
+                          double* t_out, double* out, void* stream);
 /* The ranking bm_krum_rank(mode, m) would give for honests + [avg + t*att] * k, from the same scalars (order_out: n
  * int32, indices >= h being Byzantine copies): for the rules whose output needs the vectors but whose ranking does not
  * — Bulyan (aggregators/bulyan.py:48-62 rank, :64-84 second pass): a candidate of the factor search then costs

@@ -152,6 +152,11 @@ case $name in
       python -c "import json; b=json.load(open('$out/bench$flag.json')); a=b['per_gar']['attack_search_c3_krum']; print('bench $flag:', a['scalar_form_each_ms'], a['host_scalar_form_each_ms'])"
     done
     ;;
+  cursor)   # the cursor on the device: its tests, the search tests against the reference loop, the bench's search entries
+    timeout 900 python -m pytest tests/test_gpu_search_device.py -m gpu -x -q > $out/pytest_search_device.log 2>&1; tail -5 $out/pytest_search_device.log
+    timeout 1500 python -m pytest tests/test_gpu_parity_r2.py tests/test_gpu_parity_r3.py tests/test_gpu_parity_r4.py -m gpu -x -q -k "search or factor" > $out/pytest_search_forms.log 2>&1; tail -3 $out/pytest_search_forms.log
+    timeout 600 python scripts/cursor_forms_probe.py 2>&1 | grep -v amdgpu.ids > $out/cursor_forms.txt; cat $out/cursor_forms.txt | cut -c1-400
+    ;;
   searchprobe)   # the search kernel alone: warm / cold, 1-64 evaluations
     timeout 300 python scripts/search_kernel_probe.py 2>&1 | grep -v amdgpu.ids > $out/search_kernel_probe.txt; cat $out/search_kernel_probe.txt
     ;;

@@ -203,4 +203,14 @@ def test_device_search_entry_points_validate_arguments_without_gpu(lib):
   rows = (ctypes.c_void_p * 64)()
   assert lib.bm_multi_fma3_bdev(rows, rows, rows, 1, 1000, ctypes.c_float(1.0), None, None, None) == _lib.EINVAL
   assert lib.bm_multi_fma3_bdev(rows, rows, rows, 1, 0, ctypes.c_float(1.0), buf, None, None) == 0   # empty vectors
-  assert lib.bm_abi_version() == 20
+  # ABI 21: the cursor in device memory and the evaluation that reads its factor there
+  nxt = lib.bm_search_device_next
+  shape = (ctypes.c_double(0.0), ctypes.c_double(1.0), ctypes.c_double(0.8))
+  assert nxt(None, None, 0, 0, *shape, buf, buf, None) == _lib.EINVAL            # no state
+  assert nxt(buf, None, 0, 0, *shape, None, buf, None) == _lib.EINVAL            # nowhere to put the candidate
+  assert nxt(buf, None, 0, 1, *shape, None, buf, None) == _lib.EINVAL            # the last call needs the last objective
+  assert nxt(buf, None, 0, 0, ctypes.c_double(0.0), ctypes.c_double(1.0), ctypes.c_double(0.4), buf, buf, None) == _lib.EINVAL
+  tail = (rows, rows)
+  assert lib.bm_colwise_eval_tdev(_lib.OP_TRMEAN, rows, 20, 5, 1000, 5, *tail, None, rows, rows, None) == _lib.EINVAL
+  assert lib.bm_colwise_eval_tdev(_lib.OP_MEDIAN, rows, 20, 5, 1000, 5, *tail, buf, rows, rows, None) == _lib.EINVAL
+  assert lib.bm_abi_version() == 21

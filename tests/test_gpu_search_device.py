@@ -178,3 +178,63 @@ def test_step_with_device_search_has_no_host_round_trip_and_matches_the_host_for
   graph.replay()
   torch.cuda.synchronize()
   assert torch.equal(out_graph, want_out) and torch.equal(byz_graph, want_byz)
+
+
+# ---------------------------------------------------------------------------- #
+# The exploration's cursor in device memory (bm_search_device_next)
+
+@pytest.mark.parametrize("negative", [False, True])
+def test_device_cursor_proposes_the_candidates_of_the_host_cursor(bm, negative):
+  """stats.DeviceSearch against linesearch.line_maximize (itself pinned to tools.line_maximize on 1 500 random scapes,
+  tests/test_linesearch_cpu.py) on scapes evaluated with the same IEEE operations on both sides: peaked, monotone,
+  flat (nothing ever strictly better), NaN beyond a point."""
+  from byzantinemomentum_amd import linesearch
+  scapes = [
+    (lambda t: 10.0 - (t - 3.7) * (t - 3.7), lambda t: 10.0 - (t - 3.7) * (t - 3.7)),
+    (lambda t: t * 0.5 + 1.0, lambda t: t * 0.5 + 1.0),
+    (lambda t: t * 0.0 + 2.0, lambda t: t * 0.0 + 2.0),
+    (lambda t: 1.0 / (1.0 + (t + 0.25) * (t + 0.25)), lambda t: 1.0 / (1.0 + (t + 0.25) * (t + 0.25))),
+    (lambda t: math.nan if abs(t) > 5.0 else abs(t), lambda t: torch.where(t.abs() > 5.0, torch.full_like(t, math.nan), t.abs())),
+  ]
+  for evals in (1, 2, 7, 16, 40):
+    for idx, (on_host, on_device) in enumerate(scapes):
+      want_factor, want_trace = linesearch.line_maximize(lambda x: on_host(-x if negative else x), evals=evals)
+      cursor = bm.stats.DeviceSearch(torch.device(DEV), evals, negative)
+      y = None
+      for _ in range(evals):
+        y = on_device(cursor.next(y))
+      out = cursor.finish(y).cpu().tolist()
+      got = (out[0], [(out[1 + 2 * i], out[2 + 2 * i]) for i in range(evals)])
+      _same_bits(got, (want_factor, want_trace), (idx, evals, negative))
+      with pytest.raises(RuntimeError):
+        cursor.next(y)
+
+
+STEP_RULES = [("median", {}), ("trmean", {}), ("phocas", {}), ("meamed", {}), ("aksel", {}), ("cge", {})]
+
+
+@pytest.mark.parametrize("gar,opts", STEP_RULES, ids=[r for r, _ in STEP_RULES])
+def test_step_with_the_cursor_on_the_device_equals_the_step_with_the_cursor_on_the_host(bm, gar, opts):
+  """AggregationStep(line_search="auto") keeps the cursor on the device for every rule but Bulyan / Brute: the same
+  kernels are fed the same factors as with the host's cursor ("host"), so candidates, objectives, factor, aggregated
+  gradient and study floats are the same bits — and the step queues its search without waiting (the factor is a tensor
+  when run() returns)."""
+  from byzantinemomentum_amd.step import AggregationStep
+  n, f, d = 25, 5, 60013
+  h = n - f
+  gen = torch.Generator().manual_seed(13)
+  modes = ("auto", opts.get("line", "host"))
+  steps = {mode: AggregationStep(n, f, f, gar=gar, momentum=0.9, dampening=0.9, momentum_at="worker", attack="little",
+                                 nb_past=2, attack_evals=12, attack_negative=(gar in ("phocas", "cge")), line_search=mode)
+           for mode in modes}
+  origin = torch.randn(d, generator=gen).to(DEV)
+  for it in range(3):
+    sampled = [(0.2 * torch.randn(d, generator=gen) + (0.5 + 0.1 * i) * torch.randn(d, generator=gen)).to(DEV) for i in range(h)]
+    outs = {}
+    for mode, step in steps.items():
+      outs[mode] = step.run([g.clone() for g in sampled], origin, origin).clone()
+      assert isinstance(step._factor_now, torch.Tensor) == (mode == "auto"), (gar, mode)
+    a, b = (steps[m] for m in modes)
+    assert a.last_search == b.last_search and a.last_factor == b.last_factor, (gar, it, a.last_search, b.last_search)
+    assert torch.equal(outs[modes[0]], outs[modes[1]]), (gar, it)
+    assert a.floats() == b.floats(), (gar, it)
