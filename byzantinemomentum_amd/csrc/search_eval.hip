@@ -136,10 +136,175 @@ static int launch_eval_op(int op, const float* const* rows, int h, int64_t d, in
   }
 }
 
+// |a - b|^2 of two vectors with the accumulation of colwise_eval_kernel (fp32 over 16 elements per lane, fp64 beyond, the
+// partials added in a fixed order): the objective of a candidate whose rule has no evaluate-only form
+// (aggregated.sub_(grad_avg); aggregated.dot(aggregated), identical.py:75-76).  The n x n machinery of the distance pass
+// costs 64 us for these two rows at d = 11.2 M (Gram kernel 45 + reduction + gated launch); this is one 15 us pass.
+template <int VEC>
+__global__ __launch_bounds__(kColBlock) void sqdist2_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                            int64_t nvec, double* __restrict__ partial) {
+  __shared__ double red[kColBlock / 64];
+  float acc = 0.0f;
+  double wide = 0.0;
+  int since = 0;
+  const int64_t stride = (int64_t)gridDim.x * kColBlock;
+  for (int64_t v = (int64_t)blockIdx.x * kColBlock + threadIdx.x; v < nvec; v += stride) {
+    float x[VEC], y[VEC];
+    load_stream<VEC>(a + v * VEC, x);
+    load_stream<VEC>(b + v * VEC, y);
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      const float df = x[c] - y[c];
+      acc = __builtin_fmaf(df, df, acc);
+    }
+    if (++since == 16) {
+      wide += (double)acc;
+      acc = 0.0f;
+      since = 0;
+    }
+  }
+  const double r = block_reduce_sum<kColBlock>(wide + (double)acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = r;
+}
+
+// Two order statistics of the h honest values of every column in ONE pass over the rows: the `lo` / `hi` of the median's
+// own factor search (step.py).  median(honests + [b] * k) = middle of (b, lo, hi) with lo / hi the medians of the honest
+// values and k copies of -inf / +inf (median.py:31-39 on either stack): in sorted order the -inf copies come first and
+// the +inf copies last, so lo is the honest value of rank (n-1)/2 - k (-inf below rank 0) and hi the one of rank
+// (n-1)/2 (+inf beyond rank h-1) — values of the rows, no arithmetic, hence the bits of the two median calls they
+// replace (2 (n + 1) row passes, the 2 k aliased copies among them, against h + 2 here).  A NaN anywhere in the column
+// makes both NaN, as torch.median does for either stack.  The rows are padded with +inf to the network's size N; the
+// rank is wave-uniform and picked by a chain of selects at static register indices.
+template <int N, int VEC>
+__global__ __launch_bounds__(kColBlock) void order_pair_kernel(RowTable rows, int h, int il, int ih, int64_t nvec,
+                                                               float* __restrict__ lo, float* __restrict__ hi) {
+  const float kInf = __builtin_inff();
+  const float kNaN = __builtin_nanf("");
+  const int64_t stride = (int64_t)gridDim.x * kColBlock;
+  for (int64_t v = (int64_t)blockIdx.x * kColBlock + threadIdx.x; v < nvec; v += stride) {
+    const int64_t j = v * VEC;
+    float x[VEC][N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      if (i < h) {  // wave-uniform
+        float tmp[VEC];
+        load_stream<VEC>(rows.p[i] + j, tmp);
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) x[c][i] = tmp[c];
+      } else {
+#pragma unroll
+        for (int c = 0; c < VEC; ++c) x[c][i] = kInf;
+      }
+    }
+    float a[VEC], b[VEC];
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      bool has_nan = false;
+#pragma unroll
+      for (int i = 0; i < N; ++i) has_nan |= (x[c][i] != x[c][i]);
+      sort_network<N>(x[c]);
+      float va = -kInf, vb = kInf;
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        va = (i == il) ? x[c][i] : va;
+        vb = (i == ih) ? x[c][i] : vb;
+      }
+      a[c] = has_nan ? kNaN : va;
+      b[c] = has_nan ? kNaN : vb;
+    }
+    store_stream<VEC>(lo + j, a);
+    store_stream<VEC>(hi + j, b);
+  }
+}
+
+template <int N>
+static int launch_order_pair(const float* const* rows, int h, int64_t d, int il, int ih, float* lo, float* hi,
+                             hipStream_t s) {
+  constexpr int kMaxVec = (N <= 28) ? 4 : 2;
+  RowTable tab{};
+  for (int i = 0; i < h; ++i) tab.p[i] = rows[i];
+  const void* outs[2] = {lo, hi};
+  int vec = common_vec_width(reinterpret_cast<const void* const*>(rows), h, nullptr);
+  const int vec2 = common_vec_width(outs, 2, nullptr);
+  if (vec2 < vec) vec = vec2;
+  if (vec > kMaxVec) vec = kMaxVec;
+  int64_t body = 0;
+  if (vec >= 2 && d / vec > 0) {
+    const int64_t nvec = d / vec;
+    const int grid = stream_grid(nvec, kColBlock, kColMaxBlocks);
+    auto kern = vec == 4 ? order_pair_kernel<N, (kMaxVec >= 4 ? 4 : 2)> : order_pair_kernel<N, 2>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kColBlock), 0, s, tab, h, il, ih, nvec, lo, hi);
+    BM_LAUNCH_CHECK();
+    body = nvec * vec;
+  }
+  if (body < d) {
+    RowTable tail{};
+    for (int i = 0; i < h; ++i) tail.p[i] = rows[i] + body;
+    const int64_t rest = d - body;
+    const int grid = (body == 0) ? stream_grid(rest, kColBlock, kColMaxBlocks) : 1;
+    hipLaunchKernelGGL((order_pair_kernel<N, 1>), dim3(grid), dim3(kColBlock), 0, s, tail, h, il, ih, rest, lo + body,
+                       hi + body);
+    BM_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 }  // namespace bm
 
+extern "C" int bm_order_pair_supported(int h) { return h >= 1 && h <= 51 ? 1 : 0; }
+
+extern "C" int bm_order_pair(const float* const* rows, int h, int64_t d, int il, int ih, float* lo, float* hi,
+                             void* stream) {
+  using namespace bm;
+  if (rows == nullptr || !bm_order_pair_supported(h) || d < 0) return BM_EINVAL;
+  if (d == 0) return 0;
+  if (lo == nullptr || hi == nullptr || lo == hi) return BM_EINVAL;
+  for (int i = 0; i < h; ++i)
+    if (rows[i] == nullptr) return BM_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (h <= 11) return launch_order_pair<11>(rows, h, d, il, ih, lo, hi, s);
+  if (h <= 25) return launch_order_pair<25>(rows, h, d, il, ih, lo, hi, s);
+  return launch_order_pair<51>(rows, h, d, il, ih, lo, hi, s);
+}
+
+// (BM_OP_MEDIAN, n = 3: the median's own search — every candidate is the middle of (candidate, lo, hi), lo / hi two order
+//  statistics of the honest rows formed once per search, step.py — evaluated without writing candidate or median)
 extern "C" int bm_colwise_eval_supported(int op, int n) {
+  if (op == BM_OP_MEDIAN) return n == 3 ? 1 : 0;
   return (op == BM_OP_TRMEAN || op == BM_OP_PHOCAS || op == BM_OP_MEAMED) && (n == 11 || n == 25 || n == 51) ? 1 : 0;
+}
+
+extern "C" int bm_sqdist2(const float* a, const float* b, int64_t d, double* out, void* ws, void* stream) {
+  using namespace bm;
+  if (out == nullptr || ws == nullptr || d < 0 || (d > 0 && (a == nullptr || b == nullptr))) return BM_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  double* partial = static_cast<double*>(ws);
+  const void* both[2] = {a, b};
+  const int vec = d > 0 ? common_vec_width(both, 2, nullptr) : 1;
+  int nparts = 0;
+  int64_t body = 0;
+  if (vec >= 2 && d / vec > 0) {
+    const int64_t nvec = d / vec;
+    const int grid = stream_grid(nvec, kColBlock, kEvalMaxBlocks);
+    if (vec == 4)
+      hipLaunchKernelGGL(sqdist2_kernel<4>, dim3(grid), dim3(kColBlock), 0, s, a, b, nvec, partial);
+    else
+      hipLaunchKernelGGL(sqdist2_kernel<2>, dim3(grid), dim3(kColBlock), 0, s, a, b, nvec, partial);
+    BM_LAUNCH_CHECK();
+    nparts = grid;
+    body = nvec * vec;
+  }
+  if (body < d) {
+    const int64_t rest = d - body;
+    const int grid = (body == 0) ? stream_grid(rest, kColBlock, kEvalMaxBlocks) : 1;
+    hipLaunchKernelGGL(sqdist2_kernel<1>, dim3(grid), dim3(kColBlock), 0, s, a + body, b + body, rest, partial + nparts);
+    BM_LAUNCH_CHECK();
+    nparts += grid;
+  }
+  // d == 0: no partial, the finish kernel writes zero (every rank of a sharded job reaches its all-reduce)
+  hipLaunchKernelGGL(eval_finish_kernel, dim3(1), dim3(kEvalFinishThreads), 0, s, partial, nparts, out);
+  BM_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int64_t bm_colwise_eval_workspace_bytes(void) { return (int64_t)(2 * bm::kEvalMaxBlocks) * (int64_t)sizeof(double); }
@@ -154,6 +319,7 @@ static int colwise_eval_call(int op, const float* const* honests, int h, int cop
   hipStream_t s = static_cast<hipStream_t>(stream);
   double* partial = static_cast<double*>(ws);
   switch (n) {
+    case 3: return launch_eval<3, BM_OP_MEDIAN>(honests, h, d, f, avg, dir, t, t_dev, out, partial, s);
     case 11: return launch_eval_op<11>(op, honests, h, d, f, avg, dir, t, t_dev, out, partial, s);
     case 25: return launch_eval_op<25>(op, honests, h, d, f, avg, dir, t, t_dev, out, partial, s);
     default: return launch_eval_op<51>(op, honests, h, d, f, avg, dir, t, t_dev, out, partial, s);

@@ -221,6 +221,15 @@ class HipBackend:
   def colwise_eval(self, *args, **kwargs):
     return self.stats.colwise_eval(*args, **kwargs)
 
+  def sqdist2(self, a, b):
+    return self.stats.sqdist2(a, b)
+
+  def order_pair_supported(self, h):
+    return self.stats.order_pair_supported(h)
+
+  def order_pair(self, rows, il, ih):
+    return self.stats.order_pair(rows, il, ih)
+
   def study_dots(self, core, extra):
     return self.stats.study_dots(core, extra)
 

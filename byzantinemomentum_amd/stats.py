@@ -88,7 +88,7 @@ def study_dots(core, extra=()):
   return out[:nc * nc].view(nc, nc), out[nc * nc:]
 
 
-_EVAL_OPS = {"trmean": _lib.OP_TRMEAN, "phocas": _lib.OP_PHOCAS, "meamed": _lib.OP_MEAMED}
+_EVAL_OPS = {"trmean": _lib.OP_TRMEAN, "phocas": _lib.OP_PHOCAS, "meamed": _lib.OP_MEAMED, "median": _lib.OP_MEDIAN}
 
 
 def colwise_eval_supported(rule, n):
@@ -118,6 +118,37 @@ def colwise_eval(rule, honests, copies, f, h_avg, direction, t):
                                      _ptr(direction), float(t), _ptr(out), _ptr(ws), gars._stream(device)),
                  "bm_colwise_eval")
   return out
+
+
+def sqdist2(a, b):
+  """|a - b|^2 as a device fp64[1] tensor in one pass over the two vectors (bm_sqdist2): the objective of a candidate of
+  the factor search (identical.py:75-76).  No sync."""
+  _, d, device = gars._validate([a, b])
+  lib = _lib.load()
+  out = torch.empty(1, dtype=torch.float64, device=device)
+  ws = gars._Scratch.get(device, "ws_eval", nbytes=int(lib.bm_colwise_eval_workspace_bytes()))
+  with torch.cuda.device(device):
+    _lib.check(lib.bm_sqdist2(_ptr(a), _ptr(b), d, _ptr(out), _ptr(ws), gars._stream(device)), "bm_sqdist2")
+  return out
+
+
+def order_pair_supported(h):
+  """Is there a one-pass form of two order statistics of h rows (bm_order_pair)?"""
+  return bool(_lib.load().bm_order_pair_supported(int(h)))
+
+
+def order_pair(rows, il, ih):
+  """(lo, hi): per coordinate the values of rank il and ih (0-based, ascending) among the rows; -inf below rank 0, +inf
+  beyond the last rank, NaN where the column holds one (bm_order_pair).  One pass over the rows, no sync: the two
+  vectors of the median's factor search (median.py:31-39 on the rows with k copies of -inf / +inf)."""
+  rows = list(rows)
+  h, d, device = gars._validate(rows)
+  lib = _lib.load()
+  lo, hi = torch.empty_like(rows[0]), torch.empty_like(rows[0])
+  with torch.cuda.device(device):
+    _lib.check(lib.bm_order_pair(_lib.pointer_table(rows), h, d, int(il), int(ih), _ptr(lo), _ptr(hi),
+                                 gars._stream(device)), "bm_order_pair")
+  return lo, hi
 
 
 class DeviceSearch:

@@ -226,24 +226,33 @@ class AggregationStep:
       # +inf.  Two passes over the honest rows for the whole search, then every candidate is the median of THREE
       # rows (4 row passes instead of n + 1): the same value of the rule at every coordinate — it returns one of its
       # inputs, no arithmetic — hence the same objective, bit for bit, as evaluating the rule on the n rows.
-      lo = agg.median(list(honests) + [torch.full_like(h_avg, -math.inf)] * k)
-      hi = agg.median(list(honests) + [torch.full_like(h_avg, math.inf)] * k)
+      if hasattr(ops, "order_pair") and ops.order_pair_supported(h):
+        lo, hi = ops.order_pair(honests, (n - 1) // 2 - k, (n - 1) // 2)   # both in one pass over the honest rows
+      else:
+        lo = agg.median(list(honests) + [torch.full_like(h_avg, -math.inf)] * k)
+        hi = agg.median(list(honests) + [torch.full_like(h_avg, math.inf)] * k)
       rule = lambda cand, t: agg.median([cand, lo, hi])  # noqa: E731
 
     fused_eval = (self.line_search in ("auto", "host") and k >= 1 and not self.gar_args and hasattr(ops, "colwise_eval")
                   and ops.colwise_eval_supported(self.gar, n))
+    eval_rows, eval_copies, eval_f = honests, k, self.f_decl
+    if (self.line_search in ("auto", "host") and self.gar == "median" and k >= 1 and hasattr(ops, "colwise_eval")
+        and ops.colwise_eval_supported("median", 3)):
+      # ... and the middle of (lo, hi, candidate) has an evaluate-only instance: 4 row passes, nothing written
+      fused_eval, eval_rows, eval_copies, eval_f = True, [lo, hi], 1, 0
 
     def evaluate(t):
       """The objective of candidate t as a device fp64[1] tensor; t a number or the device cursor's tensor."""
       if fused_eval:
         # trmean / phocas / meamed: candidate, rule and objective in ONE pass over the honest rows, nothing written
         # (bm_colwise_eval: h + 2 row passes instead of h + 5 read and 2 written); the same value at every column
-        sq = ops.colwise_eval(self.gar, honests, k, self.f_decl, h_avg, direction, t)
+        sq = ops.colwise_eval(self.gar, eval_rows, eval_copies, eval_f, h_avg, direction, t)
       else:
         cand = torch.empty_like(h_avg)
         ops.multi_fma3([cand], [h_avg], [direction], 1.0, t)
         out = rule(cand, t)
-        sq = ops.pairwise_sqdist([out, h_avg])[0, 1].reshape(1)  # aggregated.sub_(grad_avg); dot with itself
+        # aggregated.sub_(grad_avg); dot with itself: one pass over the two vectors where the backend has it
+        sq = ops.sqdist2(out, h_avg) if hasattr(ops, "sqdist2") else ops.pairwise_sqdist([out, h_avg])[0, 1].reshape(1)
       agg.all_reduce_sum(sq)
       return sq
 

@@ -390,7 +390,9 @@ int bm_colwise_eval_supported(int op, int n);
 int64_t bm_colwise_eval_workspace_bytes(void);
 int bm_colwise_eval(int op, const float* const* honests, int h, int copies, int64_t d, int f, const float* avg,
                     const float* dir, float t, double* out, void* ws, void* stream);
-/* The same with t read from DEVICE memory (one double, rounded to fp32 like the host's conversion of the same number):
+/* (Also op = BM_OP_MEDIAN with h = 2, copies = 1: the middle of (candidate, honests[0], honests[1]) — the median's own
+ * factor search, where the two rows are order statistics of the honest rows formed once per search.)
+ * The same with t read from DEVICE memory (one double, rounded to fp32 like the host's conversion of the same number):
  * the factor bm_search_device_next left there. */
 int bm_colwise_eval_tdev(int op, const float* const* honests, int h, int copies, int64_t d, int f, const float* avg,
                          const float* dir, const double* t_dev, double* out, void* ws, void* stream);
@@ -439,6 +441,19 @@ int bm_attack_line_search(const double* ext, int h, int k, int f, int rule, int 
  * `out` must hold 1 + 26 * evals doubles; scripts/search_kernel_probe.py.) */
 int bm_attack_line_search_device(const double* ext, int h, int k, int f, int rule, int m, int evals, int negative,
                                  double* out, void* stream);
+/* out[0] = |a - b|^2 (fp64, DEVICE): the objective `aggregated.sub_(grad_avg); aggregated.dot(aggregated)` of
+ * identical.py:75-76 for a candidate whose rule was run on the vectors; one pass over the two vectors (the n x n
+ * distance pass spends three launches on them).  ws: bm_colwise_eval_workspace_bytes().  Partial sums in a fixed order. */
+int bm_sqdist2(const float* a, const float* b, int64_t d, double* out, void* ws, void* stream);
+/* lo[j] = the value of rank il, hi[j] = the value of rank ih (0-based, ascending) among rows[0..h)[j]; a rank below 0 reads
+ * -inf, a rank beyond h - 1 reads +inf; a NaN in the column makes both NaN.  One pass over the h rows (h <= 51:
+ * bm_order_pair_supported).  With n = h + k, il = (n-1)/2 - k, ih = (n-1)/2 these are the lower medians (median.py:31-39)
+ * of the rows with k copies of -inf, resp. +inf — the two vectors between which the median of `rows + [b] * k` moves
+ * with b: the median's own factor search (identical.py:67-77) forms them once and evaluates every candidate as the
+ * middle of three (bm_colwise_eval with BM_OP_MEDIAN).  Values of the rows, no arithmetic: the bits of the two median
+ * calls it replaces. */
+int bm_order_pair_supported(int h);
+int bm_order_pair(const float* const* rows, int h, int64_t d, int il, int ih, float* lo, float* hi, void* stream);
 /* The cursor of bm_search_* kept in DEVICE memory, for the searches whose candidates are evaluated by d-sized kernels
  * (median, trimmed mean, phocas, meamed, any rule): the host queues
  *     bm_search_device_next(state, NULL, negative, 0, start, delta, ratio, t, out)      first candidate

@@ -157,6 +157,12 @@ case $name in
     timeout 1500 python -m pytest tests/test_gpu_parity_r2.py tests/test_gpu_parity_r3.py tests/test_gpu_parity_r4.py -m gpu -x -q -k "search or factor" > $out/pytest_search_forms.log 2>&1; tail -3 $out/pytest_search_forms.log
     timeout 600 python scripts/cursor_forms_probe.py 2>&1 | grep -v amdgpu.ids > $out/cursor_forms.txt; cat $out/cursor_forms.txt | cut -c1-400
     ;;
+  cursor2)  # ABI 22 (bm_sqdist2, the median's search as the middle of three): the cursor recipe + the multi-rank file
+    timeout 900 python -m pytest tests/test_gpu_search_device.py -m gpu -x -q > $out/pytest_search_device.log 2>&1; tail -5 $out/pytest_search_device.log
+    timeout 1500 python -m pytest tests/test_gpu_parity_r2.py tests/test_gpu_parity_r3.py tests/test_gpu_parity_r4.py -m gpu -x -q -k "search or factor" > $out/pytest_search_forms.log 2>&1; tail -3 $out/pytest_search_forms.log
+    timeout 600 python scripts/cursor_forms_probe.py 2>&1 | grep -v amdgpu.ids > $out/cursor_forms.txt; cat $out/cursor_forms.txt | cut -c1-400
+    BM_TEST_POISON=0 timeout 600 python -m pytest tests/test_gpu_zz_multirank.py tests/test_gpu_reference_loop.py -m gpu -x -q > $out/pytest_multirank_loop.log 2>&1; tail -3 $out/pytest_multirank_loop.log
+    ;;
   searchprobe)   # the search kernel alone: warm / cold, 1-64 evaluations
     timeout 300 python scripts/search_kernel_probe.py 2>&1 | grep -v amdgpu.ids > $out/search_kernel_probe.txt; cat $out/search_kernel_probe.txt
     ;;

@@ -213,4 +213,21 @@ def test_device_search_entry_points_validate_arguments_without_gpu(lib):
   tail = (rows, rows)
   assert lib.bm_colwise_eval_tdev(_lib.OP_TRMEAN, rows, 20, 5, 1000, 5, *tail, None, rows, rows, None) == _lib.EINVAL
   assert lib.bm_colwise_eval_tdev(_lib.OP_MEDIAN, rows, 20, 5, 1000, 5, *tail, buf, rows, rows, None) == _lib.EINVAL
-  assert lib.bm_abi_version() == 21
+  # ABI 22: the objective of a candidate in one pass over two vectors; the median's own search as the middle of three
+  assert lib.bm_sqdist2(None, rows, 1000, buf, buf, None) == _lib.EINVAL          # no first vector
+  assert lib.bm_sqdist2(rows, rows, 1000, None, buf, None) == _lib.EINVAL         # nowhere to write
+  assert lib.bm_sqdist2(rows, rows, 1000, buf, None, None) == _lib.EINVAL         # no workspace
+  assert lib.bm_sqdist2(rows, rows, -1, buf, buf, None) == _lib.EINVAL            # negative length
+  assert lib.bm_colwise_eval_supported(_lib.OP_MEDIAN, 3) == 1 and lib.bm_colwise_eval_supported(_lib.OP_MEDIAN, 5) == 0
+  assert lib.bm_colwise_eval_supported(_lib.OP_TRMEAN, 3) == 0
+  assert lib.bm_colwise_eval_tdev(_lib.OP_MEDIAN, rows, 2, 2, 1000, 0, *tail, buf, rows, rows, None) == _lib.EINVAL  # n = 4
+  assert lib.bm_order_pair_supported(1) == 1 and lib.bm_order_pair_supported(51) == 1
+  assert lib.bm_order_pair_supported(0) == 0 and lib.bm_order_pair_supported(52) == 0
+  assert lib.bm_order_pair(None, 20, 1000, 7, 12, buf, rows, None) == _lib.EINVAL      # no rows
+  assert lib.bm_order_pair(rows, 52, 1000, 7, 12, buf, rows, None) == _lib.EINVAL      # more rows than the largest network
+  assert lib.bm_order_pair(rows, 20, -1, 7, 12, buf, rows, None) == _lib.EINVAL        # negative length
+  assert lib.bm_order_pair(rows, 20, 1000, 7, 12, buf, buf, None) == _lib.EINVAL       # lo and hi are one buffer
+  assert lib.bm_order_pair(rows, 20, 1000, 7, 12, None, buf, None) == _lib.EINVAL      # nowhere to write
+  assert lib.bm_order_pair(rows, 20, 1000, 7, 12, buf, rows, None) == _lib.EINVAL      # a null row (the table is empty)
+  assert lib.bm_order_pair(rows, 20, 0, 7, 12, None, None, None) == 0                  # empty vectors: nothing to do
+  assert lib.bm_abi_version() == 22

@@ -238,3 +238,103 @@ def test_step_with_the_cursor_on_the_device_equals_the_step_with_the_cursor_on_t
     assert a.last_search == b.last_search and a.last_factor == b.last_factor, (gar, it, a.last_search, b.last_search)
     assert torch.equal(outs[modes[0]], outs[modes[1]]), (gar, it)
     assert a.floats() == b.floats(), (gar, it)
+
+
+# ---------------------------------------------------------------------------- #
+# ABI 22: the objective of a candidate in one pass (bm_sqdist2); the median's search as the middle of three rows
+
+@pytest.mark.parametrize("d", [0, 1, 3, 63, 1024, 65537, 1000003, 11173962])
+def test_sqdist2_against_fp64_and_the_evaluate_only_accumulation(bm, d):
+  """bm_sqdist2 = |a - b|^2 (aggregated.sub_(grad_avg); aggregated.dot(aggregated), identical.py:75-76) against fp64
+  (1e-6 relative: fp32 squares, 16 per lane, fp64 beyond), repeated launches bit-equal, 4- / 8- / 16-byte aligned views
+  within 1e-6 of each other, a NaN answered NaN, and — what the search tests below rest on — the SAME bits as the
+  evaluate-only kernel leaves for the rule's output on the same vectors (median of (lo, hi, candidate))."""
+  gen = torch.Generator(device=DEV).manual_seed(5 + d % 97)
+  a = torch.randn(d + 4, device=DEV, generator=gen)
+  b = 0.5 * torch.randn(d + 4, device=DEV, generator=gen)
+  want = (a[:d].double() - b[:d].double()).pow(2).sum().item()
+  got = bm.stats.sqdist2(a[:d], b[:d])
+  assert got.dtype == torch.float64 and got.shape == (1,)
+  assert abs(got.item() - want) <= 1e-6 * want + 0.0
+  assert torch.equal(got, bm.stats.sqdist2(a[:d], b[:d]))
+  if d == 0:
+    return
+  for off in (1, 2):
+    ao, bo = a.clone()[off:off + d], b[:d]
+    ao.copy_(a[:d])
+    assert abs(bm.stats.sqdist2(ao, bo).item() - want) <= 1e-6 * want
+  # the evaluate-only kernel on (lo, hi) = (-inf, +inf): the middle of (lo, hi, candidate) is the candidate
+  # avg + t * dir, so its objective is |t * dir|^2 up to the rounding of the fused multiply-add — and with avg = 0 exactly
+  # sqdist2(t * dir, 0)
+  lo, hi = torch.full((d,), -math.inf, device=DEV), torch.full((d,), math.inf, device=DEV)
+  zero, direction = torch.zeros(d, device=DEV), a[:d].clone()
+  cand = torch.empty(d, device=DEV)
+  bm.stats.multi_fma3([cand], [zero], [direction], 1.0, 0.75)
+  fused = bm.stats.colwise_eval("median", [lo, hi], 1, 0, zero, direction, 0.75)
+  assert torch.equal(fused, bm.stats.sqdist2(cand, zero)), d
+  a[d // 2] = math.nan
+  assert math.isnan(bm.stats.sqdist2(a[:d], b[:d]).item())
+
+
+@pytest.mark.parametrize("n,f,d", [(25, 5, 200003), (11, 4, 65536), (51, 24, 30001)])
+def test_median_of_three_evaluate_only_form_against_the_median_kernel(bm, n, f, d):
+  """bm_colwise_eval(BM_OP_MEDIAN, [lo, hi], copies = 1) against the median of the n rows with the candidate written out
+  (median.py:31-39 on honests + [avg + t * dir] * f, then identical.py:75-76): the same objective bit for bit at several
+  factors, from the host's number and from a factor in device memory; other shapes are refused."""
+  h = n - f
+  gen = torch.Generator(device=DEV).manual_seed(77)
+  honests = [0.3 * torch.randn(d, device=DEV, generator=gen) + 0.1 * i for i in range(h)]
+  for g in honests:
+    g[::7] = g[::7].round()   # ties
+  avg = torch.stack(honests).mean(dim=0)
+  direction = -avg
+  lo = bm.median(honests + [torch.full_like(avg, -math.inf)] * f)
+  hi = bm.median(honests + [torch.full_like(avg, math.inf)] * f)
+  for t in (0.0, 0.3, 1.0, 2.5, -4.0, 1e6):
+    cand = torch.empty_like(avg)
+    bm.stats.multi_fma3([cand], [avg], [direction], 1.0, t)
+    want = bm.stats.sqdist2(bm.median(honests + [cand] * f), avg)
+    got = bm.stats.colwise_eval("median", [lo, hi], 1, 0, avg, direction, t)
+    assert torch.equal(got, want), (n, t, got.item(), want.item())
+    t_dev = torch.tensor([t], dtype=torch.float64, device=DEV)
+    assert torch.equal(bm.stats.colwise_eval("median", [lo, hi], 1, 0, avg, direction, t_dev), want)
+  assert not bm.stats.colwise_eval_supported("median", n) and bm.stats.colwise_eval_supported("median", 3)
+  with pytest.raises(Exception):
+    bm.stats.colwise_eval("median", [lo, hi, lo], 1, 0, avg, direction, 1.0)
+
+
+@pytest.mark.parametrize("h,k,d", [(1, 1, 1000), (2, 1, 4099), (6, 5, 65537), (11, 4, 300001), (14, 11, 262144), (20, 5, 1000003),
+                                   (25, 1, 70001), (26, 25, 50002), (39, 12, 100003), (51, 13, 30001)])
+def test_order_pair_equals_the_two_medians_it_replaces(bm, h, k, d):
+  """bm_order_pair(honests, (n-1)/2 - k, (n-1)/2) against median(honests + [-inf] * k) and median(honests + [+inf] * k)
+  (median.py:31-39): bit-equal — ties, +-inf among the honest values, NaN columns, ranks that fall off either end
+  (k > h: the +-inf copies themselves are the median), views that are only 4- and 8-byte aligned, every tail length."""
+  n = h + k
+  gen = torch.Generator(device=DEV).manual_seed(1000 * h + k)
+  honests = [torch.randn(d + 3, device=DEV, generator=gen) + 0.05 * i for i in range(h)]
+  for i, g in enumerate(honests):
+    g[::5] = g[::5].round()
+    g[(7 + i)::97] = math.inf if i % 2 else -math.inf
+  honests[0][11] = math.nan
+  honests[h - 1][d - 1] = math.nan
+  for off in (0, 1, 2):
+    rows = [g[off:off + d] for g in honests]
+    if n <= 64:
+      want_lo = bm.median(rows + [torch.full((d,), -math.inf, device=DEV)] * k)
+      want_hi = bm.median(rows + [torch.full((d,), math.inf, device=DEV)] * k)
+    else:
+      continue
+    lo, hi = bm.stats.order_pair(rows, (n - 1) // 2 - k, (n - 1) // 2)
+    assert torch.equal(lo.isnan(), want_lo.isnan()) and torch.equal(hi.isnan(), want_hi.isnan()), (h, k, off)
+    assert lo.isnan().sum().item() >= 2
+    assert torch.equal(lo.nan_to_num(nan=7.0), want_lo.nan_to_num(nan=7.0)), (h, k, off)
+    assert torch.equal(hi.nan_to_num(nan=7.0), want_hi.nan_to_num(nan=7.0)), (h, k, off)
+  # ranks off both ends
+  rows = [g[:d] for g in honests]
+  lo, hi = bm.stats.order_pair(rows, -1, h)
+  clean = ~torch.stack(rows).isnan().any(dim=0)
+  assert bool((lo[clean] == -math.inf).all()) and bool((hi[clean] == math.inf).all())
+  lo, hi = bm.stats.order_pair(rows, 0, h - 1)
+  stack = torch.stack(rows)
+  assert torch.equal(lo[clean], stack.min(dim=0).values[clean]) and torch.equal(hi[clean], stack.max(dim=0).values[clean])
+  assert bm.stats.order_pair_supported(51) and not bm.stats.order_pair_supported(52)
