@@ -174,6 +174,7 @@ case $name in
     ;;
   final)  # the end of a round: suite with -x, smoke, bench as the driver runs it, a kernel trace of the headline alone, a step with the search
     for D in 11173962 36546980; do D=$D timeout 600 python scripts/step_search_probe.py 2>&1 | grep -v amdgpu.ids; done > $out/step_search.txt; cat $out/step_search.txt
+    timeout 600 python scripts/cursor_forms_probe.py 2>&1 | grep -v amdgpu.ids > $out/cursor_forms.txt; cat $out/cursor_forms.txt | cut -c1-400
     ( time timeout 1800 python -m pytest tests -m gpu -x -q ) > $out/pytest_gpu.log 2>&1; tail -4 $out/pytest_gpu.log
     timeout 200 python __graft_entry__.py smoke > $out/smoke.log 2>&1; tail -1 $out/smoke.log
     timeout 600 python bench.py > $out/bench_default.json 2> $out/bench_default.err; wc -c $out/bench_default.json
