@@ -20,7 +20,7 @@ _PKG_DIR = pathlib.Path(__file__).resolve().parent
 # scripts/gram_variant_probe.py); the default, and the only thing the tests and the bench load, is the in-tree build.
 LIB_PATH = pathlib.Path(os.environ["BM_GAR_LIB"]).resolve() if os.environ.get("BM_GAR_LIB") else _PKG_DIR / "libbm_gar.so"
 
-ABI_VERSION = 22
+ABI_VERSION = 23
 MAX_ROWS = 64
 EINVAL = -100000
 ENOCOMM, ECOMM = -100001, -100002
@@ -125,6 +125,10 @@ SIGNATURES = {
                                           ctypes.c_void_p, ctypes.c_void_p]),
   "bm_sqdist2": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                 ctypes.c_void_p]),
+  "bm_bulyan_pass2_eval_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+  "bm_bulyan_pass2_eval": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                                          ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p,
+                                          ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
   "bm_order_pair_supported": (ctypes.c_int, [ctypes.c_int]),
   "bm_order_pair": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
                                    ctypes.c_void_p, ctypes.c_void_p]),

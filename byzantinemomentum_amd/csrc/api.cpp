@@ -29,7 +29,7 @@ Tuning& tuning_mutable() {
 const Tuning& tuning() { return tuning_mutable(); }
 }  // namespace bm
 
-extern "C" int bm_abi_version(void) { return 22; }
+extern "C" int bm_abi_version(void) { return 23; }
 
 // Launch-shape knobs of the A/B runs, settable inside one process (the environment is read once, at the first call):
 // alternating two settings on the same data, on the same box, is the only comparison that resolves a 1 % effect.

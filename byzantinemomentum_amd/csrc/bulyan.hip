@@ -17,61 +17,15 @@ namespace bm {
 
 constexpr int kBulBlock = 256;
 
-// ---------------------------------------------------------------------------
-// Register-resident Bulyan pass 2 for a compile-time (n, f) and the default m = m_max.
-// ---------------------------------------------------------------------------
-//
-// (The chip-wide store-burst form that pays for the column kernels and the selected mean does not pay here: measured
-// in round 3 with identical checksums, 153.0 -> 154.1 us at n = 25, 357.7 -> 359.1 us at n = 51, 87.2 -> 85.8 us at
-// n = 15, profiles/r03_c_bulyan_pass2_burst_ab.txt.  It was removed.)
-template <int N, int F, int VEC>
-__global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(
-    RowTable rows, const int32_t* __restrict__ order, int64_t nvec, int nt_result, float* __restrict__ out,
-    int short_window, int tail) {
+// Bulyan's second pass on the columns a lane holds (W of them: VEC in the body, 1 for the d % VEC trailing columns), given
+// their MMAX ranked values: shared by the kernel that writes the result and the one that only evaluates it.
+template <int N, int F, typename X, typename R>
+__device__ __forceinline__ void bulyan_columns(X& x, R& r, int short_window) {
   constexpr int MMAX = N - F - 2;
   constexpr int THETA = N - 2 * F - 2;
   constexpr int BETA = THETA - 2 * F;
-  static_assert(BETA >= 1, "bulyan needs n >= 4f+3");
-  // The m_max ranked row pointers live in SGPRs (loads then use the saddr form with one 32-bit byte offset
-  // per lane, like the column kernels).  Up to 25 of them are fetched with scalar loads only: `order` is
-  // uniform, and the row table — the first kernel argument, passed by value — is indexed in the kernarg
-  // segment itself.  A workgroup handles one column group per lane, so this prologue runs once per 256
-  // results: through LDS, a barrier and readfirstlane it costs 5 % of the kernel at n = 25 (163.5 -> 155.4 us,
-  // profiles/r02_g_bulyan_pass2_prologue.txt).  Above 25 pointers the scalar form runs out of SGPRs (16-60
-  // spilled, n = 51: 365 -> 390 us), so the larger instances keep the LDS form.
-  const float* ranked[MMAX];
-  if constexpr (MMAX <= 25) {
-    typedef const float* __attribute__((address_space(4))) const* KargTable;
-    const KargTable karg = (KargTable)__builtin_amdgcn_kernarg_segment_ptr();
-    // (the ranking: ONE vector load per wave — lane t fetches order[t] — then a v_readlane per pointer, see load_index_coherent)
-    const int mine = (int)(threadIdx.x & 63) < MMAX ? load_index_coherent(order + (threadIdx.x & 63)) : 0;
-#pragma unroll
-    for (int t = 0; t < MMAX; ++t) ranked[t] = (const float*)karg[__builtin_amdgcn_readlane(mine, t)];
-  } else {
-    __shared__ const float* ranked_lds[MMAX];
-    if (threadIdx.x < MMAX) ranked_lds[threadIdx.x] = rows.p[load_index_coherent(order + threadIdx.x)];
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < MMAX; ++t) {
-      const uint64_t p = reinterpret_cast<uint64_t>(ranked_lds[t]);
-      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p);
-      const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
-      ranked[t] = reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
-    }
-  }
   const float kNaN = __builtin_nanf("");
-  const uint32_t nv = (uint32_t)nvec;  // nvec * VEC * 4 < 2^32: the host splits longer gradients
-  auto load_group = [&](uint32_t off, float (&x)[VEC][MMAX]) {
-#pragma unroll
-    for (int t = 0; t < MMAX; ++t) {
-      float tmp[VEC];
-      load_stream_off<VEC>(ranked[t], off, tmp);
-#pragma unroll
-      for (int c = 0; c < VEC; ++c) x[c][t] = tmp[c];
-    }
-  };
-  // (generic over the number of columns a lane holds: VEC in the body, 1 for the d % VEC trailing columns)
-  auto rule = [&](auto& x, auto& r) {
+  {
     constexpr int W = (int)(sizeof(r) / sizeof(float));
 #pragma unroll
     for (int c = 0; c < W; ++c) {
@@ -136,7 +90,63 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(
         r[c] = has_nan ? kNaN : res;
       }
     }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Register-resident Bulyan pass 2 for a compile-time (n, f) and the default m = m_max.
+// ---------------------------------------------------------------------------
+//
+// (The chip-wide store-burst form that pays for the column kernels and the selected mean does not pay here: measured
+// in round 3 with identical checksums, 153.0 -> 154.1 us at n = 25, 357.7 -> 359.1 us at n = 51, 87.2 -> 85.8 us at
+// n = 15, profiles/r03_c_bulyan_pass2_burst_ab.txt.  It was removed.)
+template <int N, int F, int VEC>
+__global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(
+    RowTable rows, const int32_t* __restrict__ order, int64_t nvec, int nt_result, float* __restrict__ out,
+    int short_window, int tail) {
+  constexpr int MMAX = N - F - 2;
+  constexpr int THETA = N - 2 * F - 2;
+  constexpr int BETA = THETA - 2 * F;
+  static_assert(BETA >= 1, "bulyan needs n >= 4f+3");
+  // The m_max ranked row pointers live in SGPRs (loads then use the saddr form with one 32-bit byte offset
+  // per lane, like the column kernels).  Up to 25 of them are fetched with scalar loads only: `order` is
+  // uniform, and the row table — the first kernel argument, passed by value — is indexed in the kernarg
+  // segment itself.  A workgroup handles one column group per lane, so this prologue runs once per 256
+  // results: through LDS, a barrier and readfirstlane it costs 5 % of the kernel at n = 25 (163.5 -> 155.4 us,
+  // profiles/r02_g_bulyan_pass2_prologue.txt).  Above 25 pointers the scalar form runs out of SGPRs (16-60
+  // spilled, n = 51: 365 -> 390 us), so the larger instances keep the LDS form.
+  const float* ranked[MMAX];
+  if constexpr (MMAX <= 25) {
+    typedef const float* __attribute__((address_space(4))) const* KargTable;
+    const KargTable karg = (KargTable)__builtin_amdgcn_kernarg_segment_ptr();
+    // (the ranking: ONE vector load per wave — lane t fetches order[t] — then a v_readlane per pointer, see load_index_coherent)
+    const int mine = (int)(threadIdx.x & 63) < MMAX ? load_index_coherent(order + (threadIdx.x & 63)) : 0;
+#pragma unroll
+    for (int t = 0; t < MMAX; ++t) ranked[t] = (const float*)karg[__builtin_amdgcn_readlane(mine, t)];
+  } else {
+    __shared__ const float* ranked_lds[MMAX];
+    if (threadIdx.x < MMAX) ranked_lds[threadIdx.x] = rows.p[load_index_coherent(order + threadIdx.x)];
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < MMAX; ++t) {
+      const uint64_t p = reinterpret_cast<uint64_t>(ranked_lds[t]);
+      const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p);
+      const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+      ranked[t] = reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
+    }
+  }
+  const float kNaN = __builtin_nanf("");
+  const uint32_t nv = (uint32_t)nvec;  // nvec * VEC * 4 < 2^32: the host splits longer gradients
+  auto load_group = [&](uint32_t off, float (&x)[VEC][MMAX]) {
+#pragma unroll
+    for (int t = 0; t < MMAX; ++t) {
+      float tmp[VEC];
+      load_stream_off<VEC>(ranked[t], off, tmp);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) x[c][t] = tmp[c];
+    }
   };
+  auto rule = [&](auto& x, auto& r) { bulyan_columns<N, F>(x, r, short_window); };
   // the d % VEC trailing columns: one lane each, in the last workgroup (no second launch: 4.3 us of a C4 aggregation),
   // before the body so that nothing of it stays live across the main loop
   if (VEC > 1 && blockIdx.x == gridDim.x - 1 && (int)threadIdx.x < tail) {
@@ -160,6 +170,136 @@ __global__ __launch_bounds__(kBulBlock) void bulyan_pass2_kernel(
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------
+// Bulyan pass 2, evaluate only: ONE candidate of the attacks' factor search (attacks/identical.py:67-77) against Bulyan.
+// ---------------------------------------------------------------------------
+// The search ranks the stack honests + [avg + t * dir] * k from scalars (bm_attack_ranking) and needs, per candidate,
+// | pass2(ranked rows) - avg |^2.  The per-evaluation form writes the candidate vector (2 rows read, 1 written), runs
+// bm_bulyan_pass2 (m_max rows read — the copies of the candidate from cache —, 1 written) and bm_sqdist2 (2 read): four
+// launches.  Here the candidate exists in registers only — fma(t, dir, 1 * avg), the bits bm_multi_fma3 writes —, the
+// ranks that hold one of its copies take it there (a wave-uniform bit per rank; their table entries point at avg, so
+// that the load of such a rank is a harmless hit), the rule is the code of the kernel above (bulyan_columns) and the
+// objective is accumulated like bm_colwise_eval / bm_sqdist2 do (fp32 over 16 column groups per lane, fp64 beyond, one
+// partial per workgroup, eval_finish_kernel): the honest ranked rows + avg + dir read, NOTHING written, two launches.
+struct Pass2Candidate {
+  const float* avg;
+  const float* dir;
+  const double* t_dev;  // the factor in device memory (the device cursor's), or null: t_host
+  float t_host;
+  int h;                // table entries h .. n-1 are copies of the candidate
+};
+
+template <int N, int F, int VEC>
+__global__ __launch_bounds__(kBulBlock) void bulyan_pass2_eval_kernel(RowTable rows, const int32_t* __restrict__ order,
+                                                                      int64_t nvec, int short_window, Pass2Candidate cd,
+                                                                      double* __restrict__ partial) {
+  constexpr int MMAX = N - F - 2;
+  static_assert(N - 4 * F - 2 >= 1 && MMAX <= 64, "bulyan needs n >= 4f+3");
+  __shared__ const float* ranked_lds[MMAX];
+  __shared__ unsigned long long copies_lds;
+  __shared__ double red[kBulBlock / 64];
+  // (the prologue of the kernel above in its LDS form for every size: it runs once per workgroup, and the workgroups of
+  //  this kernel walk many column groups)
+  if (threadIdx.x < 64) {  // wave 0 (MMAX <= 64)
+    const int idx = (int)threadIdx.x < MMAX ? load_index_coherent(order + threadIdx.x) : 0;
+    if ((int)threadIdx.x < MMAX) ranked_lds[threadIdx.x] = rows.p[idx];
+    const unsigned long long copies = __builtin_amdgcn_ballot_w64((int)threadIdx.x < MMAX && idx >= cd.h);
+    if (threadIdx.x == 0) copies_lds = copies;
+  }
+  __syncthreads();
+  const float* ranked[MMAX];
+#pragma unroll
+  for (int t = 0; t < MMAX; ++t) {
+    const uint64_t p = reinterpret_cast<uint64_t>(ranked_lds[t]);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)p);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(p >> 32));
+    ranked[t] = reinterpret_cast<const float*>(((uint64_t)hi << 32) | lo);
+  }
+  const uint64_t cbits = copies_lds;
+  const uint32_t copies_lo = __builtin_amdgcn_readfirstlane((uint32_t)cbits);
+  const uint32_t copies_hi = __builtin_amdgcn_readfirstlane((uint32_t)(cbits >> 32));
+  const float tf = cd.t_dev != nullptr ? (float)cd.t_dev[0] : cd.t_host;
+  float acc = 0.0f;
+  double wide = 0.0;
+  int since = 0;
+  // nvec * VEC * 4 < 2^32 (the host refuses longer vectors): 32-bit byte offsets, saddr loads, as in the kernel above
+  const uint32_t nv = (uint32_t)nvec, stride = gridDim.x * kBulBlock;
+  for (uint32_t v = blockIdx.x * kBulBlock + threadIdx.x; v < nv; v += stride) {
+    const uint32_t off = v * (uint32_t)(VEC * sizeof(float));
+    float x[VEC][MMAX], r[VEC], a[VEC], dr[VEC], cand[VEC];
+    load_stream_off<VEC>(cd.avg, off, a);
+    load_stream_off<VEC>(cd.dir, off, dr);
+#pragma unroll
+    for (int t = 0; t < MMAX; ++t) {
+      float tmp[VEC];
+      load_stream_off<VEC>(ranked[t], off, tmp);
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) x[c][t] = tmp[c];
+    }
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) cand[c] = __builtin_fmaf(tf, dr[c], 1.0f * a[c]);  // bm_multi_fma3(out, avg, dir, 1, t): same bits
+#pragma unroll
+    for (int t = 0; t < MMAX; ++t) {
+      const bool copy = (((t < 32 ? copies_lo : copies_hi) >> (t & 31)) & 1u) != 0u;  // wave-uniform
+#pragma unroll
+      for (int c = 0; c < VEC; ++c) x[c][t] = copy ? cand[c] : x[c][t];
+    }
+    bulyan_columns<N, F>(x, r, short_window);
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) {
+      const float df = r[c] - a[c];  // aggregated.sub_(grad_avg) (identical.py:75)
+      acc = __builtin_fmaf(df, df, acc);
+    }
+    if (++since == 16) {
+      wide += (double)acc;
+      acc = 0.0f;
+      since = 0;
+    }
+  }
+  const double tot = block_reduce_sum<kBulBlock>(wide + (double)acc, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = tot;
+}
+
+template <int N, int F>
+static int launch_bulyan_eval(const float* const* honests, int h, const int32_t* order, int64_t d, const float* avg,
+                              const float* dir, float t, const double* t_dev, double* out, double* partial, hipStream_t s) {
+  constexpr int MMAX = N - F - 2;
+  constexpr int kMaxVec = (MMAX <= 20) ? 4 : (MMAX <= 44 ? 2 : 1);
+  RowTable tab{};
+  for (int i = 0; i < N; ++i) tab.p[i] = i < h ? honests[i] : avg;
+  const void* more[2] = {avg, dir};
+  int vec = common_vec_width(reinterpret_cast<const void* const*>(honests), h, nullptr);
+  const int vec2 = common_vec_width(more, 2, nullptr);
+  if (vec2 < vec) vec = vec2;
+  if (vec > kMaxVec) vec = kMaxVec;
+  const Pass2Candidate cd{avg, dir, t_dev, t, h};
+  int nparts = 0;
+  int64_t body = 0;
+  if (vec >= 2 && d / vec > 0) {
+    const int64_t nvec = d / vec;
+    const int grid = stream_grid(nvec, kBulBlock, kEvalMaxBlocks);
+    auto kern = vec == 4 ? bulyan_pass2_eval_kernel<N, F, (kMaxVec >= 4 ? 4 : 2)> : bulyan_pass2_eval_kernel<N, F, (kMaxVec >= 2 ? 2 : 1)>;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBulBlock), 0, s, tab, order, nvec, tuning().bulyan_short, cd, partial);
+    BM_LAUNCH_CHECK();
+    nparts = grid;
+    body = nvec * vec;
+  }
+  if (body < d) {
+    RowTable tail{};
+    for (int i = 0; i < N; ++i) tail.p[i] = (i < h ? honests[i] : avg) + body;
+    const Pass2Candidate ct{avg + body, dir + body, t_dev, t, h};
+    const int64_t rest = d - body;
+    const int grid = (body == 0) ? stream_grid(rest, kBulBlock, kEvalMaxBlocks) : 1;
+    hipLaunchKernelGGL((bulyan_pass2_eval_kernel<N, F, 1>), dim3(grid), dim3(kBulBlock), 0, s, tail, order, rest,
+                       tuning().bulyan_short, ct, partial + nparts);
+    BM_LAUNCH_CHECK();
+    nparts += grid;
+  }
+  hipLaunchKernelGGL(eval_finish_kernel<kEvalFinishThreads>, dim3(1), dim3(kEvalFinishThreads), 0, s, partial, nparts, out);
+  BM_LAUNCH_CHECK();
+  return 0;
 }
 
 // ---------------------------------------------------------------------------
@@ -409,6 +549,28 @@ extern "C" int bm_bulyan_pass2(const float* const* rows, int n, const int32_t* o
                      f, m, d, out);
   BM_LAUNCH_CHECK();
   return 0;
+}
+
+// (the worker counts of reproduce.py:122-209 with their largest f, like bm_colwise_eval)
+extern "C" int bm_bulyan_pass2_eval_supported(int n, int f, int m) {
+  return ((n == 11 && f == 2) || (n == 25 && f == 5) || (n == 51 && f == 12)) && m == n - f - 2 ? 1 : 0;
+}
+
+extern "C" int bm_bulyan_pass2_eval(const float* const* honests, int h, int copies, const int32_t* order, int f, int m,
+                                    int64_t d, const float* avg, const float* dir, float t, const double* t_dev, double* out,
+                                    void* ws, void* stream) {
+  using namespace bm;
+  const int n = h + copies;
+  if (honests == nullptr || order == nullptr || out == nullptr || ws == nullptr || h < 1 || copies < 1 || d < 0 ||
+      d > kMaxColsPerLaunch || (d > 0 && (avg == nullptr || dir == nullptr)) || !bm_bulyan_pass2_eval_supported(n, f, m))
+    return BM_EINVAL;
+  for (int i = 0; i < h && d > 0; ++i)
+    if (honests[i] == nullptr) return BM_EINVAL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  double* partial = static_cast<double*>(ws);
+  if (n == 11) return launch_bulyan_eval<11, 2>(honests, h, order, d, avg, dir, t, t_dev, out, partial, s);
+  if (n == 25) return launch_bulyan_eval<25, 5>(honests, h, order, d, avg, dir, t, t_dev, out, partial, s);
+  return launch_bulyan_eval<51, 12>(honests, h, order, d, avg, dir, t, t_dev, out, partial, s);
 }
 
 extern "C" int bm_aksel_pass1(const float* const* rows, int n, int64_t d, float* median_out,

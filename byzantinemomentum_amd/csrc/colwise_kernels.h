@@ -270,6 +270,26 @@ __global__ __launch_bounds__(kBurstThreads) void colwise_burst_kernel(RowTable r
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Evaluate-only kernels (search_eval.hip, bulyan.hip): a workgroup leaves ONE partial of the objective, at most kEvalMaxBlocks
+// workgroups per launch, and the finish kernel adds the partials in a fixed order.
+// ---------------------------------------------------------------------------------------------------
+constexpr int kEvalMaxBlocks = 2048;
+
+// out[0] = sum of the partials in a fixed order (1024 lanes: lane l adds l, l + 1024, ..., then the fixed tree of
+// block_reduce_sum): the search waits for this number before it can propose the next candidate, so the 64-deep
+// chain of dependent loads a single wave would walk (17.6 us measured) is worth removing
+constexpr int kEvalFinishThreads = 1024;
+template <int THREADS>  // (a template so that every translation unit that launches it may hold the definition)
+__global__ __launch_bounds__(THREADS) void eval_finish_kernel(const double* __restrict__ partial, int nparts,
+                                                                         double* __restrict__ out) {
+  __shared__ double red[THREADS / 64];
+  double tot = 0.0;
+  for (int b = threadIdx.x; b < nparts; b += THREADS) tot += partial[b];
+  const double r = block_reduce_sum<THREADS>(tot, red);
+  if (threadIdx.x == 0) out[0] = r;
+}
+
 // Measured alternative, not kept: an LDS-DMA variant (per-wave private [N][1 KiB] LDS slot filled by
 // global_load_lds_dwordx4, read back with ds_read_b128, next chunk's DMA in flight during the
 // network, no barrier) ran at 229 / 244 us against 194 / 195 us for this kernel at n = 25,

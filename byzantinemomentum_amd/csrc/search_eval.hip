@@ -21,8 +21,6 @@
 
 namespace bm {
 
-constexpr int kEvalMaxBlocks = 2048;
-
 template <int N, int OP, int VEC>
 __global__ __launch_bounds__(kColBlock) void colwise_eval_kernel(RowTable rows, int h, const float* __restrict__ avg,
                                                                  const float* __restrict__ dir, float t_host,
@@ -72,19 +70,6 @@ __global__ __launch_bounds__(kColBlock) void colwise_eval_kernel(RowTable rows, 
   if (threadIdx.x == 0) partial[blockIdx.x] = r;
 }
 
-// out[0] = sum of the partials in a fixed order (1024 lanes: lane l adds l, l + 1024, ..., then the fixed tree of
-// block_reduce_sum): the search waits for this number before it can propose the next candidate, so the 64-deep
-// chain of dependent loads a single wave would walk (17.6 us measured) is worth removing
-constexpr int kEvalFinishThreads = 1024;
-__global__ __launch_bounds__(kEvalFinishThreads) void eval_finish_kernel(const double* __restrict__ partial, int nparts,
-                                                                         double* __restrict__ out) {
-  __shared__ double red[kEvalFinishThreads / 64];
-  double tot = 0.0;
-  for (int b = threadIdx.x; b < nparts; b += kEvalFinishThreads) tot += partial[b];
-  const double r = block_reduce_sum<kEvalFinishThreads>(tot, red);
-  if (threadIdx.x == 0) out[0] = r;
-}
-
 template <int N, int OP>
 static int launch_eval(const float* const* rows, int h, int64_t d, int f, const float* avg, const float* dir, float t,
                        const double* t_dev, double* out, double* partial, hipStream_t s) {
@@ -120,7 +105,7 @@ static int launch_eval(const float* const* rows, int h, int64_t d, int f, const 
     nparts += grid;
   }
   // d == 0: no partial, the finish kernel writes zero (every rank of a sharded job reaches its all-reduce)
-  hipLaunchKernelGGL(eval_finish_kernel, dim3(1), dim3(kEvalFinishThreads), 0, s, partial, nparts, out);
+  hipLaunchKernelGGL(eval_finish_kernel<kEvalFinishThreads>, dim3(1), dim3(kEvalFinishThreads), 0, s, partial, nparts, out);
   BM_LAUNCH_CHECK();
   return 0;
 }
@@ -302,7 +287,7 @@ extern "C" int bm_sqdist2(const float* a, const float* b, int64_t d, double* out
     nparts += grid;
   }
   // d == 0: no partial, the finish kernel writes zero (every rank of a sharded job reaches its all-reduce)
-  hipLaunchKernelGGL(eval_finish_kernel, dim3(1), dim3(kEvalFinishThreads), 0, s, partial, nparts, out);
+  hipLaunchKernelGGL(eval_finish_kernel<kEvalFinishThreads>, dim3(1), dim3(kEvalFinishThreads), 0, s, partial, nparts, out);
   BM_LAUNCH_CHECK();
   return 0;
 }

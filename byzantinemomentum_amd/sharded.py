@@ -224,6 +224,12 @@ class HipBackend:
   def sqdist2(self, a, b):
     return self.stats.sqdist2(a, b)
 
+  def bulyan_pass2_eval_supported(self, n, f, m, d=0):
+    return self.stats.bulyan_pass2_eval_supported(n, f, m, d)
+
+  def bulyan_pass2_eval(self, *args, **kwargs):
+    return self.stats.bulyan_pass2_eval(*args, **kwargs)
+
   def order_pair_supported(self, h):
     return self.stats.order_pair_supported(h)
 

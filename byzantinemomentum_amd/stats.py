@@ -132,6 +132,35 @@ def sqdist2(a, b):
   return out
 
 
+def bulyan_pass2_eval_supported(n, f, m, d=0):
+  """Is there an evaluate-only instance of Bulyan's second pass for this shape (bm_bulyan_pass2_eval)?"""
+  return d <= (1 << 29) and bool(_lib.load().bm_bulyan_pass2_eval_supported(int(n), int(f), int(m)))
+
+
+def bulyan_pass2_eval(honests, copies, order, f, m, h_avg, direction, t):
+  """| pass2(honests + [h_avg + t * direction] * copies, order) - h_avg |^2 as a device fp64[1] tensor, the candidate in
+  registers only (bm_bulyan_pass2_eval): one candidate of attacks/identical.py:67-77 against Bulyan, given the ranking of
+  the stack (device int32 tensor; indices >= len(honests) name a copy of the candidate).  t: a number, or a DEVICE
+  float64 tensor.  No sync."""
+  honests = list(honests)
+  h, d, device = gars._validate(honests)
+  gars._validate([h_avg, direction] + honests[:1])
+  lib = _lib.load()
+  out = torch.empty(1, dtype=torch.float64, device=device)
+  ws = gars._Scratch.get(device, "ws_eval", nbytes=int(lib.bm_colwise_eval_workspace_bytes()))
+  t_dev = None
+  if isinstance(t, torch.Tensor):
+    if not (t.is_cuda and t.device == device and t.dtype == torch.float64 and t.numel() >= 1 and t.is_contiguous()):
+      raise gars.GarInputError("bulyan_pass2_eval: a tensor t must be a contiguous float64 tensor on the vectors' device")
+    t_dev, t = t, 0.0
+  with torch.cuda.device(device):
+    _lib.check(lib.bm_bulyan_pass2_eval(_lib.pointer_table(honests), h, int(copies), _ptr(order), int(f), int(m), d,
+                                        _ptr(h_avg), _ptr(direction), ctypes.c_float(float(t)),
+                                        _ptr(t_dev) if t_dev is not None else None, _ptr(out), _ptr(ws),
+                                        gars._stream(device)), "bm_bulyan_pass2_eval")
+  return out
+
+
 def order_pair_supported(h):
   """Is there a one-pass form of two order statistics of h rows (bm_order_pair)?"""
   return bool(_lib.load().bm_order_pair_supported(int(h)))

@@ -202,6 +202,7 @@ class AggregationStep:
 
     rule = lambda cand, t: self._aggregate(list(honests) + [cand] * k)  # noqa: E731
     n = h + k
+    bulyan_objective = None
     host_ranked = self.gar == "brute"  # (its checked call reads a status: a synchronisation per evaluation anyway)
     if self.line_search in ("auto", "host") and self.gar == "bulyan" and k >= 1 and h + 2 <= 64 and hasattr(ops, "bulyan_pass2") \
        and not (set(self.gar_args) - {"m"}):
@@ -219,6 +220,14 @@ class AggregationStep:
         order = linesearch.attack_ranking(ext, h, k, self.f_decl, "bulyan", t, m)
         rows, table = list(honests) + [cand] * k, ops.index_tensor(order + [0] * (64 - n), h_avg)
         return ops.bulyan_pass2(rows, table, self.f_decl, m)
+
+      if hasattr(ops, "bulyan_pass2_eval") and ops.bulyan_pass2_eval_supported(n, self.f_decl, m, h_avg.shape[0]):
+        # ... and pass 2 has an evaluate-only form for the shapes of the reference's experiments: the candidate in
+        # registers, the objective accumulated in the same kernel, nothing written (bm_bulyan_pass2_eval)
+        def bulyan_objective(t):
+          order = linesearch.attack_ranking(ext, h, k, self.f_decl, "bulyan", t, m)
+          table = ops.index_tensor(order + [0] * (64 - n), h_avg)
+          return ops.bulyan_pass2_eval(honests, k, table, self.f_decl, m, h_avg, direction, t)
     if self.line_search in ("auto", "host") and self.gar == "median" and k >= 1:
       # The lower median of the h honest values and k copies of ONE value b is monotone in b, equals b while b lies
       # between two order statistics of the honest values and stays at them outside: median(honests + [b] * k) =
@@ -243,7 +252,9 @@ class AggregationStep:
 
     def evaluate(t):
       """The objective of candidate t as a device fp64[1] tensor; t a number or the device cursor's tensor."""
-      if fused_eval:
+      if bulyan_objective is not None:
+        sq = bulyan_objective(t)
+      elif fused_eval:
         # trmean / phocas / meamed: candidate, rule and objective in ONE pass over the honest rows, nothing written
         # (bm_colwise_eval: h + 2 row passes instead of h + 5 read and 2 written); the same value at every column
         sq = ops.colwise_eval(self.gar, eval_rows, eval_copies, eval_f, h_avg, direction, t)

@@ -445,6 +445,16 @@ int bm_attack_line_search_device(const double* ext, int h, int k, int f, int rul
  * identical.py:75-76 for a candidate whose rule was run on the vectors; one pass over the two vectors (the n x n
  * distance pass spends three launches on them).  ws: bm_colwise_eval_workspace_bytes().  Partial sums in a fixed order. */
 int bm_sqdist2(const float* a, const float* b, int64_t d, double* out, void* ws, void* stream);
+/* out[0] = | pass2(honests + [avg + t * dir] * copies, order) - avg |^2 (fp64, DEVICE): bm_bulyan_pass2 on a stack whose
+ * last `copies` rows are ONE candidate of the factor search (identical.py:67-77), evaluate only — the candidate is formed
+ * in registers with the arithmetic of bm_multi_fma3, nothing is written.  `order` ranks the n = h + copies rows (indices
+ * >= h name a copy), e.g. by bm_attack_ranking.  t from the host, or from DEVICE memory when t_dev != NULL (one double,
+ * rounded to fp32).  Instances: (n, f) in {(11, 2), (25, 5), (51, 12)} with m = n - f - 2 (bm_bulyan_pass2_eval_supported),
+ * d <= 2^29.  ws: bm_colwise_eval_workspace_bytes(). */
+int bm_bulyan_pass2_eval_supported(int n, int f, int m);
+int bm_bulyan_pass2_eval(const float* const* honests, int h, int copies, const int32_t* order, int f, int m, int64_t d,
+                         const float* avg, const float* dir, float t, const double* t_dev, double* out, void* ws,
+                         void* stream);
 /* lo[j] = the value of rank il, hi[j] = the value of rank ih (0-based, ascending) among rows[0..h)[j]; a rank below 0 reads
  * -inf, a rank beyond h - 1 reads +inf; a NaN in the column makes both NaN.  One pass over the h rows (h <= 51:
  * bm_order_pair_supported).  With n = h + k, il = (n-1)/2 - k, ih = (n-1)/2 these are the lower medians (median.py:31-39)

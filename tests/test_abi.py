@@ -230,4 +230,20 @@ def test_device_search_entry_points_validate_arguments_without_gpu(lib):
   assert lib.bm_order_pair(rows, 20, 1000, 7, 12, None, buf, None) == _lib.EINVAL      # nowhere to write
   assert lib.bm_order_pair(rows, 20, 1000, 7, 12, buf, rows, None) == _lib.EINVAL      # a null row (the table is empty)
   assert lib.bm_order_pair(rows, 20, 0, 7, 12, None, None, None) == 0                  # empty vectors: nothing to do
-  assert lib.bm_abi_version() == 22
+  # ABI 23: Bulyan's second pass, evaluate only
+  sup = lib.bm_bulyan_pass2_eval_supported
+  assert sup(25, 5, 18) == 1 and sup(11, 2, 7) == 1 and sup(51, 12, 37) == 1
+  assert sup(25, 5, 17) == 0 and sup(15, 3, 10) == 0 and sup(51, 10, 39) == 0
+  ev = lib.bm_bulyan_pass2_eval
+  one = ctypes.c_float(1.0)
+  assert ev(None, 20, 5, rows, 5, 18, 1000, rows, rows, one, None, buf, buf, None) == _lib.EINVAL    # no rows
+  assert ev(rows, 20, 5, None, 5, 18, 1000, rows, rows, one, None, buf, buf, None) == _lib.EINVAL    # no ranking
+  assert ev(rows, 20, 5, rows, 5, 18, 1000, None, rows, one, None, buf, buf, None) == _lib.EINVAL    # no average
+  assert ev(rows, 20, 5, rows, 5, 18, 1000, rows, rows, one, None, None, buf, None) == _lib.EINVAL   # nowhere to write
+  assert ev(rows, 20, 5, rows, 5, 18, 1000, rows, rows, one, None, buf, None, None) == _lib.EINVAL   # no workspace
+  assert ev(rows, 20, 5, rows, 5, 17, 1000, rows, rows, one, None, buf, buf, None) == _lib.EINVAL    # m != n - f - 2
+  assert ev(rows, 19, 5, rows, 5, 17, 1000, rows, rows, one, None, buf, buf, None) == _lib.EINVAL    # n = 24: no instance
+  assert ev(rows, 20, 0, rows, 5, 18, 1000, rows, rows, one, None, buf, buf, None) == _lib.EINVAL    # no copy of the candidate
+  assert ev(rows, 20, 5, rows, 5, 18, (1 << 29) + 1, rows, rows, one, None, buf, buf, None) == _lib.EINVAL   # too long for one launch
+  assert ev(rows, 20, 5, rows, 5, 18, 1000, rows, rows, one, None, buf, buf, None) == _lib.EINVAL    # a null row (the table is empty)
+  assert lib.bm_abi_version() == 23

@@ -338,3 +338,57 @@ def test_order_pair_equals_the_two_medians_it_replaces(bm, h, k, d):
   stack = torch.stack(rows)
   assert torch.equal(lo[clean], stack.min(dim=0).values[clean]) and torch.equal(hi[clean], stack.max(dim=0).values[clean])
   assert bm.stats.order_pair_supported(51) and not bm.stats.order_pair_supported(52)
+
+
+# ---------------------------------------------------------------------------- #
+# ABI 23: Bulyan's second pass, evaluate only (bm_bulyan_pass2_eval)
+
+@pytest.mark.parametrize("n,f,d", [(11, 2, 65537), (25, 5, 1000003), (25, 5, 4099), (25, 5, 11173962), (51, 12, 200002)])
+def test_bulyan_pass2_evaluate_only_form_against_the_written_form(bm, n, f, d):
+  """bm_bulyan_pass2_eval against the three launches it replaces — the candidate vector written (bm_multi_fma3), Bulyan's
+  second pass on honests + [candidate] * f (bulyan.py:64-84) and |out - avg|^2 (bm_sqdist2, identical.py:75-76) — under
+  the ranking of that very stack: the same bits where both sums walk 16-byte groups (n = 11, 25), 1e-6 where the wide
+  instance holds 8-byte groups (n = 51) or the views are only 4-byte aligned; the factor from the host and from device
+  memory; a NaN column answered NaN by both; shapes without an instance refused."""
+  from byzantinemomentum_amd import _lib, gars
+  h, m = n - f, n - f - 2
+  gen = torch.Generator(device=DEV).manual_seed(97 + n)
+  base = 0.2 * torch.randn(d + 1, device=DEV, generator=gen)
+  store = [base + (0.5 + 0.05 * i) * torch.randn(d + 1, device=DEV, generator=gen) for i in range(h)]
+  assert bm.stats.bulyan_pass2_eval_supported(n, f, m, d) and not bm.stats.bulyan_pass2_eval_supported(n, f, m - 1, d)
+  assert not bm.stats.bulyan_pass2_eval_supported(n + 4, f, m + 4, d) and not bm.stats.bulyan_pass2_eval_supported(n, f, m, (1 << 29) + 1)
+  for off in (0, 1):
+    honests = [g[off:off + d] for g in store]
+    avg = torch.stack(honests).mean(dim=0)
+    direction = -avg if n != 25 else torch.stack(honests).var(dim=0).sqrt_()
+    exact = off == 0 and n in (11, 25)
+    for t in (0.0, 0.6, 1.1, 7.5, -3.0):
+      cand = torch.empty_like(avg)
+      bm.stats.multi_fma3([cand], [avg], [direction], 1.0, t)
+      rows = honests + [cand] * f
+      gars.invalidate_rank_cache()
+      order, _ = gars._rank(rows, f, m, _lib.RANK_BULYAN)
+      want = bm.stats.sqdist2(gars.bulyan_pass2(rows, order, f, m), avg)
+      got = bm.stats.bulyan_pass2_eval(honests, f, order, f, m, avg, direction, t)
+      got_dev = bm.stats.bulyan_pass2_eval(honests, f, order, f, m, avg, direction,
+                                           torch.tensor([t], dtype=torch.float64, device=DEV))
+      assert torch.equal(got, got_dev), (n, t)
+      if exact:
+        assert torch.equal(got, want), (n, off, t, got.item(), want.item())
+      else:
+        assert abs(got.item() - want.item()) <= 1e-6 * want.item() + 1e-30, (n, off, t, got.item(), want.item())
+      assert want.item() > 0 or t == 0.0
+  honests[1][5] = math.nan
+  avg2 = torch.stack([g.nan_to_num() for g in honests]).mean(dim=0)
+  cand = torch.empty_like(avg2)
+  bm.stats.multi_fma3([cand], [avg2], [direction], 1.0, 0.9)
+  rows = honests + [cand] * f
+  gars.invalidate_rank_cache()
+  honests[1][5] = 0.0
+  order, _ = gars._rank(honests + [cand] * f, f, m, _lib.RANK_BULYAN)   # (a ranking from finite rows: the NaN is the second pass's business)
+  honests[1][5] = math.nan
+  want = bm.stats.sqdist2(gars.bulyan_pass2(rows, order, f, m), avg2)
+  got = bm.stats.bulyan_pass2_eval(honests, f, order, f, m, avg2, direction, 0.9)
+  assert math.isnan(want.item()) == math.isnan(got.item())
+  with pytest.raises(Exception):
+    bm.stats.bulyan_pass2_eval(honests[:-1], f, order, f, m, avg2, direction, 0.9)   # n - 1 rows: no instance
