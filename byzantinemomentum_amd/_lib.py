@@ -125,6 +125,8 @@ SIGNATURES = {
                                           ctypes.c_void_p, ctypes.c_void_p]),
   "bm_sqdist2": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
                                 ctypes.c_void_p]),
+  "bm_attack_ranking_device": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                              ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
   "bm_bulyan_pass2_eval_supported": (ctypes.c_int, [ctypes.c_int, ctypes.c_int, ctypes.c_int]),
   "bm_bulyan_pass2_eval": (ctypes.c_int, [_c_float_pp, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                           ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_float, ctypes.c_void_p,

@@ -104,7 +104,13 @@ constexpr int kTraceSlots = 12;
 template <bool TRACE>
 __global__ __launch_bounds__(kSearchBlock) void attack_search_kernel(const double* __restrict__ ext, int h, int k, int f,
                                                                      int rule, int m, int evals, int negative,
-                                                                     double* __restrict__ out) {
+                                                                     double* __restrict__ out, const double* __restrict__ t_dev,
+                                                                     int32_t* __restrict__ order_out, int take_arg) {
+  // RANKING MODE (order_out != null; bm_attack_ranking_device): ONE candidate, its factor read from device memory, and
+  // instead of the objective the stable ranking of the n scores — order_out[r] = the row of rank r, padded with zeros to
+  // 64 entries: what bm_krum_rank would give for honests + [avg + t att] * k (Bulyan's searches rank with it; take_arg =
+  // the number of distances a score adds, m for Bulyan's ranking, bulyan.py:48-62).
+  const bool ranking = order_out != nullptr;
   const unsigned long long clock0 = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
   extern __shared__ double search_smem[];
   const int n = h + k, e = h + 2, tid = threadIdx.x, ld = search_ld(h);
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(kSearchBlock) void attack_search_kernel(const doubl
   const double w = honest ? attack_w(a, c, ext[lane * e + h + 1]) : 0.0;
   const double* const uu = UU + (honest ? lane : 0) * ld;
   const double* const hs = HS + (honest ? lane : 0) * ld;
-  int take = n - f - 1;  // krum.py:59-60
+  int take = take_arg >= 0 ? take_arg : n - f - 1;  // krum.py:59-60
   take = take > n - 1 ? n - 1 : take;
   take = take < 0 ? 0 : take;
   const int count = krum ? m : n;
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(kSearchBlock) void attack_search_kernel(const doubl
   for (int ev = 0; ev < evals; ++ev) {  // (every lane runs the cursor: the same values everywhere)
     cursor_propose(&cur);
     const double x = cur.probe;
-    const double t = negative ? -x : x;  // identical.py:70-71
+    const double t = ranking ? t_dev[0] : (negative ? -x : x);  // identical.py:70-71
     stamp(ev, 0);
     if (krum) {
       // dq_j = |h_j - byz(t)| in lane j of every wave.  The Byzantine row needs them in ascending order: every wave counts
@@ -274,9 +280,13 @@ __global__ __launch_bounds__(kSearchBlock) void attack_search_kernel(const doubl
 #pragma unroll
         for (int q = 0; q < kSearchWaves; ++q) rank += PART[q * BM_MAX_ROWS + (lane < n ? lane : 0)];
         selected = __builtin_amdgcn_ballot_w64(lane < n && rank < m);  // krum.py:78-80: the m best scores
+        if (ranking) {  // (the ranks of the n rows are a permutation of 0 .. n-1 — unless a score is NaN: zeros first, then the rows)
+          order_out[lane] = 0;
+          if (lane < n && rank < BM_MAX_ROWS) order_out[rank] = lane;
+        }
       }
       stamp(ev, 6);
-      if (krum || ev == 0) {
+      if (!ranking && (krum || ev == 0)) {
         // row sums of <u_i, u_j> over the selected honest j in index order, as attack_row_sum (search_core.h) forms them:
         // every column of the row's span adds its value or 0.0 (the loads of a group of eight leave together)
         // — in two halves of the span, two chains of additions in flight
@@ -304,7 +314,7 @@ __global__ __launch_bounds__(kSearchBlock) void attack_search_kernel(const doubl
       stamp(ev, 8);
       const int kb = __builtin_popcountll(h >= 64 ? 0ull : (selected >> h));
       const double y = attack_objective_value(quad, lin, kb, t, c, count);
-      if (lane == 0) {
+      if (lane == 0 && !ranking) {
         out[1 + 2 * ev] = x;
         out[2 + 2 * ev] = y;
         Y[0] = y;
@@ -312,10 +322,10 @@ __global__ __launch_bounds__(kSearchBlock) void attack_search_kernel(const doubl
       stamp(ev, 9);
     }
     __syncthreads();
-    cursor_report(&cur, Y[0]);
+    if (!ranking) cursor_report(&cur, Y[0]);
     stamp(ev, 10);
   }
-  if (tid == 0) out[0] = cur.best_x;
+  if (tid == 0 && !ranking) out[0] = cur.best_x;
 }
 
 // The cursor of the exploration kept in DEVICE memory, for the searches whose candidates are evaluated by d-sized kernels
@@ -374,7 +384,31 @@ extern "C" int bm_attack_line_search_device(const double* ext, int h, int k, int
   const int rc = lds_opt_in(reinterpret_cast<const void*>(kernel), lds, 0);
   if (rc != 0) return rc;
   hipLaunchKernelGGL(kernel, dim3(1), dim3(kSearchBlock), lds, static_cast<hipStream_t>(stream), ext, h, k, f, rule, m, evals,
-                     negative ? 1 : 0, out);
+                     negative ? 1 : 0, out, static_cast<const double*>(nullptr), static_cast<int32_t*>(nullptr), -1);
+  BM_LAUNCH_CHECK();
+  return 0;
+}
+
+// bm_attack_ranking (linesearch.cpp) on the device, the factor read from DEVICE memory: the ranking of
+// honests + [avg + t att] * k from the (h+2)^2 scalars where bm_pairwise_sqdist left them.  One workgroup, the machinery
+// of the search kernel above for one candidate (its set-up included: ~15 us); no copy, no synchronisation — the searches
+// against Bulyan then keep their cursor on the device like the others.
+extern "C" int bm_attack_ranking_device(const double* ext, int h, int k, int f, int mode, int m, const double* t_dev,
+                                        int32_t* order_out, void* stream) {
+  using namespace bm;
+  const int n = h + k;
+  if (ext == nullptr || order_out == nullptr || t_dev == nullptr || h < 1 || k < 1 || n > BM_MAX_ROWS || f < 0 ||
+      (mode != BM_RANK_KRUM && mode != BM_RANK_BULYAN))
+    return BM_EINVAL;
+  if (m <= 0) m = n - f - 2;
+  if (m < 1 || m > n) return BM_EINVAL;
+  const int take = mode == BM_RANK_KRUM ? n - f - 1 : m;
+  const size_t lds = search_lds_bytes(h);
+  auto kernel = attack_search_kernel<false>;
+  const int rc = lds_opt_in(reinterpret_cast<const void*>(kernel), lds, 0);
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL(kernel, dim3(1), dim3(kSearchBlock), lds, static_cast<hipStream_t>(stream), ext, h, k, f, (int)BM_RULE_KRUM,
+                     m, 1, 0, static_cast<double*>(nullptr), t_dev, order_out, take);
   BM_LAUNCH_CHECK();
   return 0;
 }

@@ -224,6 +224,9 @@ class HipBackend:
   def sqdist2(self, a, b):
     return self.stats.sqdist2(a, b)
 
+  def attack_ranking_device(self, *args, **kwargs):
+    return self.stats.attack_ranking_device(*args, **kwargs)
+
   def bulyan_pass2_eval_supported(self, n, f, m, d=0):
     return self.stats.bulyan_pass2_eval_supported(n, f, m, d)
 

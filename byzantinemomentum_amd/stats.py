@@ -457,6 +457,25 @@ def attack_search_device(ext, h, k, f, rule, evals=16, negative=False, m=None):
   return out
 
 
+def attack_ranking_device(ext, h, k, f, mode, t_dev, m=None):
+  """linesearch.attack_ranking on the device (bm_attack_ranking_device): the ranking of honests + [avg + t*att] * k as a
+  device int32[64] tensor (the n rows by rank, then zeros) from the DEVICE (h+2) x (h+2) matrix and a factor in DEVICE
+  memory (float64[1]) — what bm_bulyan_pass2 / bm_bulyan_pass2_eval take as `order`.  Nothing is copied or awaited."""
+  if not (isinstance(ext, torch.Tensor) and ext.is_cuda and ext.dtype == torch.float64 and ext.is_contiguous()
+          and tuple(ext.shape) == (h + 2, h + 2)):
+    raise gars.GarInputError(f"ext must be a contiguous float64 device tensor of shape ({h + 2}, {h + 2})")
+  if not (isinstance(t_dev, torch.Tensor) and t_dev.is_cuda and t_dev.device == ext.device and t_dev.dtype == torch.float64
+          and t_dev.numel() >= 1 and t_dev.is_contiguous()):
+    raise gars.GarInputError("attack_ranking_device: the factor must be a contiguous float64 tensor on the matrix's device")
+  lib = _lib.load()
+  order = torch.empty(_lib.MAX_ROWS, dtype=torch.int32, device=ext.device)
+  mode_id = {"krum": _lib.RANK_KRUM, "bulyan": _lib.RANK_BULYAN}[mode]
+  with torch.cuda.device(ext.device):
+    _lib.check(lib.bm_attack_ranking_device(_ptr(ext), h, k, f, mode_id, m or 0, _ptr(t_dev), _ptr(order),
+                                            gars._stream(ext.device)), "bm_attack_ranking_device")
+  return order
+
+
 def clip_factors_from_sq(sq, k, clip):
   """Device float32 factors from a device fp64 tensor of k squared norms (possibly all-reduced)."""
   lib = _lib.load()

@@ -212,22 +212,27 @@ class AggregationStep:
       m = self.gar_args.get("m") or n - self.f_decl - 2
       unit = torch.empty_like(h_avg)
       ops.multi_fma3([unit], [h_avg], [direction], 1.0, 1.0)
-      ext = self._fetch(agg.global_sqdist(list(honests) + [h_avg, unit]))
+      sq_dev = agg.global_sqdist(list(honests) + [h_avg, unit])
+      # ranked where the matrix is, from the factor the device cursor left there (bm_attack_ranking_device: no copy, no
+      # synchronisation) — or on the host from the number the host's cursor proposed (one copy of the matrix per search)
+      device_ranked = self.line_search == "auto" and hasattr(ops, "attack_ranking_device") and sq_dev.is_cuda
+      ext = None if device_ranked else self._fetch(sq_dev)
+      host_ranked = not device_ranked
 
-      host_ranked = True
+      def ranking(t):
+        if isinstance(t, torch.Tensor):
+          return ops.attack_ranking_device(sq_dev, h, k, self.f_decl, "bulyan", t, m)
+        order = linesearch.attack_ranking(ext, h, k, self.f_decl, "bulyan", t, m)
+        return ops.index_tensor(order + [0] * (64 - n), h_avg)
 
       def rule(cand, t):  # noqa: F811
-        order = linesearch.attack_ranking(ext, h, k, self.f_decl, "bulyan", t, m)
-        rows, table = list(honests) + [cand] * k, ops.index_tensor(order + [0] * (64 - n), h_avg)
-        return ops.bulyan_pass2(rows, table, self.f_decl, m)
+        return ops.bulyan_pass2(list(honests) + [cand] * k, ranking(t), self.f_decl, m)
 
       if hasattr(ops, "bulyan_pass2_eval") and ops.bulyan_pass2_eval_supported(n, self.f_decl, m, h_avg.shape[0]):
         # ... and pass 2 has an evaluate-only form for the shapes of the reference's experiments: the candidate in
         # registers, the objective accumulated in the same kernel, nothing written (bm_bulyan_pass2_eval)
         def bulyan_objective(t):
-          order = linesearch.attack_ranking(ext, h, k, self.f_decl, "bulyan", t, m)
-          table = ops.index_tensor(order + [0] * (64 - n), h_avg)
-          return ops.bulyan_pass2_eval(honests, k, table, self.f_decl, m, h_avg, direction, t)
+          return ops.bulyan_pass2_eval(honests, k, ranking(t), self.f_decl, m, h_avg, direction, t)
     if self.line_search in ("auto", "host") and self.gar == "median" and k >= 1:
       # The lower median of the h honest values and k copies of ONE value b is monotone in b, equals b while b lies
       # between two order statistics of the honest values and stays at them outside: median(honests + [b] * k) =
@@ -269,8 +274,8 @@ class AggregationStep:
 
     if self.line_search == "auto" and not host_ranked and hasattr(ops, "device_search") and h_avg.is_cuda:
       # the cursor of the exploration in device memory: every evaluation reads its factor there and leaves its objective
-      # there — the host queues the whole search and waits for none of it (Bulyan's candidates are ranked on the host
-      # from t, and Brute's checked call synchronises by itself: those keep the host's cursor)
+      # there — the host queues the whole search and waits for none of it (Bulyan's candidates are ranked by one
+      # workgroup from that factor; Brute's checked call synchronises by itself and keeps the host's cursor)
       cursor = ops.device_search(h_avg.device, self.attack_evals, self.attack_negative)
       y = None
       for _ in range(self.attack_evals):

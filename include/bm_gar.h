@@ -445,6 +445,11 @@ int bm_attack_line_search_device(const double* ext, int h, int k, int f, int rul
  * identical.py:75-76 for a candidate whose rule was run on the vectors; one pass over the two vectors (the n x n
  * distance pass spends three launches on them).  ws: bm_colwise_eval_workspace_bytes().  Partial sums in a fixed order. */
 int bm_sqdist2(const float* a, const float* b, int64_t d, double* out, void* ws, void* stream);
+/* bm_attack_ranking on the DEVICE, the factor read from DEVICE memory (one double): order_out[0..63] (int32, DEVICE; the n
+ * rows by rank, then zeros) for honests + [avg + t*att] * k, from the matrix where bm_pairwise_sqdist left it.  One
+ * workgroup; no copy, no synchronisation.  k >= 1.  mode: BM_RANK_KRUM or BM_RANK_BULYAN (m as for bm_krum_rank). */
+int bm_attack_ranking_device(const double* ext, int h, int k, int f, int mode, int m, const double* t_dev,
+                             int32_t* order_out, void* stream);
 /* out[0] = | pass2(honests + [avg + t * dir] * copies, order) - avg |^2 (fp64, DEVICE): bm_bulyan_pass2 on a stack whose
  * last `copies` rows are ONE candidate of the factor search (identical.py:67-77), evaluate only — the candidate is formed
  * in registers with the arithmetic of bm_multi_fma3, nothing is written.  `order` ranks the n = h + copies rows (indices

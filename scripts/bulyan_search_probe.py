@@ -1,6 +1,7 @@
 """The factor search against Bulyan (attacks/identical.py:67-77, 16 evaluations) with the evaluate-only second pass
 (bm_bulyan_pass2_eval: candidate in registers, objective in the same kernel) and with the written form it replaces
-(bm_multi_fma3 + bm_bulyan_pass2 + bm_sqdist2) — same ranking on the host, same candidates.  C4 shape (n = 25, f = 5) and the
+(bm_multi_fma3 + bm_bulyan_pass2 + bm_sqdist2), both with the cursor and the ranking on the device (line_search="auto"), and
+the evaluate-only form with cursor and ranking on the host (line_search="host") — same candidates.  C4 shape (n = 25, f = 5) and the
 reference's largest (n = 51, f = 12) at d = 11 173 962, the two forms alternating, wall clock per search, synchronised
 after every search; then one evaluation of each form under HIP events."""
 import os
@@ -32,13 +33,26 @@ for n, f in ((25, 5), (51, 12)):
       runner.ops.bulyan_pass2_eval_supported = fn
       torch.cuda.synchronize()
       t0 = time.perf_counter()
-      found[name] = (runner._search_factor(honests, avg, direction), list(runner.last_search))
+      runner.last_factor = runner._search_factor(honests, avg, direction)
       torch.cuda.synchronize()
       if rep >= 2:
         times[name].append((time.perf_counter() - t0) * 1e3)
+      found[name] = (runner.last_factor, list(runner.last_search))
   runner.ops.bulyan_pass2_eval_supported = supported
+  runner.last_factor = found["evaluate-only"][0]
   assert found["evaluate-only"][0] == found["written"][0], found
   worst = max(abs(a[1] - b[1]) / abs(b[1]) for a, b in zip(found["evaluate-only"][1], found["written"][1]))
+  # the same search with the cursor and the ranking on the host (line_search="host": one synchronisation per evaluation)
+  hosted = AggregationStep(n, f, f, gar="bulyan", attack_evals=16, nb_past=0, line_search="host")
+  times["cursor and ranking on the host (evaluate-only)"] = []
+  for rep in range(10):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    found["host"] = (hosted._search_factor(honests, avg, direction), list(hosted.last_search))
+    torch.cuda.synchronize()
+    if rep >= 2:
+      times["cursor and ranking on the host (evaluate-only)"].append((time.perf_counter() - t0) * 1e3)
+  assert found["host"][0] == runner.last_factor and found["host"][1] == found["evaluate-only"][1], (found["host"], found["evaluate-only"])
   line = f"n={n} f={f} d={d}"
   for name, each in times.items():
     line += f"  {name}: {sorted(each)[len(each) // 2]:.3f} ms per search"

@@ -164,7 +164,7 @@ case $name in
     BM_TEST_POISON=0 timeout 600 python -m pytest tests/test_gpu_zz_multirank.py tests/test_gpu_reference_loop.py -m gpu -x -q > $out/pytest_multirank_loop.log 2>&1; tail -3 $out/pytest_multirank_loop.log
     ;;
   bulyaneval)  # ABI 23: Bulyan's second pass, evaluate only — its tests, the search tests, the A/B of the two forms
-    timeout 900 python -m pytest tests/test_gpu_search_device.py -m gpu -x -q -k "bulyan or sqdist2 or order_pair" > $out/pytest_new.log 2>&1; tail -5 $out/pytest_new.log
+    timeout 900 python -m pytest tests/test_gpu_search_device.py -m gpu -x -q > $out/pytest_new.log 2>&1; tail -5 $out/pytest_new.log
     timeout 900 python -m pytest tests/test_gpu_parity_r3.py tests/test_gpu_parity.py tests/test_gpu_parity_r2.py -m gpu -x -q -k "bulyan" > $out/pytest_bulyan.log 2>&1; tail -3 $out/pytest_bulyan.log
     timeout 600 python scripts/bulyan_search_probe.py 2>&1 | grep -v amdgpu.ids > $out/bulyan_search_probe.txt; cat $out/bulyan_search_probe.txt | cut -c1-400
     ;;

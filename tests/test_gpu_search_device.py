@@ -392,3 +392,77 @@ def test_bulyan_pass2_evaluate_only_form_against_the_written_form(bm, n, f, d):
   assert math.isnan(want.item()) == math.isnan(got.item())
   with pytest.raises(Exception):
     bm.stats.bulyan_pass2_eval(honests[:-1], f, order, f, m, avg2, direction, 0.9)   # n - 1 rows: no instance
+
+
+# ---------------------------------------------------------------------------- #
+# ABI 23: the ranking of a candidate stack on the device (bm_attack_ranking_device)
+
+def _rankings(bm, ext_dev, h, k, f, mode, m, ts, tag):
+  from byzantinemomentum_amd import linesearch
+  host_ext = ext_dev.cpu().contiguous()
+  n = h + k
+  for t in ts:
+    t_dev = torch.tensor([t], dtype=torch.float64, device=DEV)
+    got = bm.stats.attack_ranking_device(ext_dev, h, k, f, mode, t_dev, m).cpu().tolist()
+    want = linesearch.attack_ranking(host_ext, h, k, f, mode, t, m)
+    assert got[:n] == want and got[n:] == [0] * (64 - n), (tag, mode, t, got, want)
+
+
+@pytest.mark.parametrize("kind", ["hetero", "tight", "duplicates"])
+@pytest.mark.parametrize("shape", [s for s in SHAPES if s[1] >= 1], ids=lambda s: "h%d-k%d-f%d-m%s-e%d" % s)
+def test_device_ranking_equals_host_ranking_on_stacks(bm, shape, kind):
+  """bm_attack_ranking_device against bm_attack_ranking (linesearch.cpp; itself the ranking of the rank kernel on the
+  materialised stack, tests/test_gpu_parity_r3.py): the whole permutation, Krum's scores and Bulyan's (the m smallest
+  distances, bulyan.py:48-62), factors of both signs, zero, tiny and huge — stacks with exact ties included."""
+  h, k, f, m, _ = shape
+  ext = _ext_of_stack(bm, h, 20011, 7 * h + k, kind)
+  for mode in ("krum", "bulyan"):
+    _rankings(bm, ext, h, k, f, mode, m, (0.0, 0.3, 1.0, 1.1, -2.5, 17.0, 1e-9, 32767.0), (shape, kind))
+
+
+def test_device_ranking_equals_host_ranking_on_adversarial_matrices(bm):
+  """Integer matrices (ties in every row and among the scores), att = 0, a huge |att|^2, asymmetric low bits: the device
+  ranking is the host's, rank by rank."""
+  gen = torch.Generator().manual_seed(199)
+  cases = 0
+  for h, k, f in ((7, 2, 2), (20, 5, 5), (39, 12, 12), (50, 14, 14), (63, 1, 1)):
+    e = h + 2
+    for trial in range(9):
+      a = torch.randint(0, 6, (e, e), generator=gen).double()
+      ext = a + a.t()
+      ext.fill_diagonal_(0.0)
+      if trial % 3 == 1:
+        ext[h, h + 1] = ext[h + 1, h] = 0.0
+      if trial % 3 == 2:
+        ext[h, h + 1] = ext[h + 1, h] = 1e12
+      if trial >= 6:
+        ext = ext * (0.5 + torch.rand(e, e, generator=gen).double())
+      dev = ext.contiguous().to(DEV)
+      for mode in ("krum", "bulyan"):
+        _rankings(bm, dev, h, k, f, mode, None, (0.0, 0.5, -1.0, 3.0), (h, k, f, trial))
+        cases += 1
+  assert cases == 90
+
+
+def test_bulyan_search_with_the_cursor_on_the_device_matches_the_host_cursor(bm):
+  """AggregationStep against Bulyan: line_search="auto" ranks every candidate on the device from the factor the device
+  cursor left there and evaluates pass 2 in place (no synchronisation in the search), "host" ranks on the host from the
+  host cursor's number — same candidates, same rankings, hence the same objectives bit for bit, the same factor and the
+  same aggregated gradient; n = 25 (evaluate-only pass 2) and n = 15 (no instance: the written form)."""
+  from byzantinemomentum_amd.step import AggregationStep
+  for n, f, d, attack, negative in ((25, 5, 200003, "empire", False), (15, 3, 65537, "little", True), (51, 12, 40001, "empire", False)):
+    h = n - f
+    gen = torch.Generator(device=DEV).manual_seed(41 + n)
+    base = 0.2 * torch.randn(d, device=DEV, generator=gen)
+    honests = [base + (0.5 + 0.05 * i) * torch.randn(d, device=DEV, generator=gen) for i in range(h)]
+    traces = {}
+    for mode in ("auto", "host"):
+      step = AggregationStep(n, f, f, gar="bulyan", momentum=0.9, dampening=0.9, momentum_at="update", attack=attack,
+                             attack_factor=1.1, nb_past=0, attack_evals=12, attack_negative=negative, line_search=mode)
+      out = step.run([g.clone() for g in honests])
+      if mode == "auto":
+        assert isinstance(step._factor_now, torch.Tensor), "the device cursor must leave its factor on the device"
+      traces[mode] = (step.last_factor, list(step.last_search), out)
+    (fa, sa, oa), (fh, sh, oh) = traces["auto"], traces["host"]
+    assert sa == sh and fa == fh and len(sa) == 12, (n, sa, sh)
+    assert torch.equal(oa, oh), n
