@@ -17,7 +17,8 @@ What a replay does NOT do is run the Python of the call again: the shapes, the r
 are those of the recording.  Contents may change freely; a stack at other addresses needs its own GraphedCall.
 
 `fn` must not synchronise with the host while it is recorded.  Calls that do, and therefore cannot be graphed: the
-factor search of the attacks (`AggregationStep(attack_evals=...)`: `.item()` per evaluation), `floats()`, sharded
+attacks' factor search against Brute and any search with `line_search="host"` / `"generic"` (a read per evaluation; with
+`"auto"` the searches against every other rule keep cursor, ranking and factor on the device), `floats()`, sharded
 rules over torch.distributed collectives that stage through the host, and `ShardedAggregator.brute` with a backend
 that has no device search (the HIP backend has one, bm_brute_select_device: its brute IS capturable; the status of
 the search stays on the device until `check_brute()` / `floats()`).  A failed recording raises GraphCaptureError and

@@ -246,4 +246,12 @@ def test_device_search_entry_points_validate_arguments_without_gpu(lib):
   assert ev(rows, 20, 0, rows, 5, 18, 1000, rows, rows, one, None, buf, buf, None) == _lib.EINVAL    # no copy of the candidate
   assert ev(rows, 20, 5, rows, 5, 18, (1 << 29) + 1, rows, rows, one, None, buf, buf, None) == _lib.EINVAL   # too long for one launch
   assert ev(rows, 20, 5, rows, 5, 18, 1000, rows, rows, one, None, buf, buf, None) == _lib.EINVAL    # a null row (the table is empty)
+  rk = lib.bm_attack_ranking_device
+  assert rk(None, 20, 5, 5, _lib.RANK_BULYAN, 0, buf, rows, None) == _lib.EINVAL     # no matrix
+  assert rk(buf, 20, 5, 5, _lib.RANK_BULYAN, 0, None, rows, None) == _lib.EINVAL     # no factor
+  assert rk(buf, 20, 5, 5, _lib.RANK_BULYAN, 0, buf, None, None) == _lib.EINVAL      # nowhere to write
+  assert rk(buf, 20, 0, 5, _lib.RANK_BULYAN, 0, buf, rows, None) == _lib.EINVAL      # no copy of the candidate
+  assert rk(buf, 60, 5, 5, _lib.RANK_KRUM, 0, buf, rows, None) == _lib.EINVAL        # n > BM_MAX_ROWS
+  assert rk(buf, 20, 5, 5, 7, 0, buf, rows, None) == _lib.EINVAL                     # no such mode
+  assert rk(buf, 20, 5, 5, _lib.RANK_KRUM, 26, buf, rows, None) == _lib.EINVAL       # m > n
   assert lib.bm_abi_version() == 23
