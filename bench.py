@@ -881,13 +881,15 @@ def attack_search(bm, honests, n, f, d, evals=16, gar="krum"):
   evaluations are queued without a synchronisation; `host_scalar_form_ms` = the same evaluations driven from the host).
   Against the median (C2 shape): every candidate as the middle of (candidate, lo, hi), lo / hi being two order
   statistics of the honest rows formed once per search (the key stays `scalar_form_ms`), and the reference's form.
-  Against Bulyan (C4 shape): every candidate ranked on the host from one distance pass, pass 2 alone on the vectors.
+  Against Bulyan (C4 shape): every candidate ranked from the scalars of one distance pass — by one workgroup from the
+  factor in device memory (bm_attack_ranking_device), on the host in `host_scalar_form_ms` —, pass 2 alone on the vectors,
+  evaluate only (bm_bulyan_pass2_eval).
   Against the trimmed mean (C2 shape; phocas and meamed alike): every candidate in one pass over the honest rows that
   writes nothing (bm_colwise_eval; the key stays `scalar_form_ms`)."""
   from byzantinemomentum_amd.step import AggregationStep
   avg, _, direction = bm.stats.stack_stats_async(honests, scale=1.0, attack="empire", direction=True)
   res = {"config": f"empire against {gar}, n={n}, f={f}, d={d}, {evals} evaluations, one GPU"}
-  modes = (("auto", 10), ("generic", 3)) if gar == "bulyan" else (("auto", 10), ("host", 10), ("generic", 3))  # (Bulyan: "auto" IS the host's cursor)
+  modes = (("auto", 10), ("host", 10), ("generic", 3))
   for mode, reps in modes:
     runner = AggregationStep(n, f, f, gar=gar, attack_evals=evals, line_search=mode, nb_past=0)
     runner._search_factor(honests, avg, direction)
@@ -946,6 +948,12 @@ def search_legs(bm, honests, avg, direction, n, f, gar, evals, reps=10):
     t4 = time.perf_counter()
     if gar == "krum":  # the same candidates by one workgroup where the matrix is (what line_search="auto" runs)
       stats.attack_search_device(sq, h, k, f, "krum", evals=evals)
+      torch.cuda.synchronize()
+    else:  # Bulyan: the same rankings by one workgroup each, the factor in device memory (bm_attack_ranking_device)
+      where = torch.tensor([0.75], dtype=torch.float64, device=sq.device)
+      t4 = time.perf_counter()
+      for e in range(evals):
+        stats.attack_ranking_device(sq, h, k, f, "bulyan", where)
       torch.cuda.synchronize()
     t5 = time.perf_counter()
     for key, dt in zip(legs, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
