@@ -927,6 +927,7 @@ def search_legs(bm, honests, avg, direction, n, f, gar, evals, reps=10):
   k = n - h
   unit = torch.empty_like(avg)
   pinned = torch.empty((h + 2, h + 2), dtype=torch.float64, pin_memory=True)
+  where = torch.tensor([0.75], dtype=torch.float64, device=avg.device)
   legs = {"distance_pass_ms": [], "d2h_pageable_ms": [], "d2h_pinned_ms": [], "host_search_ms": [], "device_search_ms": []}
   for _ in range(reps):
     torch.cuda.synchronize()
@@ -950,8 +951,6 @@ def search_legs(bm, honests, avg, direction, n, f, gar, evals, reps=10):
       stats.attack_search_device(sq, h, k, f, "krum", evals=evals)
       torch.cuda.synchronize()
     else:  # Bulyan: the same rankings by one workgroup each, the factor in device memory (bm_attack_ranking_device)
-      where = torch.tensor([0.75], dtype=torch.float64, device=sq.device)
-      t4 = time.perf_counter()
       for e in range(evals):
         stats.attack_ranking_device(sq, h, k, f, "bulyan", where)
       torch.cuda.synchronize()
