@@ -101,16 +101,16 @@ __device__ __forceinline__ double butterfly_sum(double v) {
 // at the phase boundaries of every candidate behind the results — out[1 + 2 evals + (2 e + wave) * kTraceSlots + slot],
 // cycles since the kernel started (scripts/search_kernel_probe.py prints them).
 constexpr int kTraceSlots = 12;
-template <bool TRACE>
+template <bool TRACE, bool RANKING = false>
 __global__ __launch_bounds__(kSearchBlock) void attack_search_kernel(const double* __restrict__ ext, int h, int k, int f,
                                                                      int rule, int m, int evals, int negative,
                                                                      double* __restrict__ out, const double* __restrict__ t_dev,
                                                                      int32_t* __restrict__ order_out, int take_arg) {
-  // RANKING MODE (order_out != null; bm_attack_ranking_device): ONE candidate, its factor read from device memory, and
+  // RANKING MODE (the RANKING instance; bm_attack_ranking_device): ONE candidate, its factor read from device memory, and
   // instead of the objective the stable ranking of the n scores — order_out[r] = the row of rank r, padded with zeros to
   // 64 entries: what bm_krum_rank would give for honests + [avg + t att] * k (Bulyan's searches rank with it; take_arg =
   // the number of distances a score adds, m for Bulyan's ranking, bulyan.py:48-62).
-  const bool ranking = order_out != nullptr;
+  constexpr bool ranking = RANKING;  // (its own instance: the search instances carry none of it)
   const unsigned long long clock0 = TRACE ? __builtin_amdgcn_s_memtime() : 0ull;
   extern __shared__ double search_smem[];
   const int n = h + k, e = h + 2, tid = threadIdx.x, ld = search_ld(h);
@@ -280,9 +280,20 @@ __global__ __launch_bounds__(kSearchBlock) void attack_search_kernel(const doubl
 #pragma unroll
         for (int q = 0; q < kSearchWaves; ++q) rank += PART[q * BM_MAX_ROWS + (lane < n ? lane : 0)];
         selected = __builtin_amdgcn_ballot_w64(lane < n && rank < m);  // krum.py:78-80: the m best scores
-        if (ranking) {  // (the ranks of the n rows are a permutation of 0 .. n-1 — unless a score is NaN: zeros first, then the rows)
-          order_out[lane] = 0;
-          if (lane < n && rank < BM_MAX_ROWS) order_out[rank] = lane;
+        if (ranking) {
+          // slot r names the row of rank r: the permutation is inverted through LDS (SC is free — every wave read its
+          // scores before the last barrier), so that every entry of order_out is written once, by its own lane.  (The
+          // ranks of the n rows are a permutation of 0 .. n-1 unless a score is NaN: a slot nobody claims reads 0.)
+          int* const inv = reinterpret_cast<int*>(SC);
+          inv[lane] = 0;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          if (lane < n && rank < BM_MAX_ROWS) inv[rank] = lane;
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          order_out[lane] = lane < n ? inv[lane] : 0;
         }
       }
       stamp(ev, 6);
@@ -404,7 +415,7 @@ extern "C" int bm_attack_ranking_device(const double* ext, int h, int k, int f, 
   if (m < 1 || m > n) return BM_EINVAL;
   const int take = mode == BM_RANK_KRUM ? n - f - 1 : m;
   const size_t lds = search_lds_bytes(h);
-  auto kernel = attack_search_kernel<false>;
+  auto kernel = attack_search_kernel<false, true>;
   const int rc = lds_opt_in(reinterpret_cast<const void*>(kernel), lds, 0);
   if (rc != 0) return rc;
   hipLaunchKernelGGL(kernel, dim3(1), dim3(kSearchBlock), lds, static_cast<hipStream_t>(stream), ext, h, k, f, (int)BM_RULE_KRUM,

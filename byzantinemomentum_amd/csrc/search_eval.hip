@@ -17,6 +17,12 @@
 //
 // Instances: n = h + k in {11, 25, 51} (the worker counts of reproduce.py:122-209, reproduce-appendix.py:109), any
 // split into honest rows and copies; other shapes take the generic form (bm_colwise_eval_supported says which).
+//
+// Also here, for the other searches (ABI 22): the median's own — its candidates are the middle of (lo, hi, candidate),
+// lo / hi two order statistics of the honest rows formed once per search by order_pair_kernel and every candidate one
+// launch of colwise_eval_kernel<3, MEDIAN> — and sqdist2_kernel, the objective |rule - avg|^2 of a candidate whose rule
+// ran in full (Aksel, CGE, Brute, any rule through the generic form).  Bulyan's evaluate-only second pass lives next to
+// the pass it mirrors (bulyan.hip, bm_bulyan_pass2_eval).
 #include "colwise_kernels.h"
 
 namespace bm {

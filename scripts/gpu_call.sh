@@ -168,6 +168,21 @@ case $name in
     timeout 900 python -m pytest tests/test_gpu_parity_r3.py tests/test_gpu_parity.py tests/test_gpu_parity_r2.py -m gpu -x -q -k "bulyan" > $out/pytest_bulyan.log 2>&1; tail -3 $out/pytest_bulyan.log
     timeout 600 python scripts/bulyan_search_probe.py 2>&1 | grep -v amdgpu.ids > $out/bulyan_search_probe.txt; cat $out/bulyan_search_probe.txt | cut -c1-400
     ;;
+  libab)  # the in-tree library against the kernels of the ABI 22 tree (scratch/old/libbm_gar_abi22_kernels.so: scratch/abi22/build.py), whole default bench lines alternating
+    for side in new old new old; do
+      lib=""; [ $side = old ] && lib=scratch/old/libbm_gar_abi22_kernels.so
+      BM_GAR_LIB=$lib timeout 600 python bench.py --no-cpu-baseline --no-traffic > $out/bench_${side}_$(date +%s).json 2>> $out/bench.err
+    done
+    OUT=$out python - <<'PY' | tee $out/summary.txt
+import glob, json, os
+for path in sorted(glob.glob(os.environ["OUT"] + "/bench_*.json"), key=lambda p: p.split("_")[-1]):
+  b = json.load(open(path)); pg = b["per_gar"]; k = pg["krum_c3"]
+  print(path.split("/")[-1][:9], "agg/s %.0f | krum_c3 med %.3f avg %.3f dist %.3f | slab %.3f | m1 %.3f | brute_c3 %.3f | bulyan_c4 %.3f | step_krum %.3f | step_median %.3f | search_krum %.3f" % (
+    b["value"], k["median_ms"], k["avg_ms"], k["distance_pass_ms"], pg["krum_c3_slab_rows"]["median_ms"], pg["krum_c3_m1"]["median_ms"],
+    pg["brute_c3"]["median_ms"], pg["bulyan_c4_1gpu"]["median_ms"], pg["step_c5_krum"]["median_ms"], pg["step_c5_median"]["median_ms"],
+    pg["attack_search_c3_krum"]["scalar_form_ms"]))
+PY
+    ;;
   searchprobe)   # the search kernel alone: warm / cold, 1-64 evaluations
     timeout 300 python scripts/search_kernel_probe.py 2>&1 | grep -v amdgpu.ids > $out/search_kernel_probe.txt; cat $out/search_kernel_probe.txt
     ;;
