@@ -157,11 +157,17 @@ class KernelTimer:
     each = sorted(a.elapsed_time(b) for a, b in ps)
     out = Milliseconds(sum(each) / len(each))
     out.median = each[len(each) // 2]
+    out.slowest = each[-1]
+    out.held_up = sum(1 for v in each if v > 3.0 * out.median)  # calls that took more than three times the median call
+    out.calls = len(each)
     return out
 
 
 class Milliseconds(float):
   median = None
+  slowest = None
+  held_up = None
+  calls = None
 
 
 def entry(ms, nbytes, gpus=1, units=1, **more):
@@ -172,6 +178,8 @@ def entry(ms, nbytes, gpus=1, units=1, **more):
   median = getattr(ms, "median", None)
   if median:  # the same figures on the median call (robust against a host that stalls between two launches)
     rec.update(median_ms=median, frac_of_8TBps_median=nbytes / median / 1e6 / (HBM_PEAK_GBPS * gpus))
+    if getattr(ms, "held_up", None):  # why `avg_ms` and `median_ms` disagree: a call or two held up on the host
+      rec.update(held_up_calls=ms.held_up, timed_calls=ms.calls, slowest_ms=ms.slowest)
   return dict(rec, **more)
 
 
