@@ -982,6 +982,20 @@ def search_legs(bm, honests, avg, direction, n, f, gar, evals, reps=10):
   return out
 
 
+def gpu_wake(device, ms=250.0):
+  """Keep the GPU busy for `ms` before a timed series that follows a long idle stretch of this process (the CPU baselines
+  and the PMC child runs of a default run: 20-60 s).  In 3 of 11 default runs of round 6 the first series after them —
+  `krum_c3`, behind its three warm-up calls, 2 ms — ran 10 % slow with one call held up ~40 ms, and nothing after it
+  did; the same series without the idle stretch in front never did (profiles/r06_abi23_library_ab.txt).  Untimed."""
+  x = torch.empty(1 << 24, device=device)
+  t0 = time.perf_counter()
+  while (time.perf_counter() - t0) * 1e3 < ms:
+    for _ in range(20):
+      x.mul_(1.0)
+    torch.cuda.synchronize()
+  del x
+
+
 def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
   """C3, C4 (one GPU) and C5 in a few iterations each: the driver-run record then carries every
   single-GPU configuration of BASELINE.json, not only the headline one."""
@@ -989,6 +1003,7 @@ def extras_single_gpu(bm, device, timer, aliased, cpu_baseline=False):
   global SEPARATE_ROWS
   out = {}
   d = D_RESNET18
+  gpu_wake(device)
   c3_sample = c4_sample = None
   for name, n, f in (("krum_c3", 51, 12), ("bulyan_c4_1gpu", 25, 5)):
     m = n - f - 2

@@ -171,7 +171,7 @@ case $name in
   libab)  # the in-tree library against the kernels of the ABI 22 tree (scratch/old/libbm_gar_abi22_kernels.so: scratch/abi22/build.py), whole default bench lines alternating
     for side in new old new old; do
       lib=""; [ $side = old ] && lib=scratch/old/libbm_gar_abi22_kernels.so
-      BM_GAR_LIB=$lib timeout 600 python bench.py --no-cpu-baseline --no-traffic > $out/bench_${side}_$(date +%s).json 2>> $out/bench.err
+      BM_GAR_LIB=$lib timeout 600 python bench.py ${LIBAB_FLAGS---no-cpu-baseline --no-traffic} > $out/bench_${side}_$(date +%s).json 2>> $out/bench.err
     done
     OUT=$out python - <<'PY' | tee $out/summary.txt
 import glob, json, os
