@@ -116,7 +116,9 @@ def child(args):
                          aggregator=ShardedAggregator(local_only=True))
   params, origin = torch.randn(d, generator=gen).to(dev), torch.randn(d, generator=gen).to(dev)
   searchers = {"mediansearch": AggregationStep(N, F, F, gar="median", attack_evals=16, nb_past=0),
-               "akselsearch": AggregationStep(N, F, F, gar="aksel", attack_evals=16, nb_past=0)}
+               "akselsearch": AggregationStep(N, F, F, gar="aksel", attack_evals=16, nb_past=0),
+               # ABI 23: every candidate ranked by one workgroup from the factor in device memory, pass 2 evaluate only
+               "bulyansearch": AggregationStep(N, F, F, gar="bulyan", attack_evals=16, nb_past=0)}
   kinds = args.kinds.split(",")
   stats = {k: {"launch_sets": 0, "transient": 0, "first_launch_wrong": 0, "wrong_words": 0} for k in kinds + ["step"]}
   ranked_now = lambda rws, ordr, cols: [[float(rws[r][j]) for r in ordr[:MMAX].tolist()] for j in cols]
@@ -146,7 +148,7 @@ def child(args):
         unit = torch.empty_like(avg_)
         bm.stats.multi_fma3([unit], [avg_], [att], 1.0, 1.0)
         return bm.stats.attack_search_device(gars.pairwise_sqdist(rows[:h] + [avg_, unit]), h, F, F, "krum", evals=16)
-      if kind in ("mediansearch", "akselsearch"):
+      if kind in ("mediansearch", "akselsearch", "bulyansearch"):
         # ABI 22: the median's search (bm_order_pair once, then 16 x [cursor, bm_colwise_eval on (lo, hi, candidate)]), resp. a
         # search in the generic form (candidate written, rule, bm_sqdist2) — factor and all 16 (abscissa, objective) pairs
         avg_, _, att = bm.stats.stack_stats_async(rows[:h], scale=1.0, attack="empire", direction=True)
