@@ -183,6 +183,29 @@ for path in sorted(glob.glob(os.environ["OUT"] + "/bench_*.json"), key=lambda p:
     pg["attack_search_c3_krum"]["scalar_form_ms"]))
 PY
     ;;
+  searchpmc)  # HBM traffic of the search kernels of ABI 22 / 23: FETCH_SIZE and WRITE_SIZE passes (their own runs, --kernel-trace only)
+    timeout 200 python scripts/search_kernels_pmc_probe.py 2>&1 | grep -v amdgpu.ids > $out/algorithmic.txt; cat $out/algorithmic.txt
+    for counter in FETCH_SIZE WRITE_SIZE; do
+      timeout 300 rocprofv3 --pmc $counter --kernel-trace --output-format csv -d $out/pmc_$counter -o pmc -- python scripts/search_kernels_pmc_probe.py > $out/pmc_$counter.log 2>&1
+    done
+    OUT=$out python - <<'PY' | tee $out/traffic.txt
+import collections, csv, glob, os
+vals = collections.defaultdict(lambda: collections.defaultdict(list))
+for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+  for path in glob.glob(os.environ["OUT"] + f"/pmc_{counter}/**/*counter_collection.csv", recursive=True):
+    per = collections.defaultdict(float); names = {}
+    for r in csv.DictReader(open(path)):
+      if r["Counter_Name"] == counter:
+        per[r["Dispatch_Id"]] += float(r["Counter_Value"]); names[r["Dispatch_Id"]] = r["Kernel_Name"]
+    for disp, v in per.items():
+      vals[names[disp]][counter].append(v)
+for kern, c in sorted(vals.items()):
+  if any(key in kern for key in ("order_pair_kernel<25, 4", "colwise_eval_kernel<3, 0, 4", "sqdist2_kernel<4", "bulyan_pass2_eval_kernel<25, 5, 4")):
+    fetch = sum(c["FETCH_SIZE"]) / max(len(c["FETCH_SIZE"]), 1); write = sum(c["WRITE_SIZE"]) / max(len(c["WRITE_SIZE"]), 1)
+    print(f"{kern[:70]:70s} launches {len(c['FETCH_SIZE'])}  FETCH_SIZE {fetch:.0f} KiB  WRITE_SIZE {write:.0f} KiB  HBM bytes = 1024 * (2 * FETCH + WRITE) = {1024 * (2 * fetch + write):.0f}")
+PY
+    find $out -name "*counter_collection.csv" -size +5M -delete
+    ;;
   searchprobe)   # the search kernel alone: warm / cold, 1-64 evaluations
     timeout 300 python scripts/search_kernel_probe.py 2>&1 | grep -v amdgpu.ids > $out/search_kernel_probe.txt; cat $out/search_kernel_probe.txt
     ;;
