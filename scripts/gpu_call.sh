@@ -206,6 +206,13 @@ for kern, c in sorted(vals.items()):
 PY
     find $out -name "*counter_collection.csv" -size +5M -delete
     ;;
+  searchtrace)  # kernel trace of the searches against Bulyan and the median (what each launch of a candidate costs)
+    for probe in bulyan_search_probe cursor_forms_probe; do
+      timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace_$probe -o trace -- python scripts/$probe.py > $out/$probe.log 2>&1
+      f=$(find $out/trace_$probe -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $out/${probe}_kernel_stats.csv && head -14 $out/${probe}_kernel_stats.csv | cut -c1-170
+      find $out/trace_$probe -name "*kernel_trace.csv" -size +20M -delete
+    done
+    ;;
   searchprobe)   # the search kernel alone: warm / cold, 1-64 evaluations
     timeout 300 python scripts/search_kernel_probe.py 2>&1 | grep -v amdgpu.ids > $out/search_kernel_probe.txt; cat $out/search_kernel_probe.txt
     ;;
