@@ -141,3 +141,26 @@ def test_self_spawn_spells_the_length_flag_so_that_the_launcher_leaves_it_alone(
     assert bench.parse.__call__ is not None
     monkeypatch.setattr(sys, "argv", ["bench.py", *tail])
     assert bench.parse().d == 1000 and bench.parse().gpus == 2
+
+
+def test_entries_name_their_held_up_calls():
+  """per_gar records: mean and median ride along, and a record whose mean a held-up call pulled away from its median
+  says so (`held_up_calls`, `timed_calls`, `slowest_ms`) — a record without one carries none of the three."""
+  bench = load_bench()
+
+  class FakeEvent:
+    def __init__(self, ms):
+      self.ms = ms
+
+    def elapsed_time(self, other):
+      return other.ms
+
+  timer = bench.KernelTimer()
+  timer.pairs["calm"] = [(FakeEvent(0.0), FakeEvent(v)) for v in (0.70, 0.69, 0.71, 0.70, 0.72, 0.68)]
+  timer.pairs["stalled"] = [(FakeEvent(0.0), FakeEvent(v)) for v in (0.70, 0.69, 40.0, 0.70, 0.72, 0.68, 0.71, 0.69, 0.70, 0.73, 0.70, 0.69)]
+  calm = bench.entry(timer.mean_ms("calm"), 4 * 10**9)
+  assert abs(calm["avg_ms"] - 0.70) < 1e-9 and calm["median_ms"] == 0.70 and "held_up_calls" not in calm and "slowest_ms" not in calm
+  stalled = bench.entry(timer.mean_ms("stalled"), 4 * 10**9)
+  assert stalled["held_up_calls"] == 1 and stalled["timed_calls"] == 12 and stalled["slowest_ms"] == 40.0
+  assert stalled["median_ms"] == 0.70 and stalled["avg_ms"] > 3.9
+  assert stalled["frac_of_8TBps_median"] > 0.7 > 0.2 > stalled["frac_of_8TBps"]
